@@ -1,0 +1,286 @@
+"""Seeded synthetic pocket-ligand complexes at the BASELINE.json shapes.
+
+There is no network (no PDB/SDF corpora, no checkpoint), so benchmarks and
+parity tests run on synthetic complexes whose tensors follow the reference's
+data contract exactly (produced in the reference by
+druglib/datasets/Docking/{pocket_pipeline,mol_pipeline,struct_init,formatting}.py):
+
+* pocket: residues with random aatype placed on a jittered lattice inside a
+  ball (protein-like heavy-atom density => ~10 neighbours within 4 A), random
+  backbone frames, per-residue template frames = AF2 literature tables
+  (diffbindfr_amd/data/residue_tables.npz) with a small perturbation of the
+  rigid-group positions so per-residue templates are really exercised;
+* ligand: random tree with a few ring closures, 1.5 A bonds, bond list in both
+  directions sorted by src*N+dst (druglib/utils/obj/ligand.py:568-570), rotatable
+  bonds by bridge analysis (druglib/datasets/Docking/utils.py:47-92);
+* pose initialisation like LigInit / SCProtInit
+  (druglib/datasets/Docking/struct_init.py:24-53,115-136).
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+_TABLES = None
+
+
+def residue_tables():
+    global _TABLES
+    if _TABLES is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "residue_tables.npz")
+        _TABLES = {k: v for k, v in np.load(path).items()}
+    return _TABLES
+
+
+# BASELINE.json configs -> generator sizes
+CONFIGS = {
+    1: dict(name="single-3dbs-shape", n_complex=1, poses=4, n_atoms=866, n_lig=35),
+    2: dict(name="posebusters-shape", n_complex=128, poses=40, n_atoms=200, n_lig=30),
+    3: dict(name="forward-screen", n_complex=10000, poses=40, n_atoms=200, n_lig=30, shared="receptor"),
+    4: dict(name="reverse-fishing", n_complex=2000, poses=40, n_atoms=200, n_lig=30, shared="ligand"),
+    5: dict(name="large-pocket", n_complex=64, poses=40, n_atoms=600, n_lig=80),
+}
+
+
+def _rand_rot(rng):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _rodrigues(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+
+def build_atom14_np(seq, transl, rots, default_frame, rigid_pos, torsion_angle, a14_to_group):
+    """numpy mirror of the side-chain rebuild (used only to initialise poses)."""
+    N = seq.shape[0]
+    ang = np.concatenate([np.zeros((N, 1)), torsion_angle[:, 1:]], 1)  # frames 4..7 use chi1..4
+    R8 = np.tile(np.eye(3), (N, 8, 1, 1))
+    t8 = np.zeros((N, 8, 3))
+    psi = torsion_angle[:, 0]
+
+    def rx(a):
+        r = np.tile(np.eye(3), (a.shape[0], 1, 1))
+        r[:, 1, 1], r[:, 1, 2], r[:, 2, 1], r[:, 2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+        return r
+
+    Rd, td = default_frame[:, :, :3, :3], default_frame[:, :, :3, 3]
+    R8[:, 3], t8[:, 3] = Rd[:, 3] @ rx(psi), td[:, 3]
+    R8[:, 4], t8[:, 4] = Rd[:, 4] @ rx(ang[:, 1]), td[:, 4]
+    for k in (5, 6, 7):
+        Rk = Rd[:, k] @ rx(ang[:, k - 3])
+        R8[:, k] = R8[:, k - 1] @ Rk
+        t8[:, k] = t8[:, k - 1] + np.einsum("nij,nj->ni", R8[:, k - 1], td[:, k])
+    Rg = np.einsum("nij,nkjl->nkil", rots, R8)
+    tg = transl[:, None] + np.einsum("nij,nkj->nki", rots, t8)
+    grp = a14_to_group[seq]
+    Ra = np.take_along_axis(Rg, grp[:, :, None, None], 1)
+    ta = np.take_along_axis(tg, grp[:, :, None], 1)
+    return np.einsum("naij,naj->nai", Ra, rigid_pos) + ta
+
+
+def make_pocket(rng, n_atoms_target):
+    T = residue_tables()
+    seq, natoms = [], 0
+    while natoms < n_atoms_target:
+        aa = int(rng.integers(0, 20))
+        seq.append(aa)
+        natoms += int(T["atom14_mask"][aa].sum())
+    seq = np.asarray(seq, np.int64)
+    N = len(seq)
+    # jittered lattice of CA positions in a ball; ~130 A^3 per residue (protein-like)
+    spacing = 5.2
+    R = (N * spacing ** 3 * 3 / (4 * np.pi)) ** (1 / 3) + 1.0
+    g = np.arange(-np.ceil(R / spacing), np.ceil(R / spacing) + 1) * spacing
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    pts = pts[np.argsort(np.linalg.norm(pts, axis=1) + 1e-3 * rng.random(len(pts)))][:N]
+    transl = pts + rng.normal(0, 0.6, size=(N, 3))
+    transl -= transl.mean(0, keepdims=True)            # Decentration: CA-centred
+    rots = np.stack([_rand_rot(rng) for _ in range(N)])
+    mask14 = T["atom14_mask"][seq].astype(bool)
+    default_frame = T["default_frame"][seq].copy()
+    rigid_pos = T["atom14_lit_pos"][seq] + rng.normal(0, 0.03, size=(N, 14, 3)) * mask14[..., None]
+    chi_mask = T["chi_mask"][seq].astype(bool)
+    # compacted atom indexing + pocket_node_feature (pocket_pipeline.py:224-262)
+    node_idx = np.zeros((N, 14), np.int64)
+    node_idx[mask14] = np.arange(mask14.sum())
+    a37 = T["atom14_to_atom37"][seq]
+    feat14 = np.stack([a37, T["atom37_to_coarse"][a37], T["atom37_to_element"][a37],
+                       np.repeat(seq[:, None], 14, 1), (np.arange(14)[None] < 4).repeat(N, 0)], -1).astype(np.float32)
+    feat14 = feat14 * mask14[..., None]
+    tors = T["torsion_edges"][seq]                                   # [N,4,2] atom14 ids
+    tors = np.take_along_axis(node_idx[:, None, :].repeat(4, 1), tors, 2) * chi_mask[..., None]
+    return dict(sequence=seq, backbone_transl=transl.astype(np.float32), backbone_rots=rots.astype(np.float32),
+                default_frame=default_frame.astype(np.float32), rigid_group_positions=rigid_pos.astype(np.float32),
+                atom14_mask=mask14, sc_torsion_edge_mask=chi_mask, torsion_edge_index=tors.astype(np.int64),
+                pocket_node_feature=feat14[mask14], n_atoms=int(mask14.sum()))
+
+
+def _components_without(adj, n, u, v):
+    """Component containing v after removing edge u-v (iterative DFS)."""
+    seen = np.zeros(n, bool)
+    stack = [v]
+    seen[v] = True
+    while stack:
+        a = stack.pop()
+        for b in adj[a]:
+            if (a == v and b == u) or (a == u and b == v):
+                continue
+            if not seen[b]:
+                seen[b] = True
+                stack.append(b)
+    return seen
+
+
+def make_ligand(rng, n):
+    pos = np.zeros((n, 3))
+    deg = np.zeros(n, int)
+    bonds = set()
+    for i in range(1, n):
+        for _ in range(200):
+            p = int(rng.integers(max(0, i - 6), i))
+            if deg[p] >= 3:
+                continue
+            d = rng.standard_normal(3)
+            cand = pos[p] + 1.5 * d / np.linalg.norm(d)
+            dist = np.linalg.norm(pos[:i] - cand, axis=1)
+            dist[p] = 9.0
+            if dist.min() > 1.9:
+                break
+        pos[i] = cand
+        bonds.add((p, i))
+        deg[p] += 1
+        deg[i] += 1
+    # ring closures: ~7% extra bonds between close, non-bonded, low-degree atoms
+    D = np.linalg.norm(pos[:, None] - pos[None], axis=-1)
+    cand = [(D[a, b], a, b) for a in range(n) for b in range(a + 3, n)
+            if D[a, b] < 2.8 and deg[a] < 4 and deg[b] < 4 and (a, b) not in bonds]
+    cand.sort()
+    for _, a, b in cand[: max(1, int(round(0.07 * n)))]:
+        if deg[a] < 4 and deg[b] < 4:
+            bonds.add((a, b))
+            deg[a] += 1
+            deg[b] += 1
+    und = sorted(bonds)
+    adj = [[] for _ in range(n)]
+    for a, b in und:
+        adj[a].append(b)
+        adj[b].append(a)
+    directed = sorted([(a, b) for a, b in und] + [(b, a) for a, b in und], key=lambda e: e[0] * n + e[1])
+    ei = np.asarray(directed, np.int64).T
+    E = ei.shape[1]
+    tor_mask = np.zeros(E, bool)
+    rot_masks = []
+    for k, (u, v) in enumerate(directed):
+        comp_v = _components_without(adj, n, u, v)
+        if comp_v[u]:
+            continue                      # not a bridge
+        nv = int(comp_v.sum())
+        small_is_v = nv < n - nv or (nv == n - nv and v < u)
+        if small_is_v and nv > 1:
+            tor_mask[k] = True
+            rot_masks.append(comp_v.copy())
+    rot = np.asarray(rot_masks, bool) if rot_masks else np.zeros((0, n), bool)
+    feat = np.zeros((E, 10), np.float32)
+    kind = rng.integers(0, 4, size=len(und))
+    flags = rng.integers(0, 2, size=(len(und), 4))
+    lut = {e: i for i, e in enumerate(und)}
+    for k, (u, v) in enumerate(directed):
+        i = lut[(min(u, v), max(u, v))]
+        feat[k, kind[i]] = 1.0
+        feat[k, 6:] = flags[i]
+    node = np.clip(rng.standard_normal((n, 27)), -3, 3).astype(np.float32)
+    node[:, 13:] = (node[:, 13:] > 0.8)            # ring-size / pharmacophore flags are 0/1
+    return dict(lig_pos_ref=pos.astype(np.float32), lig_edge_index=ei, lig_edge_feat=feat,
+                tor_edge_mask=tor_mask, rot_node_mask=rot, lig_node=node, n_lig=n)
+
+
+def init_pose(rng, pocket, lig, tr_sigma=10.0):
+    """LigInit + SCProtInit (struct_init.py:24-53,115-136)."""
+    T = residue_tables()
+    pos = lig["lig_pos_ref"].astype(np.float64).copy()
+    bonds = lig["lig_edge_index"].T[lig["tor_edge_mask"]]
+    for k, (u, v) in enumerate(bonds):
+        ang = rng.uniform(-np.pi, np.pi)
+        m = lig["rot_node_mask"][k]
+        Rm = _rodrigues(pos[u] - pos[v], ang)
+        pos[m] = (pos[m] - pos[v]) @ Rm.T + pos[v]
+    pos = (pos - pos.mean(0, keepdims=True)) @ _rand_rot(rng).T + rng.normal(0, tr_sigma, size=(1, 3))
+    N = pocket["sequence"].shape[0]
+    tor = np.zeros((N, 5))
+    tor[:, 0] = rng.uniform(-np.pi, np.pi, size=N)                       # psi (from the input structure)
+    tor[:, 1:] = rng.uniform(-np.pi, np.pi, size=(N, 4)) * pocket["sc_torsion_edge_mask"]
+    a14 = build_atom14_np(pocket["sequence"], pocket["backbone_transl"].astype(np.float64),
+                          pocket["backbone_rots"].astype(np.float64), pocket["default_frame"].astype(np.float64),
+                          pocket["rigid_group_positions"].astype(np.float64), tor, T["atom14_to_group"])
+    return pos.astype(np.float32), tor.astype(np.float32), a14[pocket["atom14_mask"]].astype(np.float32)
+
+
+def collate(items):
+    """Batch (pocket, ligand, lig_pos, torsion_angle, rec_atm_pos) tuples into the
+    reference's batched layout (formatting.py:6-26 increments; follow_batch)."""
+    cat = lambda xs, dt=None: torch.from_numpy(np.concatenate(xs, 0)) if dt is None else torch.from_numpy(np.concatenate(xs, 0)).to(dt)
+    d = SimpleNamespace()
+    lo, ao = 0, 0
+    ei, tei, lb, ab = [], [], [], []
+    for g, (pk, lg, lp, ta, rp) in enumerate(items):
+        ei.append(lg["lig_edge_index"] + lo)
+        tei.append(pk["torsion_edge_index"] + ao)
+        lb.append(np.full(lg["n_lig"], g, np.int64))
+        ab.append(np.full(pk["n_atoms"], g, np.int64))
+        lo += lg["n_lig"]
+        ao += pk["n_atoms"]
+    P = [it[0] for it in items]
+    L = [it[1] for it in items]
+    d.lig_node = cat([l["lig_node"] for l in L])
+    d.lig_pos = cat([it[2] for it in items])
+    d.lig_edge_index = torch.from_numpy(np.concatenate(ei, 1))
+    d.lig_edge_feat = cat([l["lig_edge_feat"] for l in L])
+    d.tor_edge_mask = cat([l["tor_edge_mask"] for l in L]).long()
+    d.lig_node_batch = torch.from_numpy(np.concatenate(lb))
+    d.pocket_node_feature = cat([p["pocket_node_feature"] for p in P])
+    d.rec_atm_pos = cat([it[4] for it in items])
+    d.rec_atm_pos_batch = torch.from_numpy(np.concatenate(ab))
+    d.sc_torsion_edge_mask = cat([p["sc_torsion_edge_mask"] for p in P])
+    d.torsion_edge_index = torch.from_numpy(np.concatenate(tei, 0))
+    d.backbone_transl = cat([p["backbone_transl"] for p in P])
+    d.backbone_rots = cat([p["backbone_rots"] for p in P])
+    d.default_frame = cat([p["default_frame"] for p in P])
+    d.rigid_group_positions = cat([p["rigid_group_positions"] for p in P])
+    d.torsion_angle = cat([it[3] for it in items])
+    d.sequence = cat([p["sequence"] for p in P])
+    d.atom14_mask = cat([p["atom14_mask"] for p in P])
+    d.rot_node_mask = [torch.from_numpy(l["rot_node_mask"]) for l in L]
+    d.batch = d.lig_node_batch
+    d.num_graphs = len(items)
+    return d
+
+
+def make_batch(cfg_id=2, n_complex=None, poses=None, seed=0, n_atoms=None, n_lig=None):
+    """A collated batch of n_complex x poses graphs of config ``cfg_id`` (sizes may be
+    overridden for small parity cases).  Poses of one complex are consecutive."""
+    c = CONFIGS[cfg_id]
+    n_complex = c["n_complex"] if n_complex is None else n_complex
+    poses = c["poses"] if poses is None else poses
+    n_atoms = c["n_atoms"] if n_atoms is None else n_atoms
+    n_lig = c["n_lig"] if n_lig is None else n_lig
+    shared = c.get("shared")
+    items = []
+    shared_rng = np.random.default_rng(cfg_id * 1000 + 999983 + seed)
+    sp = make_pocket(shared_rng, n_atoms) if shared == "receptor" else None
+    sl = make_ligand(shared_rng, n_lig) if shared == "ligand" else None
+    for ci in range(n_complex):
+        rng = np.random.default_rng([cfg_id * 1000 + ci, seed])
+        # +-10% size jitter around the named sizes so batches are ragged like real data
+        pk = sp or make_pocket(rng, int(round(n_atoms * rng.uniform(0.9, 1.1))))
+        lg = sl or make_ligand(rng, max(4, int(round(n_lig * rng.uniform(0.85, 1.15)))))
+        for _ in range(poses):
+            items.append((pk, lg) + init_pose(rng, pk, lg))
+    return collate(items)

@@ -1,0 +1,37 @@
+"""CPU oracle for the DiffBindFR pose-denoising hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it, and there only as the checker / the timed CPU
+baseline -- never as the thing that is measured as the product or shipped.
+The product path (``diffbindfr_amd``) fails loudly when its HIP library is
+missing; it never falls back to this code.
+
+What it is: an op-for-op PyTorch-CPU (fp32) restatement of the reference
+algorithm, each function citing the reference ``file:line`` it follows
+(paths relative to ``/root/reference``):
+
+* ``e3nn_lite``     -- clean-room restatement of the e3nn 0.5.1 arithmetic the
+                       reference calls (spherical harmonics, Wigner-3j,
+                       FullyConnectedTensorProduct, FullTensorProduct).
+* ``cluster``       -- torch_cluster 1.6.0 ``radius`` / ``radius_graph`` and
+                       torch_scatter 2.1.0 ``scatter`` semantics.
+* ``score_model``   -- ``TensorProductModel.forward`` (tpscore.py:462-759).
+* ``geometry``      -- ligand rigid+torsion update, Kabsch, side-chain rebuild.
+* ``schedule``      -- t/sigma/g schedule, so3 / torus score-norm tables.
+* ``sampler``       -- ``DiffBindFR.sample`` (scFlex.py:124-250).
+
+Pinning status (see DESIGN.md "Oracle"):
+
+* Every function whose reference source imports in the build container
+  (geometry, schedule, embeddings, LayerNorm, bipartite graph, the whole
+  ``tpscore.py`` / ``scFlex.py`` glue) is checked against the reference's own
+  source by ``tests/golden/make_golden.py`` (run in the build container only)
+  and frozen as fixtures under ``tests/golden/``.
+* The e3nn / torch_cluster / torch_scatter arithmetic lives in un-vendored,
+  absent third-party wheels (e3nn==0.5.1, torch-cluster==1.6.0,
+  torch-scatter==2.1.0; reference env.yaml:29-31,51) and the reference holds no
+  tests or golden vectors for it => **parity unpinned at that boundary**: it is
+  restated from the published algorithms and validated by property tests
+  (SE(3) equivariance, Wigner-3j invariance, known-answer values) only.
+"""

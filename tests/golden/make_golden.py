@@ -1,0 +1,297 @@
+"""Generate the golden fixtures under tests/golden/ FROM THE REFERENCE'S OWN SOURCE.
+
+Runs only in the build container (needs /root/reference; see ref_shims.py).
+For every piece of the hot path whose reference source executes here it
+
+  1. runs the reference function on seeded inputs,
+  2. asserts the oracle restatement agrees (this is the oracle's pin), and
+  3. freezes inputs + reference outputs as small .npz fixtures that travel to
+     the GPU box, where tests compare oracle AND HIP path against them.
+
+e3nn / torch_cluster / torch_scatter calls inside the reference are served by
+the oracle's restatements (parity UNPINNED at that boundary, see oracle/__init__).
+
+    python tests/golden/make_golden.py
+"""
+import copy
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import ref_shims  # noqa: E402
+
+ns = ref_shims.load_hot_path()
+from oracle import geometry, sampler, schedule, score_model as sm  # noqa: E402
+from diffbindfr_amd import synthetic  # noqa: E402
+
+ED = ns.EasyDict
+T = synthetic.residue_tables()
+
+
+def npy(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def close(a, b, tol, what):
+    a, b = torch.as_tensor(npy(a)).double(), torch.as_tensor(npy(b)).double()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= tol, f"{what}: oracle vs reference max abs err {err} > {tol}"
+    print(f"  pinned {what:45s} max|d|={err:.2e}")
+
+
+def params_digest(params):
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(k.encode())
+        h.update(npy(params[k]).tobytes())
+    return h.hexdigest()
+
+
+def ref_model_cfg():
+    return ED(dict(
+        task="struct_gen", no_sc_torsion=False,
+        features_dim={"protein_atom": {"feature_list": ((37, 22, 4, 21, 2), 0)},
+                      "ligand_atom": {"node_features": 27, "edge_features": 10}},
+        ns=48, nv=12, sh_lmax=2, lig_cutoff=5, atom_cutoff=4, cross_cutoff=32, dynamic_max_cross=True,
+        center_max_distance=32, atom_max_neighbors=1000, distance_embed_dim=32, time_emb_type="sinusoidal",
+        sigma_embed_dim=32, emb_scale=1000, num_conv_layers=6, use_second_order_repr=False, dropout=0.1,
+        batch_norm=True, scale_by_sigma=True))
+
+
+def batch_to_npz(d):
+    out = {k: npy(v) for k, v in vars(d).items() if torch.is_tensor(v)}
+    for g, m in enumerate(d.rot_node_mask):
+        out[f"rot_node_mask_{g}"] = npy(m)
+    out["num_graphs"] = np.asarray(d.num_graphs)
+    return out
+
+
+# --------------------------------------------------------------------------- 1. geometry
+def golden_geometry():
+    print("[geometry]")
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    aa = torch.randn(16, 3, generator=g)
+    aa[0] = torch.tensor([1e-8, 0.0, 0.0])           # small-angle branch
+    aa[1] = torch.tensor([0.0, 0.0, 0.0]) + 3e-7
+    R_ref = ns.geom.axis_angle_to_rot(aa)
+    close(geometry.axis_angle_to_rot(aa), R_ref, 1e-6, "axis_angle_to_rot")
+    out["aa"], out["aa_rot"] = npy(aa), npy(R_ref)
+
+    A = torch.randn(3, 12, generator=g)
+    Rt = ns.geom.axis_angle_to_rot(torch.tensor([0.3, -1.1, 0.7]))
+    B = Rt @ A + torch.tensor([[1.0], [2.0], [-0.5]]) + 0.05 * torch.randn(3, 12, generator=g)
+    R_ref, t_ref = ns.superimposition.rigid_transform_Kabsch_3D_torch(A, B)
+    R_o, t_o = geometry.kabsch(A, B)
+    close(R_o, R_ref, 1e-6, "kabsch R")
+    close(t_o, t_ref, 1e-6, "kabsch t")
+    out.update(kabsch_A=npy(A), kabsch_B=npy(B), kabsch_R=npy(R_ref), kabsch_t=npy(t_ref))
+
+    # update_batchlig_pos: 3 ligands incl. one with no torsion (tiny ring-only ligand)
+    rng = np.random.default_rng(5)
+    ligs = [synthetic.make_ligand(rng, 14), synthetic.make_ligand(rng, 9), synthetic.make_ligand(rng, 4)]
+    ligs[2]["tor_edge_mask"][:] = False
+    ligs[2]["rot_node_mask"] = np.zeros((0, 4), bool)
+    pk = synthetic.make_pocket(rng, 30)
+    items = [(pk, lg) + synthetic.init_pose(rng, pk, lg) for lg in ligs]
+    d = synthetic.collate(items)
+    n_tor = int(d.tor_edge_mask.sum())
+    tr, rot = torch.randn(3, 3, generator=g), 0.5 * torch.randn(3, 3, generator=g)
+    tor = torch.randn(n_tor, generator=g)
+    tor[1] = 0.0                                        # exercises the ==0 skip
+    ref = ns.conformer.update_batchlig_pos(tr, rot, tor, d.lig_pos, d.lig_edge_index, d.tor_edge_mask,
+                                           d.rot_node_mask, batch=d.lig_node_batch)
+    close(geometry.update_batchlig_pos(tr, rot, tor, d.lig_pos, d.lig_edge_index, d.tor_edge_mask,
+                                       d.rot_node_mask, d.lig_node_batch), ref, 2e-5, "update_batchlig_pos")
+    out.update({f"lig_{k}": v for k, v in batch_to_npz(d).items()
+                if k.startswith(("lig_", "tor_edge", "rot_node"))})
+    out.update(lig_tr=npy(tr), lig_rot=npy(rot), lig_tor=npy(tor), lig_new_pos=npy(ref))
+
+    # build_pdb_from_template: all 20 residue types, perturbed templates, random chi
+    seq = torch.arange(21) % 20
+    N = len(seq)
+    transl = 5 * torch.randn(N, 3, generator=g)
+    rots = ns.geom.axis_angle_to_rot(torch.randn(N, 3, generator=g))
+    dframe = torch.from_numpy(T["default_frame"])[seq].clone()
+    rigid = torch.from_numpy(T["atom14_lit_pos"])[seq] + 0.05 * torch.randn(N, 14, 3, generator=g)
+    ang = (torch.rand(N, 5, generator=g) * 2 - 1) * np.pi
+    tmpl = ED(sequence=seq, backbone_transl=transl, backbone_rots=rots, default_frame=dframe,
+              rigid_group_positions=rigid, torsion_angle=ns.geom.radian2sincos_torch(ang))
+    ref14, _ = ns.prot_math.build_pdb_from_template(tmpl, torch.device("cpu"))
+    o14 = geometry.build_atom14(seq, transl, rots, dframe, rigid, ang, torch.from_numpy(T["atom14_to_group"]).long())
+    close(o14, ref14, 2e-5, "build_pdb_from_template")
+    out.update(sc_seq=npy(seq), sc_transl=npy(transl), sc_rots=npy(rots), sc_default_frame=npy(dframe),
+               sc_rigid=npy(rigid), sc_angle=npy(ang), sc_atom14=npy(ref14))
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
+
+
+# --------------------------------------------------------------------------- 2. embeddings
+def golden_embeddings():
+    print("[embeddings]")
+    g = torch.Generator().manual_seed(12)
+    out = {}
+    t = torch.tensor([1.0, 0.545459, 0.136372, 1e-5])
+    ref = ns.time_emb.sinusoidal_embedding(1000 * t, 32)
+    close(sm.sinusoidal_embedding(1000 * t, 32), ref, 0, "sinusoidal_embedding")
+    out.update(temb_t=npy(t), temb=npy(ref))
+    for stop in (4.0, 5.0, 32.0):
+        gs = ns.schnet.GaussianSmearing(0.0, stop, 32)
+        dist = torch.rand(40, generator=g) * stop * 1.3
+        ref = gs(dist)
+        p = {"x.offset": gs.offset, "x.coeff": gs.coeff}
+        close(sm.gaussian_smearing(p, "x", dist), ref, 0, f"GaussianSmearing stop={stop}")
+        out[f"gs{int(stop)}_d"], out[f"gs{int(stop)}"] = npy(dist), npy(ref)
+    ei, ne = ns.torch_utils.get_complete_bipartite_graph(torch.tensor([2, 3, 2]), torch.tensor([4, 2, 5]))
+    close(sm.complete_bipartite(torch.tensor([2, 3, 2]), torch.tensor([4, 2, 5])), ei, 0, "complete_bipartite")
+    out["bip"] = npy(ei)
+    irreps = "48x0e + 12x1o + 12x1e + 48x0o"
+    ln = ns.tpscore.LayerNorm(irreps)
+    with torch.no_grad():
+        ln.mean_shift += 0.1 * torch.randn(ln.mean_shift.shape, generator=g)
+        ln.affine_weight += 0.1 * torch.randn(ln.affine_weight.shape, generator=g)
+        ln.affine_bias += 0.1 * torch.randn(ln.affine_bias.shape, generator=g)
+        x = torch.randn(7, 168, generator=g)
+        x[3] = 0                                        # isolated node -> all-zero row
+        ref = ln(x)
+    p = {"n.mean_shift": ln.mean_shift.detach(), "n.affine_weight": ln.affine_weight.detach(),
+         "n.affine_bias": ln.affine_bias.detach()}
+    close(sm.layer_norm(p, "n", irreps, x), ref, 0, "equivariant LayerNorm")
+    out.update(ln_x=npy(x), ln_y=npy(ref), ln_mean_shift=npy(p["n.mean_shift"]),
+               ln_weight=npy(p["n.affine_weight"]), ln_bias=npy(p["n.affine_bias"]))
+    np.savez_compressed(os.path.join(HERE, "embeddings.npz"), **out)
+
+
+# --------------------------------------------------------------------------- 3. schedule
+def _exec_prefix(path, stop_marker):
+    src = open(path).read()
+    src = src[: src.index(stop_marker)].replace("from . import io", "")
+    env = {"__name__": "ref_prefix"}
+    exec(compile(src, path, "exec"), env)
+    return env
+
+
+def golden_schedule():
+    print("[schedule]")
+    out = {}
+    scfg = schedule.default_sample_cfg()
+    test_cfg = ED(sample_cfg=ED(vars(scfg)))
+    sampler_ref = ns.scflex.DiffBindFR(diffusion_model=None, test_cfg=test_cfg)
+    sampler_ref.diffusion_model_cfg = ED(no_sc_torsion=False)
+    ts = sampler_ref.t_schedule()
+    close(schedule.t_schedule(scfg), ts, 0, "t_schedule")
+    rows = []
+    for i in range(scfg.actual_steps):
+        t, dt = ts[i], ts[i] - ts[i + 1]
+        s = sampler_ref.sigma_fn(t, t, t, t)
+        sc = schedule.step_scalars(scfg, i)
+        for a, b in zip(s, (sc.tr_sigma, sc.rot_sigma, sc.tor_sigma, sc.sc_tor_sigma)):
+            assert float(a) == float(b)
+        rows.append([float(t), float(dt)] + [float(x) for x in s] + [float(sc.tr_g), float(sc.rot_g), float(sc.tor_g)])
+    out["steps"] = np.asarray(rows, np.float64)
+    # SURVEY Appendix B.4 known-answer spot checks
+    assert abs(rows[0][2] - 6.0) < 1e-5 and abs(rows[19][2] - 0.17478) < 1e-4 and abs(rows[0][6] - 17.16953) < 1e-3
+    so3 = _exec_prefix(os.path.join(ref_shims.COPY, "druglib/utils/geometry_utils/so3.py"), "resource_dir =")
+    eps_arr = 10 ** np.linspace(np.log10(so3["MIN_EPS"]), np.log10(so3["MAX_EPS"]), so3["N_EPS"])
+    om = np.linspace(0, np.pi, so3["X_N"] + 1)[1:]
+    idxs, vals = [952, 613, 309, 0, 999], []
+    for i in idxs:
+        ex = so3["_expansion"](om, eps_arr[i])
+        pdf = so3["_density"](ex, om, marginal=True)
+        scn = so3["_score"](ex, om, eps_arr[i])
+        vals.append(np.sqrt(np.sum(scn ** 2 * pdf) / np.sum(pdf) / np.pi))
+        close(schedule.so3_exp_score_norm(i), vals[-1], 1e-12 * max(1, abs(vals[-1])), f"so3 exp_score_norm[{i}]")
+    out["so3_idx"], out["so3_val"] = np.asarray(idxs), np.asarray(vals)
+    sig = np.array([1.55, 0.25799, 0.05138], np.float32)
+    assert list(schedule.so3_eps_index(sig)) == [952, 613, 309]
+    tor = _exec_prefix(os.path.join(ref_shims.COPY, "druglib/utils/geometry_utils/torus.py"), "resource_dir =")
+    tor["tqdm"] = types.SimpleNamespace(trange=range)
+    tidx = [4467, 2857, 1408, 0, 5000]
+    rows_ref = []
+    for i in tidx:
+        sg = tor["sigma"][i:i + 1]
+        p_ = tor["p"](tor["x"], sg[:, None], N=100)
+        sc_ = tor["grad"](tor["x"], sg[:, None], N=100) / p_
+        rows_ref.append(sc_[0])
+        # oracle's row (recomputed the same way inside torus_score_norm_entry) -> compare via the MC mean
+        np.random.seed(1234)
+        smp = sg[0] * np.random.randn(200000)
+        smp = (smp + np.pi) % (2 * np.pi) - np.pi
+        xs = np.log(np.abs(smp) / np.pi)
+        xs = np.round(np.clip((xs - np.log(tor["X_MIN"])) / (0 - np.log(tor["X_MIN"])) * tor["X_N"], 0, tor["X_N"])).astype(int)
+        big = float((sc_[0][xs] ** 2).mean())
+        mine = schedule.torus_score_norm_entry(i, seed=0)
+        assert abs(mine - big) / big < 0.08, (i, mine, big)
+        print(f"  pinned torus score_norm_[{i}] oracle(10k draws)={mine:.5f} ref-table(200k draws)={big:.5f}")
+    assert list(schedule.torus_sigma_index(np.array([3.14, 0.38712, 0.05884], np.float32))) == [4467, 2857, 1408]
+    out["torus_idx"] = np.asarray(tidx)
+    out["torus_score_rows_head"] = np.asarray([r[::250] for r in rows_ref])
+    out["torus_norm_seed0"] = np.asarray([schedule.torus_score_norm_entry(i, 0) for i in tidx])
+    np.savez_compressed(os.path.join(HERE, "schedule.npz"), **out)
+
+
+# --------------------------------------------------------------------------- 4/5. model + sampler
+def golden_model_and_sampler():
+    print("[score model + sampler]")
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=1)
+    digest = params_digest(params)
+    model = ns.tpscore.TensorProductModel(ref_model_cfg()).eval()
+    sd = model.state_dict()
+    assert sorted(sd) == sorted(params), "state_dict key set differs from the reference module"
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(params[k].shape), k
+    model.load_state_dict(params, strict=True)
+    scfg = schedule.default_sample_cfg()
+    d = synthetic.make_batch(2, n_complex=2, poses=2, seed=3, n_atoms=60, n_lig=10)
+    G = d.num_graphs
+    out = batch_to_npz(d)
+    out["params_seed"], out["params_sha256"] = np.asarray(1), np.asarray(digest)
+    for step in (0, 10, 19):
+        sc = schedule.step_scalars(scfg, step)
+        with torch.no_grad():
+            ref = model(ED(vars(sampler.set_time(copy.deepcopy(d), sc, G))))
+            mine = sm.forward(params, mcfg, sampler.set_time(copy.deepcopy(d), sc, G))
+        for nm, a, b in zip(("tr", "rot", "tor", "sc_tor"), mine, ref):
+            close(a, b, 1e-6, f"score[{nm}] step {step}")
+            out[f"score_{nm}_{step}"] = npy(b)
+
+    # sampler: reference DiffBindFR.sample with the so3/torus tables served by the oracle
+    # (their own import would build GB-sized tables); noise from torch's global generator.
+    go = sys.modules["druglib.utils.geometry_utils"]
+    go.so3 = types.SimpleNamespace(score_norm=schedule.so3_score_norm)
+    go.torus = types.SimpleNamespace(score_norm=lambda s: schedule.torus_score_norm(s, 0))
+    test_cfg = ED(sample_cfg=ED(vars(scfg)))
+    ref_sampler = ns.scflex.DiffBindFR(diffusion_model=None, test_cfg=test_cfg)
+    ref_sampler.diffusion_model_cfg = ED(no_sc_torsion=False)
+    ref_sampler.diffusion_model = model
+    rd = ED({k: (v.clone() if torch.is_tensor(v) else v) for k, v in vars(d).items() if k != "rot_node_mask"})
+    rd.metastore = {"rot_node_mask": [m.clone() for m in d.rot_node_mask]}
+    torch.manual_seed(77)
+    res = ref_sampler.sample(rd, visualize=True)
+    lig_ref = torch.cat([r[0] for r in res], dim=1)            # [T, N_l_total, 3]
+    a14_ref = torch.cat([r[1] for r in res], dim=1)            # [T, N_res_total, 14, 3]
+    n_tor, n_sc = int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum())
+    noise = sampler.draw_noise(scfg.actual_steps, G, n_tor, n_sc, seed=77)
+    lig_o, a14_o = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise,
+                                  torch.from_numpy(T["atom14_to_group"]).long(), torus_seed=0, visualize=True)
+    close(lig_o, lig_ref, 1e-4, "sample(): ligand trajectory (20 steps)")
+    close(a14_o, a14_ref, 1e-4, "sample(): atom14 trajectory (20 steps)")
+    out.update(noise_seed=np.asarray(77), noise_tr=npy(noise.tr), noise_rot=npy(noise.rot), noise_tor=npy(noise.tor),
+               noise_sc=npy(noise.sc), traj_lig=npy(lig_ref), traj_atom14=npy(a14_ref))
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    golden_geometry()
+    golden_embeddings()
+    golden_schedule()
+    golden_model_and_sampler()
+    print("golden fixtures written to", HERE)
