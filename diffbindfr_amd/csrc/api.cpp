@@ -1,0 +1,710 @@
+// libdbfr host side: model packing, workspace planning, kernel orchestration, C ABI (include/dbfr.h).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "common.h"
+
+// ---- kernel launchers (conv.hip / graph.hip / heads.hip)
+void launch_conv(const ConvArgs& a, hipStream_t st);
+void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
+                      const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
+enum SetKind { SET_LL = 0, SET_AA = 1, SET_AL = 2, SET_LA = 3, SET_TOR = 4, SET_SC = 5, N_SETS = 6 };
+struct GraphArgs {
+  dbfr_batch b;
+  const int* lig_batch; const int* atm_batch; const uint8_t* is_cab; const int* n_cab; const float* tr_sigma;
+  float lig_cut2, atom_cut2, cross_cut2;
+  int lig_cap, atom_cap, dynamic_cross;
+  EdgeSet set[N_SETS];
+  int* err;
+};
+void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
+void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
+                          int* tor_batch, int* sc_batch, hipStream_t st);
+void launch_time_embed(const float* t, int G, float emb_scale, float* temb, hipStream_t st);
+enum MlpIn { IN_LIGNODE = 0, IN_LIGEDGE = 1, IN_TG = 2, IN_G = 3 };
+struct MlpArgs {
+  Mlp2 w; int mode; const int* n_rows_dev; int n_rows_max; const float* temb; const int* row_graph_tab; const int* tgt;
+  const int* aux; const float* dist; const float* bond_feat; int nfeat; const float* lig_node; int nnode;
+  const float* gs_offset; const float* gs_coeff; float* out;
+};
+void launch_mlp(const MlpArgs& a, hipStream_t st);
+struct AtomEncArgs {
+  const float* pocket_feat; const int* atm_batch; const float* temb; const float* emb[5]; int dims[5];
+  const float* lin_t; int NA; float* out;
+};
+void launch_atom_encoder(const AtomEncArgs& a, hipStream_t st);
+void launch_center_edges(const dbfr_batch& b, int* tgt, int* gth, float* dist, float* sh, int* row_start, int* row_cnt,
+                         hipStream_t st);
+struct TrRotArgs {
+  const float* gp; const float* temb; const float* tr_sigma; const float* rot_norm; Mlp2 tr, rot; int G;
+  int scale_by_sigma; float* tr_out; float* rot_out; int* err;
+};
+void launch_trrot(const TrRotArgs& a, hipStream_t st);
+void launch_bond_attr(const float* x, int ldx, const int* b0, const int* b1, const int* bsel, int stride, int n,
+                      float* out, hipStream_t st);
+void launch_tor_final(const float* feat, const Mlp2& w, const float* norm2, int scale, int n, float* out, hipStream_t st);
+struct SdeLigArgs {
+  dbfr_batch b; const float* tr_score; const float* rot_score; const float* tor_score; const float* z_tr;
+  const float* z_rot; const float* z_tor; float dt, tr_g2, tr_gsdt, rot_g2, rot_gsdt, tor_g2, tor_gsdt; float* traj;
+  int* err;
+};
+void launch_sde_ligand(const SdeLigArgs& a, hipStream_t st);
+void launch_sidechain(const dbfr_batch& b, const float* score, const float* z, float dt, float g2, float gsdt,
+                      const int* a14_group, float* atom14_out, float* traj14, hipStream_t st);
+void launch_fill(float* p, float v, int n, hipStream_t st);
+void launch_set_int(int* p, int v, hipStream_t st);
+void launch_acc_flops(const int* n_edges, double per_edge, double* counter, hipStream_t st);
+
+// restype_atom14_to_rigid_group (AF2 constant table; reference protein_constants.py:1177, data only)
+static const int kAtom14ToGroup[21 * 14] = {
+    0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 6, 7, 7, 7, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 3, 0, 4, 5, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 6, 6, 0, 0, 0, 0, 0,
+    0, 0, 0, 3, 0, 4, 5, 6, 6, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 0, 0, 0, 0,
+    0, 0, 0, 3, 0, 4, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 6, 7, 0, 0, 0, 0, 0,
+    0, 0, 0, 3, 0, 4, 5, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 5, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 3, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 5, 5, 5, 5,
+    0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 5, 5, 0, 0, 0, 0, 0, 3, 0, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+static thread_local std::string g_err;
+void dbfr_set_error(const std::string& s) { g_err = s; }
+static int fail(int code, const std::string& s) { g_err = s; return code; }
+
+struct dbfr_model {
+  dbfr_model_cfg cfg;
+  std::vector<void*> allocs;
+  ConvW layer[8][4];   // [l][family]: 0 lig, 1 cross_al, 2 atom, 3 cross_la
+  ConvW final_conv, tor_conv, sc_conv;
+  Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
+  Mlp2 tr_final, rot_final, tor_final, sc_final;
+  const float* atom_emb[5]; int atom_dims[5];
+  const float* atom_lin_t;
+  const float *gs_lig_off, *gs_lig_c, *gs_atom_off, *gs_atom_c, *gs_cross_off, *gs_cross_c, *gs_center_off, *gs_center_c;
+  int* a14_group;
+  // profiling of the dominant kernel
+  int profile;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used;
+  double* flops_dev;
+  double conv_ms_acc; int64_t conv_launches_acc;
+};
+
+template <typename T>
+static T* upload(dbfr_model* m, const std::vector<T>& h, int* rc) {
+  void* d = nullptr;
+  size_t bytes = std::max<size_t>(h.size() * sizeof(T), 16);
+  if (hipMalloc(&d, bytes) != hipSuccess) { *rc = DBFR_ERR_HIP; g_err = "hipMalloc failed (model weights)"; return nullptr; }
+  if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+    *rc = DBFR_ERR_HIP; g_err = "hipMemcpy failed (model weights)"; return nullptr;
+  }
+  m->allocs.push_back(d);
+  return (T*)d;
+}
+
+typedef std::map<std::string, const dbfr_tensor*> TMap;
+
+static const float* need(const TMap& tm, const std::string& name, int64_t numel, int* rc) {
+  auto it = tm.find(name);
+  if (it == tm.end()) { *rc = fail(DBFR_ERR_ARG, "missing tensor '" + name + "'"); return nullptr; }
+  if (it->second->numel != numel) {
+    *rc = fail(DBFR_ERR_ARG, "tensor '" + name + "' has " + std::to_string(it->second->numel) + " elements, expected " +
+                                 std::to_string(numel));
+    return nullptr;
+  }
+  return it->second->data;
+}
+
+static int pack_mlp(dbfr_model* m, const TMap& tm, const std::string& name, int in, int hid, int out, bool bias, Mlp2* o) {
+  int rc = 0;
+  const float* w0 = need(tm, name + ".lin.0.weight", (int64_t)hid * in, &rc);
+  const float* w1 = need(tm, name + ".lin.3.weight", (int64_t)out * hid, &rc);
+  const float *b0 = nullptr, *b1 = nullptr;
+  if (bias) { b0 = need(tm, name + ".lin.0.bias", hid, &rc); b1 = need(tm, name + ".lin.3.bias", out, &rc); }
+  if (rc) return rc;
+  std::vector<float> w0t((size_t)in * hid), w1t((size_t)hid * out);
+  for (int h = 0; h < hid; ++h) for (int i = 0; i < in; ++i) w0t[(size_t)i * hid + h] = w0[(size_t)h * in + i];
+  for (int q = 0; q < out; ++q) for (int h = 0; h < hid; ++h) w1t[(size_t)h * out + q] = w1[(size_t)q * hid + h];
+  o->in = in; o->hid = hid; o->out = out;
+  o->w0t = upload(m, w0t, &rc); o->w1t = upload(m, w1t, &rc);
+  o->b0 = o->b1 = nullptr;
+  if (bias) {
+    o->b0 = upload(m, std::vector<float>(b0, b0 + hid), &rc);
+    o->b1 = upload(m, std::vector<float>(b1, b1 + out), &rc);
+  }
+  return rc;
+}
+
+static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int kind, ConvW* o) {
+  ConvSpec sp = make_conv_spec(kind);
+  for (auto& p : sp.paths)
+    if (p.type < 0) return fail(DBFR_ERR_ARG, "unsupported tensor-product path in " + name);
+  const int K = sp.K;
+  int rc = 0;
+  const float* W1 = need(tm, name + ".fc.lin.0.weight", (int64_t)K * K, &rc);
+  const float* B1 = need(tm, name + ".fc.lin.0.bias", K, &rc);
+  const float* W2 = need(tm, name + ".fc.lin.3.weight", (int64_t)sp.W * K, &rc);
+  const float* B2 = need(tm, name + ".fc.lin.3.bias", sp.W, &rc);
+  int nirr = 0, n0e = 0;
+  for (auto& ir : sp.out) { nirr += ir.mul; if (ir.l == 0 && ir.p == 1) n0e += ir.mul; }
+  const float* ms = need(tm, name + ".batch_norm.mean_shift", nirr, &rc);
+  const float* aw = need(tm, name + ".batch_norm.affine_weight", nirr, &rc);
+  const float* ab = need(tm, name + ".batch_norm.affine_bias", n0e, &rc);
+  if (rc) return rc;
+  const int KT = K / 16;
+  // lin.0 in MFMA A-fragment order: [m][s4][lane][q] = W1[16m + (lane&15)][4(4 s4+q) + (lane>>4)]
+  std::vector<float> w1p((size_t)KT * KT * 64 * 4);
+  for (int mt = 0; mt < KT; ++mt)
+    for (int s4 = 0; s4 < KT; ++s4)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int q = 0; q < 4; ++q)
+          w1p[(((size_t)mt * KT + s4) * 64 + lane) * 4 + q] = W1[(size_t)(16 * mt + (lane & 15)) * K + 4 * (4 * s4 + q) + (lane >> 4)];
+  // lin.3 rows permuted to (path, w_out, u_in), each path padded to a multiple of 16 rows
+  struct Row { int orig; float scale; };
+  std::vector<Row> rows;
+  std::vector<uint32_t> quads;
+  for (auto& p : sp.paths) {
+    if (p.mul1 % 4) return fail(DBFR_ERR_ARG, "input multiplicity not a multiple of 4 in " + name);
+    const int d1 = 2 * p.l1 + 1, d_o = 2 * p.lo + 1;
+    size_t start = rows.size();
+    for (int w = 0; w < p.mulo; ++w)
+      for (int u = 0; u < p.mul1; ++u) {
+        if ((u & 3) == 0) {
+          uint32_t xo = p.in_off + u * d1, oo = p.out_off + w * d_o;
+          if (xo > 255 || oo > 255) return fail(DBFR_ERR_ARG, "irreps too wide for the quad descriptor");
+          quads.push_back(xo | (oo << 8) | ((uint32_t)p.type << 16) | ((uint32_t)p.sh_off << 20));
+        }
+        rows.push_back({p.w_off + u * p.mulo + w, p.fold});
+      }
+    while ((rows.size() - start) % 16) {
+      if ((rows.size() & 3) == 0)
+        quads.push_back((uint32_t)p.in_off | ((uint32_t)p.out_off << 8) | ((uint32_t)p.type << 16) | ((uint32_t)p.sh_off << 20));
+      rows.push_back({-1, 0.f});
+    }
+  }
+  const int n_tiles = (int)rows.size() / 16;
+  std::vector<float> w2p((size_t)n_tiles * KT * 64 * 4), b2p((size_t)n_tiles * 16);
+  for (int t = 0; t < n_tiles; ++t) {
+    for (int i = 0; i < 16; ++i) { const Row& r = rows[16 * t + i]; b2p[16 * t + i] = r.orig >= 0 ? r.scale * B2[r.orig] : 0.f; }
+    for (int s4 = 0; s4 < KT; ++s4)
+      for (int lane = 0; lane < 64; ++lane) {
+        const Row& r = rows[16 * t + (lane & 15)];
+        for (int q = 0; q < 4; ++q)
+          w2p[(((size_t)t * KT + s4) * 64 + lane) * 4 + q] =
+              r.orig >= 0 ? r.scale * W2[(size_t)r.orig * K + 4 * (4 * s4 + q) + (lane >> 4)] : 0.f;
+      }
+  }
+  o->K = K; o->D_in = sp.D_in; o->D_out = sp.D_out; o->n_tiles = n_tiles; o->W = sp.W;
+  o->W1p = upload(m, w1p, &rc);
+  o->b1 = upload(m, std::vector<float>(B1, B1 + K), &rc);
+  o->W2p = upload(m, w2p, &rc);
+  o->b2p = upload(m, b2p, &rc);
+  o->quads = upload(m, quads, &rc);
+  LNDesc& ln = o->ln;
+  memset(&ln, 0, sizeof ln);
+  ln.nblk = (int)sp.out.size();
+  int off = 0;
+  for (int i = 0; i < ln.nblk; ++i) {
+    ln.mul[i] = sp.out[i].mul; ln.dim[i] = sp.out[i].dim(); ln.off[i] = off;
+    ln.is0e[i] = sp.out[i].l == 0 && sp.out[i].p == 1;
+    off += ln.mul[i] * ln.dim[i];
+  }
+  ln.mean_shift = upload(m, std::vector<float>(ms, ms + nirr), &rc);
+  ln.weight = upload(m, std::vector<float>(aw, aw + nirr), &rc);
+  ln.bias = upload(m, std::vector<float>(ab, ab + std::max(n0e, 0)), &rc);
+  return rc;
+}
+
+extern "C" int dbfr_abi_version(void) { return DBFR_ABI_VERSION; }
+extern "C" const char* dbfr_last_error(void) { return g_err.c_str(); }
+
+extern "C" int dbfr_wigner3j(int32_t l1, int32_t l2, int32_t l3, double* out) {
+  if (!out || l1 < 0 || l2 < 0 || l3 < 0 || l1 > 4 || l2 > 4 || l3 > 4) return fail(DBFR_ERR_ARG, "bad l");
+  std::vector<double> v;
+  wigner3j_real(l1, l2, l3, v);
+  memcpy(out, v.data(), v.size() * sizeof(double));
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_conv_paths(int32_t kind, int32_t* t10, int32_t max_paths, int32_t* weight_numel) {
+  if (kind < 0 || kind > 5) return fail(DBFR_ERR_ARG, "bad conv kind");
+  ConvSpec sp = make_conv_spec(kind);
+  if (weight_numel) *weight_numel = sp.W;
+  int n = (int)sp.paths.size();
+  for (int i = 0; i < n && i < max_paths && t10; ++i) {
+    const PathDesc& p = sp.paths[i];
+    int32_t* r = t10 + 10 * i;
+    r[0] = p.i1; r[1] = p.i2; r[2] = p.io; r[3] = p.l1; r[4] = p.l2; r[5] = p.lo; r[6] = p.mul1; r[7] = p.mulo; r[8] = p.w_off;
+    memcpy(&r[9], &p.coeff, 4);
+  }
+  return n;
+}
+
+extern "C" int dbfr_model_create(const dbfr_model_cfg* cfg, const dbfr_tensor* tensors, int32_t n_tensors,
+                                 dbfr_model** out) {
+  if (!cfg || !tensors || !out) return fail(DBFR_ERR_ARG, "null argument");
+  if (cfg->ns != NS || cfg->nv != NV || cfg->sh_lmax != 2 || cfg->distance_embed_dim != EMB ||
+      cfg->sigma_embed_dim != EMB || cfg->num_conv_layers < 1 || cfg->num_conv_layers > 8)
+    return fail(DBFR_ERR_ARG, "unsupported model configuration (need ns=48, nv=12, sh_lmax=2, 32-d embeddings)");
+  if (cfg->lig_edge_features + 2 * EMB > 80 || cfg->lig_node_features + EMB > 80)
+    return fail(DBFR_ERR_ARG, "ligand feature width too large");
+  std::string serr;
+  int rc = so3_selftest(serr);
+  if (rc) return fail(rc, serr);
+  TMap tm;
+  for (int i = 0; i < n_tensors; ++i) tm[tensors[i].name] = &tensors[i];
+  dbfr_model* m = new dbfr_model();
+  m->cfg = *cfg;
+  m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
+  const char* fam[4] = {"lig_conv_layers", "cross_al_conv_layers", "atom_conv_layers", "cross_la_conv_layers"};
+  for (int l = 0; l < cfg->num_conv_layers && !rc; ++l)
+    for (int f = 0; f < 4 && !rc; ++f)
+      rc = pack_conv(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), &m->layer[l][f]);
+  if (!rc) rc = pack_conv(m, tm, "final_conv", 4, &m->final_conv);
+  if (!rc) rc = pack_conv(m, tm, "tor_bond_conv", 5, &m->tor_conv);
+  if (!rc && !cfg->no_sc_torsion) rc = pack_conv(m, tm, "sc_tor_bond_conv", 5, &m->sc_conv);
+  if (!rc) rc = pack_mlp(m, tm, "lig_node_embedding", cfg->lig_node_features + EMB, NS, NS, true, &m->lig_node_emb);
+  if (!rc) rc = pack_mlp(m, tm, "lig_edge_embedding", cfg->lig_edge_features + 2 * EMB, NS, NS, true, &m->lig_edge_emb);
+  if (!rc) rc = pack_mlp(m, tm, "atom_edge_embedding", 2 * EMB, NS, NS, true, &m->atom_edge_emb);
+  if (!rc) rc = pack_mlp(m, tm, "la_edge_embedding", 2 * EMB, NS, NS, true, &m->la_edge_emb);
+  if (!rc) rc = pack_mlp(m, tm, "center_edge_embedding", 2 * EMB, NS, NS, true, &m->center_edge_emb);
+  if (!rc) rc = pack_mlp(m, tm, "tor_edge_embedding", EMB, NS, NS, true, &m->tor_edge_emb);
+  if (!rc) rc = pack_mlp(m, tm, "tr_final_layer", 1 + EMB, NS, 1, true, &m->tr_final);
+  if (!rc) rc = pack_mlp(m, tm, "rot_final_layer", 1 + EMB, NS, 1, true, &m->rot_final);
+  if (!rc) rc = pack_mlp(m, tm, "tor_final_layer", 2 * NS, NS, 1, false, &m->tor_final);
+  if (!rc && !cfg->no_sc_torsion) {
+    rc = pack_mlp(m, tm, "sc_edge_embedding", EMB, NS, NS, true, &m->sc_edge_emb);
+    if (!rc) rc = pack_mlp(m, tm, "sc_tor_final_layer", 2 * NS, NS, 1, false, &m->sc_final);
+  }
+  const int dims[5] = {37, 22, 4, 21, 2};
+  for (int i = 0; i < 5 && !rc; ++i) {
+    const float* e = need(tm, "atom_node_embedding.atom_emb_list." + std::to_string(i) + ".weight", (int64_t)dims[i] * NS, &rc);
+    if (!rc) { m->atom_emb[i] = upload(m, std::vector<float>(e, e + dims[i] * NS), &rc); m->atom_dims[i] = dims[i]; }
+  }
+  if (!rc) {
+    const float* w = need(tm, "atom_node_embedding.scalar_lin.weight", (int64_t)NS * (NS + EMB), &rc);
+    if (!rc) {
+      std::vector<float> t((size_t)(NS + EMB) * NS);
+      for (int o = 0; o < NS; ++o) for (int i = 0; i < NS + EMB; ++i) t[(size_t)i * NS + o] = w[(size_t)o * (NS + EMB) + i];
+      m->atom_lin_t = upload(m, t, &rc);
+    }
+  }
+  struct { const char* n; const float** off; const float** c; } gs[4] = {
+      {"lig", &m->gs_lig_off, &m->gs_lig_c}, {"atom", &m->gs_atom_off, &m->gs_atom_c},
+      {"cross", &m->gs_cross_off, &m->gs_cross_c}, {"center", &m->gs_center_off, &m->gs_center_c}};
+  for (int i = 0; i < 4 && !rc; ++i) {
+    const float* off = need(tm, std::string(gs[i].n) + "_distance_expansion.offset", EMB, &rc);
+    const float* c = need(tm, std::string(gs[i].n) + "_distance_expansion.coeff", 1, &rc);
+    if (!rc) { *gs[i].off = upload(m, std::vector<float>(off, off + EMB), &rc); *gs[i].c = upload(m, std::vector<float>(c, c + 1), &rc); }
+  }
+  if (!rc) m->a14_group = upload(m, std::vector<int>(kAtom14ToGroup, kAtom14ToGroup + 21 * 14), &rc);
+  if (!rc) { m->flops_dev = upload(m, std::vector<double>(1, 0.0), &rc); }
+  if (rc) { dbfr_model_destroy(m); return rc; }
+  *out = m;
+  return DBFR_OK;
+}
+
+extern "C" void dbfr_model_destroy(dbfr_model* m) {
+  if (!m) return;
+  for (void* p : m->allocs) (void)hipFree(p);
+  for (auto e : m->ev) (void)hipEventDestroy(e);
+  delete m;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct WsEntry { std::string name; size_t offset, bytes; };
+struct Bump {
+  char* base; size_t off; size_t cap;
+  std::vector<WsEntry>* log;
+  template <typename T> T* take(size_t n, const char* name = nullptr) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    if (log && name) log->push_back({name, off, n * sizeof(T)});
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Ws {
+  int* err; int64_t* counters;
+  int *lig_batch, *atm_batch, *n_cab, *tor_batch, *sc_batch; uint8_t* is_cab;
+  float* temb;
+  float *c_t, *c_tr_sigma, *c_rot_norm, *c_tor_n2, *c_sc_n2;
+  float *s_tr, *s_rot, *s_tor, *s_sc;
+  float *lig_x[2], *atom_x[2];
+  EdgeSet set[N_SETS]; int n_edges_store_dummy;
+  // centre set
+  int *c_tgt, *c_gth, *c_row_start, *c_row_cnt, *c_n; float *c_dist, *c_sh, *c_emb;
+  float* msg; float* gp; float *tor_attr, *sc_attr, *tor_feat, *sc_feat;
+  int* n_edges6;  // [8] device counters
+};
+
+static void edge_set_take(Bump& b, EdgeSet& S, int cap, int n_targets, int G, int* n_edges, const char* nm) {
+  S.cap = cap; S.n_edges = n_edges;
+  std::string p(nm);
+  S.tgt = b.take<int>(cap, (p + ".tgt").c_str()); S.gth = b.take<int>(cap, (p + ".gth").c_str());
+  S.aux = b.take<int>(cap, (p + ".aux").c_str());
+  S.dist = b.take<float>(cap, (p + ".dist").c_str()); S.sh = b.take<float>((size_t)cap * SH_LD, (p + ".sh").c_str());
+  S.emb = b.take<float>((size_t)cap * NS, (p + ".emb").c_str());
+  S.row_start = b.take<int>(n_targets, (p + ".row_start").c_str()); S.row_cnt = b.take<int>(n_targets, (p + ".row_cnt").c_str());
+  S.g_cnt = b.take<int>(G, (p + ".g_cnt").c_str()); S.g_base = b.take<int>(G, (p + ".g_base").c_str());
+}
+
+static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim, char* base, size_t cap, Ws* w,
+                size_t* need_bytes, std::vector<WsEntry>* log = nullptr) {
+  dbfr_limits L = {24, 64};
+  if (lim) { if (lim->aa_avg_neighbors > 0) L.aa_avg_neighbors = lim->aa_avg_neighbors; if (lim->cross_avg_neighbors > 0) L.cross_avg_neighbors = lim->cross_avg_neighbors; }
+  Bump b{base, 0, cap, log};
+  const int G = B->G, NL = B->NL, NA = B->NA;
+  w->err = b.take<int>(16, "err"); w->counters = (int64_t*)b.take<int64_t>(8); w->n_edges6 = b.take<int>(8, "n_edges");
+  w->lig_batch = b.take<int>(NL); w->atm_batch = b.take<int>(NA); w->is_cab = b.take<uint8_t>(NA, "is_cab");
+  w->n_cab = b.take<int>(G); w->tor_batch = b.take<int>(B->NTOR + 1); w->sc_batch = b.take<int>(B->NSC + 1);
+  w->temb = b.take<float>((size_t)G * EMB, "temb");
+  w->c_t = b.take<float>(G); w->c_tr_sigma = b.take<float>(G); w->c_rot_norm = b.take<float>(G);
+  w->c_tor_n2 = b.take<float>(B->NTOR + 1); w->c_sc_n2 = b.take<float>(B->NSC + 1);
+  w->s_tr = b.take<float>(3 * G); w->s_rot = b.take<float>(3 * G); w->s_tor = b.take<float>(B->NTOR + 1); w->s_sc = b.take<float>(B->NSC + 1);
+  for (int i = 0; i < 2; ++i) { w->lig_x[i] = b.take<float>((size_t)NL * MAXD, i ? "lig_x1" : "lig_x0"); w->atom_x[i] = b.take<float>((size_t)NA * MAXD, i ? "atom_x1" : "atom_x0"); }
+  const int lig_cap = m->cfg.lig_max_neighbors;
+  const long cap_ll = (long)NL * std::min(lig_cap + 1, std::max(B->max_nl - 1, 1)) + B->EB;
+  const long cap_aa = (long)NA * std::min(L.aa_avg_neighbors, std::max(B->max_na - 1, 1));
+  const long cap_x = (long)NL * std::min(B->max_na, 2 * B->max_nr + L.cross_avg_neighbors);
+  const long cap_t = (long)B->NTOR * lig_cap, cap_s = m->cfg.no_sc_torsion ? 0 : (long)B->NSC * lig_cap;
+  const long caps[N_SETS] = {cap_ll, cap_aa, cap_x, cap_x, cap_t, cap_s};
+  const int ntg[N_SETS] = {NL, NA, NL, NA, B->NTOR, B->NSC};
+  long maxcap = NL;
+  for (int k = 0; k < N_SETS; ++k) {
+    if (caps[k] > 0x7fffff00L) return fail(DBFR_ERR_ARG, "batch too large for int32 edge indices; split it");
+    static const char* names[N_SETS] = {"ll", "aa", "al", "la", "tor", "sc"};
+    edge_set_take(b, w->set[k], (int)caps[k], ntg[k] + 1, G, w->n_edges6 ? w->n_edges6 + k : nullptr, names[k]);
+    maxcap = std::max(maxcap, caps[k]);
+  }
+  w->c_tgt = b.take<int>(NL); w->c_gth = b.take<int>(NL); w->c_dist = b.take<float>(NL); w->c_sh = b.take<float>((size_t)NL * SH_LD, "center.sh");
+  w->c_emb = b.take<float>((size_t)NL * NS, "center.emb"); w->c_row_start = b.take<int>(G); w->c_row_cnt = b.take<int>(G);
+  w->c_n = w->n_edges6 ? w->n_edges6 + 6 : nullptr;
+  w->msg = b.take<float>((size_t)maxcap * MAXD, "msg");
+  w->gp = b.take<float>((size_t)G * 12, "gp");
+  w->tor_attr = b.take<float>((size_t)(B->NTOR + 1) * NS, "tor_attr"); w->sc_attr = b.take<float>((size_t)(B->NSC + 1) * NS);
+  w->tor_feat = b.take<float>((size_t)(B->NTOR + 1) * 2 * NS, "tor_feat"); w->sc_feat = b.take<float>((size_t)(B->NSC + 1) * 2 * NS);
+  *need_bytes = b.off + 256;
+  return DBFR_OK;
+}
+
+static int check_batch(const dbfr_model* m, const dbfr_batch* B) {
+  if (!m || !B) return fail(DBFR_ERR_ARG, "null argument");
+  if (B->G <= 0 || B->NL <= 0 || B->NA <= 0 || B->NR <= 0) return fail(DBFR_ERR_ARG, "empty batch");
+  if (B->max_nl > 256) return fail(DBFR_ERR_ARG, "ligand with more than 256 heavy atoms is not supported");
+  if (B->max_na > 2048) return fail(DBFR_ERR_ARG, "pocket with more than 2048 heavy atoms is not supported");
+  if (B->max_nl <= 0 || B->max_na <= 0 || B->max_nr <= 0) return fail(DBFR_ERR_ARG, "max_nl/max_na/max_nr must be set");
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_workspace_bytes(const dbfr_model* m, const dbfr_batch* b, const dbfr_limits* lim, size_t* bytes) {
+  int rc = check_batch(m, b);
+  if (rc) return rc;
+  if (!bytes) return fail(DBFR_ERR_ARG, "null argument");
+  Ws w; memset(&w, 0, sizeof w);
+  return plan(m, b, lim, nullptr, 0, &w, bytes);
+}
+
+// ------------------------------------------------------------------------------------------------ score network
+static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int max_edges, const int* tgt, const int* gth,
+                      const float* emb, const float* sh, const float* tab1, int ld1, const int* idx1, const float* tab2,
+                      int ld2, const int* idx2, const float* x, int ldx, float* msg, hipStream_t st) {
+  ConvArgs a;
+  a.n_edges = n_edges; a.max_edges = max_edges; a.tgt = tgt; a.gth = gth; a.emb = emb; a.sh = sh; a.sh_sign = 1.f;
+  a.tab1 = tab1; a.ld1 = ld1; a.idx1 = idx1; a.tab2 = tab2; a.ld2 = ld2; a.idx2 = idx2; a.x = x; a.ldx = ldx;
+  a.w = cw; a.msg = msg;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (m->profile) {
+    if (m->ev_used + 2 > m->ev.size()) {
+      size_t old = m->ev.size();
+      m->ev.resize(old + 512);
+      for (size_t i = old; i < m->ev.size(); ++i) (void)hipEventCreate(&m->ev[i]);
+    }
+    e0 = m->ev[m->ev_used++]; e1 = m->ev[m->ev_used++];
+    (void)hipEventRecord(e0, st);
+  }
+  launch_conv(a, st);
+  if (m->profile) {
+    (void)hipEventRecord(e1, st);
+    // algorithmic flops per edge: radial MLP 2K(K + W) + tensor-product contraction 2*(sum_paths mul1*mulo*dim_o)
+    launch_acc_flops(n_edges, 2.0 * cw.K * ((double)cw.K + cw.W), m->flops_dev, st);
+  }
+}
+
+static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, const dbfr_scores* out, Ws& w,
+                     hipStream_t st) {
+  const dbfr_model_cfg& cfg = m->cfg;
+  const int G = B->G, NL = B->NL, NA = B->NA;
+  launch_time_embed(c->t, G, cfg.emb_scale, w.temb, st);
+  // ---- graphs (all six radius-type sets in one count/scan/fill pass)
+  GraphArgs ga;
+  ga.b = *B; ga.lig_batch = w.lig_batch; ga.atm_batch = w.atm_batch; ga.is_cab = w.is_cab; ga.n_cab = w.n_cab;
+  ga.tr_sigma = c->tr_sigma;
+  ga.lig_cut2 = cfg.lig_cutoff * cfg.lig_cutoff; ga.atom_cut2 = cfg.atom_cutoff * cfg.atom_cutoff;
+  ga.cross_cut2 = cfg.dynamic_max_cross ? 1.0f : cfg.cross_cutoff * cfg.cross_cutoff;
+  ga.lig_cap = cfg.lig_max_neighbors; ga.atom_cap = cfg.atom_max_neighbors; ga.dynamic_cross = cfg.dynamic_max_cross;
+  for (int k = 0; k < N_SETS; ++k) ga.set[k] = w.set[k];
+  ga.err = w.err;
+  launch_edges(ga, false, st);
+  // ---- embeddings
+  {
+    MlpArgs a; memset(&a, 0, sizeof a);
+    a.w = m->lig_node_emb; a.mode = IN_LIGNODE; a.n_rows_max = NL; a.temb = w.temb; a.row_graph_tab = w.lig_batch;
+    a.lig_node = B->lig_node; a.nnode = cfg.lig_node_features; a.out = w.lig_x[0];
+    launch_mlp(a, st);
+  }
+  {
+    AtomEncArgs a; a.pocket_feat = B->pocket_feat; a.atm_batch = w.atm_batch; a.temb = w.temb;
+    for (int i = 0; i < 5; ++i) { a.emb[i] = m->atom_emb[i]; a.dims[i] = m->atom_dims[i]; }
+    a.lin_t = m->atom_lin_t; a.NA = NA; a.out = w.atom_x[0];
+    launch_atom_encoder(a, st);
+  }
+  auto edge_mlp = [&](const Mlp2& mw, int mode, const EdgeSet& S, const int* tab, const float* off, const float* co) {
+    MlpArgs a; memset(&a, 0, sizeof a);
+    a.w = mw; a.mode = mode; a.n_rows_dev = S.n_edges; a.n_rows_max = S.cap; a.temb = w.temb; a.row_graph_tab = tab;
+    a.tgt = S.tgt; a.aux = S.aux; a.dist = S.dist; a.bond_feat = B->bond_feat; a.nfeat = cfg.lig_edge_features;
+    a.gs_offset = off; a.gs_coeff = co; a.out = S.emb;
+    launch_mlp(a, st);
+  };
+  edge_mlp(m->lig_edge_emb, IN_LIGEDGE, w.set[SET_LL], w.lig_batch, m->gs_lig_off, m->gs_lig_c);
+  edge_mlp(m->atom_edge_emb, IN_TG, w.set[SET_AA], w.atm_batch, m->gs_atom_off, m->gs_atom_c);
+  edge_mlp(m->la_edge_emb, IN_TG, w.set[SET_AL], w.lig_batch, m->gs_cross_off, m->gs_cross_c);
+  edge_mlp(m->la_edge_emb, IN_TG, w.set[SET_LA], w.atm_batch, m->gs_cross_off, m->gs_cross_c);
+  // ---- interaction layers
+  static const int dims[4] = {48, 84, 120, 168};
+  int cur = 0;
+  for (int l = 0; l < cfg.num_conv_layers; ++l) {
+    const int Di = dims[std::min(l, 3)], Do = dims[std::min(l + 1, 3)];
+    const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
+    float *lnew = w.lig_x[cur ^ 1], *anew = w.atom_x[cur ^ 1];
+    const EdgeSet &LL = w.set[SET_LL], &AA = w.set[SET_AA], &AL = w.set[SET_AL], &LA = w.set[SET_LA];
+    conv_call(m, m->layer[l][0], LL.n_edges, LL.cap, LL.tgt, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg, st);
+    launch_reduce_ln(w.msg, LL.row_start, LL.row_cnt, NL, Do, m->layer[l][0].ln, lx, Di, lnew, Do, 0, st);
+    conv_call(m, m->layer[l][1], AL.n_edges, AL.cap, AL.tgt, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg, st);
+    launch_reduce_ln(w.msg, AL.row_start, AL.row_cnt, NL, Do, m->layer[l][1].ln, nullptr, 0, lnew, Do, 1, st);
+    conv_call(m, m->layer[l][2], AA.n_edges, AA.cap, AA.tgt, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg, st);
+    launch_reduce_ln(w.msg, AA.row_start, AA.row_cnt, NA, Do, m->layer[l][2].ln, ax, Di, anew, Do, 0, st);
+    conv_call(m, m->layer[l][3], LA.n_edges, LA.cap, LA.tgt, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg, st);
+    launch_reduce_ln(w.msg, LA.row_start, LA.row_cnt, NA, Do, m->layer[l][3].ln, nullptr, 0, anew, Do, 1, st);
+    cur ^= 1;
+  }
+  const int D = dims[std::min(cfg.num_conv_layers, 3)];
+  if (D != MAXD) return fail(DBFR_ERR_ARG, "heads need num_conv_layers >= 3");
+  const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
+  // ---- translation / rotation head
+  launch_center_edges(*B, w.c_tgt, w.c_gth, w.c_dist, w.c_sh, w.c_row_start, w.c_row_cnt, st);
+  {
+    MlpArgs a; memset(&a, 0, sizeof a);
+    a.w = m->center_edge_emb; a.mode = IN_TG; a.n_rows_max = NL; a.temb = w.temb; a.row_graph_tab = w.lig_batch;
+    a.dist = w.c_dist; a.gs_offset = m->gs_center_off; a.gs_coeff = m->gs_center_c; a.out = w.c_emb;
+    launch_mlp(a, st);
+  }
+  conv_call(m, m->final_conv, w.n_edges6 + 7, NL, w.c_tgt, w.c_gth, w.c_emb, w.c_sh, lx, D, w.c_gth, nullptr, 0, w.c_gth, lx, D, w.msg, st);
+  launch_reduce_ln(w.msg, w.c_row_start, w.c_row_cnt, G, 12, m->final_conv.ln, nullptr, 0, w.gp, 12, 2, st);
+  {
+    TrRotArgs a; a.gp = w.gp; a.temb = w.temb; a.tr_sigma = c->tr_sigma; a.rot_norm = c->rot_score_norm;
+    a.tr = m->tr_final; a.rot = m->rot_final; a.G = G; a.scale_by_sigma = cfg.scale_by_sigma; a.tr_out = out->tr;
+    a.rot_out = out->rot; a.err = w.err;
+    launch_trrot(a, st);
+  }
+  // ---- ligand torsion head
+  if (B->NTOR > 0) {
+    const EdgeSet& T = w.set[SET_TOR];
+    launch_bond_attr(lx, D, B->bond_src, B->bond_dst, B->tor_bond, 0, B->NTOR, w.tor_attr, st);
+    {
+      MlpArgs a; memset(&a, 0, sizeof a);
+      a.w = m->tor_edge_emb; a.mode = IN_G; a.n_rows_dev = T.n_edges; a.n_rows_max = T.cap; a.dist = T.dist;
+      a.gs_offset = m->gs_lig_off; a.gs_coeff = m->gs_lig_c; a.out = T.emb;
+      launch_mlp(a, st);
+    }
+    conv_call(m, m->tor_conv, T.n_edges, T.cap, T.tgt, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg, st);
+    launch_reduce_ln(w.msg, T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
+    launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, st);
+  }
+  // ---- side-chain torsion head
+  if (!cfg.no_sc_torsion && B->NSC > 0) {
+    const EdgeSet& S = w.set[SET_SC];
+    launch_bond_attr(ax, D, B->sc_bond, nullptr, nullptr, 2, B->NSC, w.sc_attr, st);
+    {
+      MlpArgs a; memset(&a, 0, sizeof a);
+      a.w = m->sc_edge_emb; a.mode = IN_G; a.n_rows_dev = S.n_edges; a.n_rows_max = S.cap; a.dist = S.dist;
+      a.gs_offset = m->gs_atom_off; a.gs_coeff = m->gs_atom_c; a.out = S.emb;
+      launch_mlp(a, st);
+    }
+    conv_call(m, m->sc_conv, S.n_edges, S.cap, S.tgt, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg, st);
+    launch_reduce_ln(w.msg, S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, st);
+    launch_tor_final(w.sc_feat, m->sc_final, c->sc_tor_score_norm2, cfg.scale_by_sigma, B->NSC, out->sc_tor, st);
+  }
+  return DBFR_OK;
+}
+
+static int begin(dbfr_model* m, const dbfr_batch* B, void* workspace, size_t wbytes, const dbfr_limits* lim, Ws* w,
+                 hipStream_t st) {
+  int rc = check_batch(m, B);
+  if (rc) return rc;
+  if (!workspace) return fail(DBFR_ERR_ARG, "null workspace");
+  size_t needb = 0;
+  memset(w, 0, sizeof *w);
+  rc = plan(m, B, lim, (char*)workspace, wbytes, w, &needb);
+  if (rc) return rc;
+  if (needb > wbytes) return fail(DBFR_ERR_ARG, "workspace too small: need " + std::to_string(needb) + " bytes");
+  HIPCHECK(hipMemsetAsync(workspace, 0, 1024, st));   // err @0, counters @256, n_edges6 @512
+  launch_set_int(w->n_edges6 + 7, B->NL, st);           // the centre set has exactly one edge per ligand atom
+  launch_batch_vectors(*B, w->lig_batch, w->atm_batch, w->is_cab, w->n_cab, w->tor_batch, w->sc_batch, st);
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_score(dbfr_model* m, const dbfr_batch* b, const dbfr_cond* cond, const dbfr_scores* out,
+                          void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream) {
+  if (!cond || !out) return fail(DBFR_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  Ws w;
+  int rc = begin(m, b, workspace, workspace_bytes, lim, &w, st);
+  if (rc) return rc;
+  rc = run_score(m, b, cond, out, w, st);
+  if (rc) return rc;
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps,
+                           const dbfr_noise* noise, float* atom14_out, float* traj_lig, float* traj_atom14,
+                           void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream) {
+  if (!steps || n_steps <= 0 || !noise) return fail(DBFR_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  Ws w;
+  int rc = begin(m, b, workspace, workspace_bytes, lim, &w, st);
+  if (rc) return rc;
+  const int G = b->G;
+  for (int s = 0; s < n_steps; ++s) {
+    const dbfr_step& sp = steps[s];
+    // set_time (scFlex.py:104-122): uniform conditioning over the batch
+    launch_fill(w.c_t, sp.t, G, st);
+    launch_fill(w.c_tr_sigma, sp.tr_sigma, G, st);
+    launch_fill(w.c_rot_norm, sp.rot_score_norm, G, st);
+    launch_fill(w.c_tor_n2, sp.tor_score_norm2, b->NTOR, st);
+    launch_fill(w.c_sc_n2, sp.tor_score_norm2, b->NSC, st);
+    dbfr_cond c = {w.c_t, w.c_tr_sigma, w.c_rot_norm, w.c_tor_n2, w.c_sc_n2};
+    dbfr_scores sc = {w.s_tr, w.s_rot, w.s_tor, w.s_sc};
+    rc = run_score(m, b, &c, &sc, w, st);
+    if (rc) return rc;
+    SdeLigArgs la;
+    la.b = *b; la.tr_score = w.s_tr; la.rot_score = w.s_rot; la.tor_score = w.s_tor;
+    la.z_tr = noise->z_tr + (size_t)s * G * 3; la.z_rot = noise->z_rot + (size_t)s * G * 3;
+    la.z_tor = noise->z_tor + (size_t)s * b->NTOR;
+    la.dt = sp.dt; la.tr_g2 = sp.tr_g2; la.tr_gsdt = sp.tr_gsdt; la.rot_g2 = sp.rot_g2; la.rot_gsdt = sp.rot_gsdt;
+    la.tor_g2 = sp.tor_g2; la.tor_gsdt = sp.tor_gsdt;
+    la.traj = traj_lig ? traj_lig + (size_t)s * b->NL * 3 : nullptr;
+    la.err = w.err;
+    launch_sde_ligand(la, st);
+    if (!m->cfg.no_sc_torsion) {
+      const bool last = s == n_steps - 1;
+      launch_sidechain(*b, w.s_sc, noise->z_sc + (size_t)s * b->NSC, sp.dt, sp.sc_g2, sp.sc_gsdt, m->a14_group,
+                       last ? atom14_out : nullptr, traj_atom14 ? traj_atom14 + (size_t)s * b->NR * 42 : nullptr, st);
+    }
+  }
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters) {
+  if (!workspace) return fail(DBFR_ERR_ARG, "null workspace");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIPCHECK(hipStreamSynchronize(st));
+  int h[16 + 16 + 8];
+  HIPCHECK(hipMemcpy(h, workspace, sizeof h, hipMemcpyDeviceToHost));
+  // layout of plan(): err[16] @0 (64 B), counters[8] @256, n_edges6[8] @512
+  int err = h[0];
+  if (counters) {
+    int ne[8];
+    HIPCHECK(hipMemcpy(ne, (char*)workspace + 512, sizeof ne, hipMemcpyDeviceToHost));
+    counters[0] = ne[SET_LL]; counters[1] = ne[SET_AA]; counters[2] = ne[SET_AL]; counters[3] = ne[7];
+    counters[4] = ne[SET_TOR]; counters[5] = ne[SET_SC]; counters[6] = ne[SET_LA]; counters[7] = 0;
+  }
+  if (err == DBFR_ERR_CAPACITY) return fail(err, "edge capacity exceeded: raise dbfr_limits");
+  if (err == DBFR_ERR_NUMERIC) return fail(err, "non-finite score or Kabsch determinant check failed");
+  return err;
+}
+
+extern "C" int dbfr_profile_enable(dbfr_model* m, int32_t on) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  m->profile = on;
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops,
+                                 int32_t reset) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  HIPCHECK(hipDeviceSynchronize());
+  for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) { m->conv_ms_acc += ms; m->conv_launches_acc++; }
+  }
+  m->ev_used = 0;
+  double fl = 0;
+  HIPCHECK(hipMemcpy(&fl, m->flops_dev, sizeof fl, hipMemcpyDeviceToHost));
+  if (conv_ms) *conv_ms = m->conv_ms_acc;
+  if (conv_launches) *conv_launches = m->conv_launches_acc;
+  if (conv_flops) *conv_flops = fl;
+  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, sizeof(double))); }
+  return DBFR_OK;
+}
+
+// test hook: named offsets of the internal buffers inside the workspace
+extern "C" int dbfr_workspace_layout(const dbfr_model* m, const dbfr_batch* b, const dbfr_limits* lim, char* names,
+                                     size_t names_cap, size_t* offsets, size_t* bytes, int32_t max_entries) {
+  int rc = check_batch(m, b);
+  if (rc) return rc;
+  std::vector<WsEntry> log;
+  Ws w; memset(&w, 0, sizeof w);
+  size_t nb = 0;
+  rc = plan(m, b, lim, nullptr, 0, &w, &nb, &log);
+  if (rc) return rc;
+  size_t pos = 0;
+  int n = 0;
+  for (auto& e : log) {
+    if (n >= max_entries || pos + e.name.size() + 2 > names_cap) break;
+    memcpy(names + pos, e.name.c_str(), e.name.size());
+    pos += e.name.size();
+    names[pos++] = ';';
+    offsets[n] = e.offset; bytes[n] = e.bytes;
+    ++n;
+  }
+  names[pos] = 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------ unit-test hooks
+static const ConvW* pick_conv(const dbfr_model* m, int layer, int family) {
+  if (layer >= 0 && layer < m->cfg.num_conv_layers && family >= 0 && family < 4) return &m->layer[layer][family];
+  if (layer == -1) return &m->final_conv;
+  if (layer == -2) return &m->tor_conv;
+  if (layer == -3 && !m->cfg.no_sc_torsion) return &m->sc_conv;
+  return nullptr;
+}
+
+extern "C" int dbfr_test_conv(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,
+                              const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh,
+                              const float* tab1, int32_t ld1, const int32_t* idx1, const float* tab2, int32_t ld2,
+                              const int32_t* idx2, const float* x, int32_t ldx, float* msg, void* hip_stream) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  const ConvW* cw = pick_conv(m, layer, family);
+  if (!cw) return fail(DBFR_ERR_ARG, "no such conv");
+  conv_call(m, *cw, n_edges_dev, n_edges, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg,
+            (hipStream_t)hip_stream);
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_test_reduce_ln(dbfr_model* m, int32_t layer, int32_t family, const float* msg,
+                                   const int32_t* row_start, const int32_t* row_cnt, int32_t n_nodes, const float* old,
+                                   int32_t d_old, float* out, int32_t mode, void* hip_stream) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  const ConvW* cw = pick_conv(m, layer, family);
+  if (!cw) return fail(DBFR_ERR_ARG, "no such conv");
+  launch_reduce_ln(msg, row_start, row_cnt, n_nodes, cw->D_out, cw->ln, old, d_old, out, cw->D_out, mode,
+                   (hipStream_t)hip_stream);
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}

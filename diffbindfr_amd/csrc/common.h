@@ -1,0 +1,109 @@
+// Internal declarations shared by the host code and the HIP kernels of libdbfr.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dbfr.h"
+
+#define NS 48           // scalar multiplicity (cfg.ns), also the edge/node embedding width
+#define NV 12           // vector multiplicity (cfg.nv)
+#define SH_LD 9         // per-edge spherical-harmonic record (l=0..2), tor convs use 7 of 9
+#define EMB 32          // sigma / distance embedding width
+#define MAXD 168        // widest irreps feature: 48x0e+12x1o+12x1e+48x0o
+
+// kernel-side tensor-product path types: closed forms of the real Wigner-3j tensors
+enum PathType { PT_SS = 0, PT_SV = 1, PT_VS = 2, PT_VVS = 3, PT_VVV = 4, PT_VTV = 5 };
+
+struct Irr { int mul, l, p; int dim() const { return 2 * l + 1; } };
+
+struct PathDesc {
+  int i1, i2, io, l1, l2, lo, mul1, mulo, w_off;
+  float coeff;       // e3nn path_weight: sqrt((2lo+1)/sum fan-in)
+  int type;          // PathType
+  int in_off, sh_off, out_off;  // float offsets of the slots in x / sh / out rows
+  float fold;        // coeff * closed-form CG scalar, folded into W2/b2 rows
+};
+
+struct ConvSpec {
+  std::vector<Irr> in, sh, out;
+  std::vector<PathDesc> paths;
+  int K;             // n_edge_features = hidden width of the radial MLP (144 or 96)
+  int W;             // tp.weight_numel
+  int D_in, D_out;
+};
+
+// conv kinds: 0..3 layer convs by irreps depth, 4 final_conv, 5 tor / sc_tor convs
+ConvSpec make_conv_spec(int kind);
+void wigner3j_real(int l1, int l2, int l3, std::vector<double>& out);
+int so3_selftest(std::string& err);
+
+// ------------------------------------------------------------------ device-side descriptors
+struct LNDesc {            // equivariant LayerNorm over the out irreps (tpscore.py:20-107)
+  int nblk;
+  int mul[4], dim[4], off[4], is0e[4];
+  const float* mean_shift;   // [num_irreps]
+  const float* weight;       // [num_irreps]
+  const float* bias;         // [num 0e]
+};
+
+struct ConvW {             // one TensorProductConvLayer, device resident
+  int K, D_in, D_out, n_tiles, W;
+  const float* W1p;   // [K/16][K/16][64][4]   lin.0 weight in MFMA A-fragment order
+  const float* b1;    // [K]
+  const float* W2p;   // [n_tiles][K/16][64][4] lin.3 weight rows permuted (path, w, u), path norm folded
+  const float* b2p;   // [n_tiles*16]
+  const uint32_t* quads;  // [n_tiles*4]  x_off | out_off<<8 | type<<16 | sh_off<<20
+  LNDesc ln;
+};
+
+struct Mlp2 {              // SimpleLinear: Linear(in,hid) -> act -> Linear(hid,out)
+  int in, hid, out;
+  const float* w0t;   // [in][hid]   (transposed for coalesced/bank-friendly reads)
+  const float* b0;    // [hid] or null
+  const float* w1t;   // [hid][out]
+  const float* b1;    // [out] or null
+};
+
+struct EdgeSet {           // one per-step edge list, grouped (CSR) by scatter-target node
+  int cap;
+  int* n_edges;        // device scalar
+  int* tgt;            // [cap] scatter target (reference edge_index[0] of the conv call)
+  int* gth;            // [cap] gather source  (reference edge_index[1])
+  int* aux;            // [cap] bond index for ligand bond edges, -1 otherwise
+  float* dist;         // [cap] |edge_vec|
+  float* sh;           // [cap][SH_LD]
+  float* emb;          // [cap][NS] edge embedding after its SimpleLinear
+  int* row_start;      // [n_targets]
+  int* row_cnt;        // [n_targets]
+  int* g_cnt;          // [G] per-graph totals (count pass)
+  int* g_base;         // [G] per-graph base offset (scan)
+};
+
+struct ConvArgs {
+  const int* n_edges;
+  int max_edges;
+  const int* tgt;
+  const int* gth;
+  const float* emb;       // [E][NS]
+  const float* sh;        // [E][SH_LD]
+  float sh_sign;          // -1 flips the l=1 components (cross_la reuses the al harmonics)
+  // radial-MLP input = [emb | tab1[idx1[e]][:NS] | tab2[idx2[e]][:NS]] (K=144) or [emb | tab1..] (K=96)
+  const float* tab1; int ld1; const int* idx1;
+  const float* tab2; int ld2; const int* idx2;
+  const float* x; int ldx;      // tensor-product input rows, gathered by gth
+  ConvW w;
+  float* msg;                   // [E][D_out]
+};
+
+#define HIPCHECK(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      dbfr_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+      return DBFR_ERR_HIP;                                                                     \
+    }                                                                                          \
+  } while (0)
+
+void dbfr_set_error(const std::string& s);

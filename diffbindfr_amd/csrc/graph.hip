@@ -1,0 +1,524 @@
+// Per-step graph construction and embeddings for gfx950.
+//
+// Replaces (every reverse-diffusion step, positions move):
+//   torch_cluster.radius_graph / radius          tpscore.py:586,613,655-660,721-723,747-749
+//   get_complete_bipartite_graph                 torch_utils/graph.py:81-140 (lig x {CA,CB})
+//   edge_vec, GaussianSmearing, o3.spherical_harmonics, FullTensorProduct(sh,"2e")
+//                                                tpscore.py:593-598,615-620,676-680,704-708,715-729,740-755
+//   SimpleLinear edge/node embeddings, AtomEncoder, sinusoidal_embedding   tpscore.py:464-479
+//
+// Layout: one workgroup per (graph, edge set); the graph's coordinates sit in LDS, one thread per
+// scatter-target node scans its candidates in index order (N <= ~900 per graph: brute force in LDS
+// beats any cell list).  Edge lists come out grouped by target node (CSR: row_start/row_cnt), graphs
+// in batch order, so that downstream reductions are contiguous and reproducible:
+//   k_edges_count -> k_edges_scan (per set, one block) -> k_edges_fill.
+// torch_cluster semantics reproduced: strict d^2 < r^2, "first max_num_neighbors by index" per query,
+// radius_graph queries max+1 then drops the self loop.
+#include "common.h"
+
+#define MAX_NL 256
+#define MAX_NA 2048
+
+enum SetKind { SET_LL = 0, SET_AA = 1, SET_AL = 2, SET_LA = 3, SET_TOR = 4, SET_SC = 5, N_SETS = 6 };
+
+struct GraphArgs {
+  dbfr_batch b;
+  const int* lig_batch;   // [NL]
+  const int* atm_batch;   // [NA]
+  const uint8_t* is_cab;  // [NA]
+  const int* n_cab;       // [G]
+  const float* tr_sigma;  // [G]
+  float lig_cut2, atom_cut2, cross_cut2;
+  int lig_cap, atom_cap, dynamic_cross;
+  EdgeSet set[N_SETS];
+  int* err;               // device status word
+};
+
+__device__ __forceinline__ float d2_rn(float ax, float ay, float az, float bx, float by, float bz) {
+  // ((dx*dx + dy*dy) + dz*dz) with every op rounded (no fma contraction): the oracle's order
+  float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ void sh_l2(float x, float y, float z, float* o) {
+  // component-normalised real harmonics l=2, y polar (e3nn): sqrt15 xz, sqrt15 xy, sqrt5(y^2-(x^2+z^2)/2), ...
+  const float s15 = 3.872983346207417f, s5 = 2.23606797749979f;
+  o[0] = s15 * x * z;
+  o[1] = s15 * x * y;
+  o[2] = s5 * (y * y - 0.5f * (x * x + z * z));
+  o[3] = s15 * y * z;
+  o[4] = (s15 * 0.5f) * (z * z - x * x);
+}
+
+__device__ __forceinline__ float vec_sh(float vx, float vy, float vz, float* sh9) {
+  float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+  float inv = 1.0f / fmaxf(nrm, 1e-12f);
+  float x = vx * inv, y = vy * inv, z = vz * inv;
+  const float s3 = 1.7320508075688772f;
+  sh9[0] = 1.0f;
+  sh9[1] = s3 * x;
+  sh9[2] = s3 * y;
+  sh9[3] = s3 * z;
+  sh_l2(x, y, z, sh9 + 4);
+  return nrm;
+}
+
+// shared staging of one graph
+struct GraphLds {
+  float lx[MAX_NL], ly[MAX_NL], lz[MAX_NL];
+  float ax[MAX_NA], ay[MAX_NA], az[MAX_NA];
+  int thr[MAX_NA];        // radius_graph cap threshold per centre
+  int scan[256];
+};
+
+__device__ void load_graph(GraphLds& s, const GraphArgs& A, int g, int kind, int& l0, int& nl, int& a0, int& na) {
+  l0 = A.b.lig_ptr[g];
+  nl = A.b.lig_ptr[g + 1] - l0;
+  a0 = A.b.atm_ptr[g];
+  na = A.b.atm_ptr[g + 1] - a0;
+  float scale = 1.0f;
+  bool scaled = (kind == SET_AL || kind == SET_LA) && A.dynamic_cross;
+  if (scaled) scale = __fadd_rn(__fmul_rn(A.tr_sigma[g], 0.2f), 5.0f);
+  if (kind != SET_AA && kind != SET_SC)
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+      float x = A.b.lig_pos[3 * (l0 + i)], y = A.b.lig_pos[3 * (l0 + i) + 1], z = A.b.lig_pos[3 * (l0 + i) + 2];
+      if (scaled) { x = __fdiv_rn(x, scale); y = __fdiv_rn(y, scale); z = __fdiv_rn(z, scale); }
+      s.lx[i] = x; s.ly[i] = y; s.lz[i] = z;
+    }
+  if (kind == SET_AA || kind == SET_AL || kind == SET_LA || kind == SET_SC)
+    for (int i = threadIdx.x; i < na; i += blockDim.x) {
+      float x = A.b.rec_pos[3 * (a0 + i)], y = A.b.rec_pos[3 * (a0 + i) + 1], z = A.b.rec_pos[3 * (a0 + i) + 2];
+      if (scaled) { x = __fdiv_rn(x, scale); y = __fdiv_rn(y, scale); z = __fdiv_rn(z, scale); }
+      s.ax[i] = x; s.ay[i] = y; s.az[i] = z;
+    }
+  __syncthreads();
+}
+
+// radius_graph cap: centre i keeps the first (cap+1) in-range points incl. itself, by index
+__device__ void cap_thresholds(GraphLds& s, const float* px, const float* py, const float* pz, int n, float r2,
+                               int cap) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int thr = 0x7fffffff;
+    if (n > cap + 1) {
+      int c = 0;
+      for (int j = 0; j < n; ++j)
+        if (d2_rn(px[i], py[i], pz[i], px[j], py[j], pz[j]) < r2 && ++c == cap + 1) { thr = j; break; }
+    }
+    s.thr[i] = thr;
+  }
+  __syncthreads();
+}
+
+// Count (emit == false) or emit the edges of target `t` (local index) of the given set.
+// Returns the number of edges of the target.  `base` = absolute slot of its first edge.
+template <bool EMIT>
+__device__ int target_edges(const GraphLds& s, const GraphArgs& A, int kind, int g, int t, int l0, int nl, int a0,
+                            int na, int base) {
+  const EdgeSet& S = A.set[kind];
+  int cnt = 0;
+  auto emit = [&](int tgt, int gth, int aux, float vx, float vy, float vz) {
+    if (EMIT) {
+      int e = base + cnt;
+      if (e < S.cap) {
+        float sh9[9];
+        float d = vec_sh(vx, vy, vz, sh9);
+        S.tgt[e] = tgt; S.gth[e] = gth; S.aux[e] = aux; S.dist[e] = d;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S.sh[(size_t)e * SH_LD + k] = sh9[k];
+      }
+    }
+    ++cnt;
+  };
+  const float* LP = A.b.lig_pos;
+  const float* RP = A.b.rec_pos;
+  if (kind == SET_LL) {
+    const int gt = l0 + t;
+    for (int k = A.b.bond_ptr[gt]; k < A.b.bond_ptr[gt + 1]; ++k) {  // bond edges (u=t -> v): tgt=u, gth=v
+      int v = A.b.bond_dst[k];
+      emit(gt, v, k, LP[3 * v] - LP[3 * gt], LP[3 * v + 1] - LP[3 * gt + 1], LP[3 * v + 2] - LP[3 * gt + 2]);
+    }
+    for (int i = 0; i < nl; ++i) {
+      if (i == t || t > s.thr[i]) continue;
+      if (d2_rn(s.lx[i], s.ly[i], s.lz[i], s.lx[t], s.ly[t], s.lz[t]) < A.lig_cut2) {
+        int gi = l0 + i;  // radius edge (neighbour=t, centre=i): scatter to t, gather from i
+        emit(gt, gi, -1, LP[3 * gi] - LP[3 * gt], LP[3 * gi + 1] - LP[3 * gt + 1], LP[3 * gi + 2] - LP[3 * gt + 2]);
+      }
+    }
+  } else if (kind == SET_AA) {
+    const int gt = a0 + t;
+    for (int i = 0; i < na; ++i) {
+      if (i == t || t > s.thr[i]) continue;
+      if (d2_rn(s.ax[i], s.ay[i], s.az[i], s.ax[t], s.ay[t], s.az[t]) < A.atom_cut2) {
+        int gi = a0 + i;
+        emit(gt, gi, -1, RP[3 * gi] - RP[3 * gt], RP[3 * gi + 1] - RP[3 * gt + 1], RP[3 * gi + 2] - RP[3 * gt + 2]);
+      }
+    }
+  } else if (kind == SET_AL) {  // target ligand atom, gathers pocket atoms; vec = rec - lig
+    const int gt = l0 + t;
+    for (int i = 0; i < na; ++i) {
+      int gi = a0 + i;
+      bool in = A.is_cab[gi] || d2_rn(s.lx[t], s.ly[t], s.lz[t], s.ax[i], s.ay[i], s.az[i]) < A.cross_cut2;
+      if (in) emit(gt, gi, -1, RP[3 * gi] - LP[3 * gt], RP[3 * gi + 1] - LP[3 * gt + 1], RP[3 * gi + 2] - LP[3 * gt + 2]);
+    }
+  } else if (kind == SET_LA) {  // target pocket atom, gathers ligand atoms; harmonics of the SAME vec = rec - lig
+    const int gt = a0 + t;
+    const bool cab = A.is_cab[gt];
+    for (int i = 0; i < nl; ++i) {
+      int gi = l0 + i;
+      bool in = cab || d2_rn(s.lx[i], s.ly[i], s.lz[i], s.ax[t], s.ay[t], s.az[t]) < A.cross_cut2;
+      if (in) emit(gt, gi, -1, RP[3 * gt] - LP[3 * gi], RP[3 * gt + 1] - LP[3 * gi + 1], RP[3 * gt + 2] - LP[3 * gi + 2]);
+    }
+  }
+  return cnt;
+}
+
+// pseudotorque graphs: target = torsion bond (mid-point), gathers atoms within r, first `cap` by index
+template <bool EMIT>
+__device__ int torsion_edges(const GraphArgs& A, int kind, int tgt, const float* P, int p0, int np, const float* px,
+                             const float* py, const float* pz, int u, int v, float r2, int cap, int base) {
+  const EdgeSet& S = A.set[kind];
+  float mx = (P[3 * u] + P[3 * v]) / 2, my = (P[3 * u + 1] + P[3 * v + 1]) / 2, mz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
+  float b9[9];
+  if (EMIT) vec_sh(P[3 * v] - P[3 * u], P[3 * v + 1] - P[3 * u + 1], P[3 * v + 2] - P[3 * u + 2], b9);
+  int cnt = 0;
+  for (int i = 0; i < np && cnt < cap; ++i) {
+    if (d2_rn(mx, my, mz, px[i], py[i], pz[i]) < r2) {
+      if (EMIT) {
+        int e = base + cnt;
+        if (e < S.cap) {
+          int gi = p0 + i;
+          float a9[9];
+          float d = vec_sh(P[3 * gi] - mx, P[3 * gi + 1] - my, P[3 * gi + 2] - mz, a9);
+          S.tgt[e] = tgt; S.gth[e] = gi; S.aux[e] = -1; S.dist[e] = d;
+          // FullTensorProduct(sh(0e+1o+2e), 2e): only the 0e (2e x 2e), 1o (1o x 2e), 1e (2e x 2e) blocks
+          // can reach the scalar outputs of the torsion conv; coefficient sqrt(2 l_out + 1) folded.
+          const float* a1 = a9 + 1; const float* a2 = a9 + 4; const float* b = b9 + 4;
+          const float r3 = 1.7320508075688772f;
+          float* o = S.sh + (size_t)e * SH_LD;
+          o[0] = (a2[0] * b[0] + a2[1] * b[1] + a2[2] * b[2] + a2[3] * b[3] + a2[4] * b[4]) * 0.4472135954999579f;
+          {  // 1o = sqrt3 * w3j(1,2,1): symmetric traceless M(b) a1 / sqrt10
+            float m00 = -b[2] - r3 * b[4], m01 = r3 * b[1], m02 = r3 * b[0], m11 = 2.f * b[2], m12 = r3 * b[3],
+                  m22 = -b[2] + r3 * b[4];
+            const float c = 0.31622776601683794f;
+            o[1] = c * (m00 * a1[0] + m01 * a1[1] + m02 * a1[2]);
+            o[2] = c * (m01 * a1[0] + m11 * a1[1] + m12 * a1[2]);
+            o[3] = c * (m02 * a1[0] + m12 * a1[1] + m22 * a1[2]);
+          }
+          {  // 1e = sqrt3 * w3j(2,2,1)[i,j,k] a2_i b_j ; table in units of 1/sqrt30
+            const float c = 0.31622776601683794f;
+            float k0 = -a2[0] * b[1] + a2[1] * b[0] + r3 * a2[2] * b[3] - r3 * a2[3] * b[2] + a2[3] * b[4] - a2[4] * b[3];
+            float k1 = -2.f * a2[0] * b[4] - a2[1] * b[3] + a2[3] * b[1] + 2.f * a2[4] * b[0];
+            float k2 = a2[0] * b[3] + r3 * a2[1] * b[2] + a2[1] * b[4] - r3 * a2[2] * b[1] - a2[3] * b[0] - a2[4] * b[1];
+            o[4] = c * k0; o[5] = c * k1; o[6] = c * k2;
+          }
+          o[7] = 0.f; o[8] = 0.f;
+        }
+      }
+      ++cnt;
+    }
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ void target_range(const GraphArgs& A, int kind, int g, int& t0, int& nt) {
+  const int* ptr = (kind == SET_LL || kind == SET_AL) ? A.b.lig_ptr
+                 : (kind == SET_AA || kind == SET_LA) ? A.b.atm_ptr
+                 : (kind == SET_TOR)                  ? A.b.tor_ptr
+                                                      : A.b.sc_ptr;
+  t0 = ptr[g];
+  nt = ptr[g + 1] - t0;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
+  __shared__ GraphLds s;
+  const int g = blockIdx.x, kind = blockIdx.y;
+  const EdgeSet& S = A.set[kind];
+  if (S.cap == 0) return;
+  int l0, nl, a0, na;
+  load_graph(s, A, g, kind, l0, nl, a0, na);
+  if (kind == SET_LL) cap_thresholds(s, s.lx, s.ly, s.lz, nl, A.lig_cut2, A.lig_cap);
+  if (kind == SET_AA) cap_thresholds(s, s.ax, s.ay, s.az, na, A.atom_cut2, A.atom_cap);
+  int t0, nt;  // first global target id of the graph, number of targets
+  target_range(A, kind, g, t0, nt);
+  int running = EMIT ? S.g_base[g] : 0;
+  int total = 0;
+  for (int c0 = 0; c0 < nt; c0 += 256) {  // chunks of 256 targets, block scan inside each
+    const int t = c0 + threadIdx.x;
+    int cnt = 0;
+    if (t < nt) {
+      if (EMIT) {
+        cnt = S.row_cnt[t0 + t];
+      } else if (kind <= SET_LA) {
+        cnt = target_edges<false>(s, A, kind, g, t, l0, nl, a0, na, 0);
+      } else if (kind == SET_TOR) {
+        int k = A.b.tor_bond[t0 + t];
+        cnt = torsion_edges<false>(A, kind, t0 + t, A.b.lig_pos, l0, nl, s.lx, s.ly, s.lz, A.b.bond_src[k],
+                                   A.b.bond_dst[k], A.lig_cut2, A.lig_cap, 0);
+      } else {
+        // side-chain bonds: mid-point of (j,k) vs the graph's pocket atoms; s.ax holds UNSCALED coords for SC
+        cnt = torsion_edges<false>(A, kind, t0 + t, A.b.rec_pos, a0, na, s.ax, s.ay, s.az, A.b.sc_bond[2 * (t0 + t)],
+                                   A.b.sc_bond[2 * (t0 + t) + 1], A.atom_cut2, A.lig_cap, 0);
+      }
+      if (!EMIT) S.row_cnt[t0 + t] = cnt;
+    }
+    // inclusive scan over the 256 threads
+    s.scan[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int v = threadIdx.x >= o ? s.scan[threadIdx.x - o] : 0;
+      __syncthreads();
+      s.scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int incl = s.scan[threadIdx.x], chunk_total = s.scan[255];
+    __syncthreads();
+    if (EMIT && t < nt) {
+      const int base = running + incl - cnt;
+      S.row_start[t0 + t] = base;
+      if (kind <= SET_LA) {
+        target_edges<true>(s, A, kind, g, t, l0, nl, a0, na, base);
+      } else if (kind == SET_TOR) {
+        int k = A.b.tor_bond[t0 + t];
+        torsion_edges<true>(A, kind, t0 + t, A.b.lig_pos, l0, nl, s.lx, s.ly, s.lz, A.b.bond_src[k], A.b.bond_dst[k],
+                            A.lig_cut2, A.lig_cap, base);
+      } else {
+        torsion_edges<true>(A, kind, t0 + t, A.b.rec_pos, a0, na, s.ax, s.ay, s.az, A.b.sc_bond[2 * (t0 + t)],
+                            A.b.sc_bond[2 * (t0 + t) + 1], A.atom_cut2, A.lig_cap, base);
+      }
+    }
+    running += chunk_total;
+    total += chunk_total;
+  }
+  if (!EMIT && threadIdx.x == 0) S.g_cnt[g] = total;
+}
+
+// exclusive scan of the per-graph totals; one block per edge set
+__global__ __launch_bounds__(256) void k_edges_scan(GraphArgs A) {
+  __shared__ int sc[256];
+  const EdgeSet& S = A.set[blockIdx.x];
+  if (S.cap == 0) { if (threadIdx.x == 0 && S.n_edges) *S.n_edges = 0; return; }
+  const int G = A.b.G;
+  int running = 0;
+  for (int c0 = 0; c0 < G; c0 += 256) {
+    int g = c0 + threadIdx.x;
+    int v = g < G ? S.g_cnt[g] : 0;
+    sc[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int w = threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+      __syncthreads();
+      sc[threadIdx.x] += w;
+      __syncthreads();
+    }
+    if (g < G) S.g_base[g] = running + sc[threadIdx.x] - v;
+    running += sc[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (running > S.cap) { atomicMin(A.err, (int)DBFR_ERR_CAPACITY); running = 0; }
+    *S.n_edges = running;
+  }
+}
+
+void launch_edges(const GraphArgs& A, bool with_heads_only, hipStream_t st) {
+  (void)with_heads_only;
+  hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G, N_SETS), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_edges<true>, dim3(A.b.G, N_SETS), dim3(256), 0, st, A);
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch vectors / static per-batch tables
+__global__ void k_batch_vectors(dbfr_batch b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
+                                int* tor_batch, int* sc_batch) {
+  const int g = blockIdx.x;
+  for (int i = b.lig_ptr[g] + threadIdx.x; i < b.lig_ptr[g + 1]; i += blockDim.x) lig_batch[i] = g;
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = b.atm_ptr[g] + threadIdx.x; i < b.atm_ptr[g + 1]; i += blockDim.x) {
+    atm_batch[i] = g;
+    int a37 = (int)b.pocket_feat[5 * i];
+    uint8_t f = (a37 == 1 || a37 == 3);  // protein_constants.atom_order['CA'], ['CB']
+    is_cab[i] = f;
+    c += f;
+  }
+  atomicAdd(&cnt, c);
+  for (int i = b.tor_ptr[g] + threadIdx.x; i < b.tor_ptr[g + 1]; i += blockDim.x) tor_batch[i] = g;
+  for (int i = b.sc_ptr[g] + threadIdx.x; i < b.sc_ptr[g + 1]; i += blockDim.x) sc_batch[i] = g;
+  __syncthreads();
+  if (threadIdx.x == 0) n_cab[g] = cnt;
+}
+
+void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
+                          int* tor_batch, int* sc_batch, hipStream_t st) {
+  hipLaunchKernelGGL(k_batch_vectors, dim3(b.G), dim3(128), 0, st, b, lig_batch, atm_batch, is_cab, n_cab, tor_batch,
+                     sc_batch);
+}
+
+// sinusoidal_embedding(emb_scale * t, 32): time_emb.py:9-26 (evaluated in double, rounded once)
+__global__ void k_time_embed(const float* t, int G, float emb_scale, float* temb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * EMB) return;
+  int g = i / EMB, k = i % EMB;
+  const int half = EMB / 2;
+  int kk = k % half;
+  float neg = -(float)(9.210340371976184 / (half - 1));        // -log(10000)/(half-1) as fp32
+  float arg = (float)kk * neg;
+  float f = (float)exp((double)arg);
+  float x = (emb_scale * t[g]) * f;
+  temb[i] = (float)(k < half ? sin((double)x) : cos((double)x));
+}
+
+void launch_time_embed(const float* t, int G, float emb_scale, float* temb, hipStream_t st) {
+  hipLaunchKernelGGL(k_time_embed, dim3((G * EMB + 255) / 256), dim3(256), 0, st, t, G, emb_scale, temb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-tiled 2-layer MLP (SimpleLinear, relu) with on-the-fly input assembly.
+//   IN_LIGNODE : [lig_node(27) | temb[g]]                rows = ligand atoms
+//   IN_LIGEDGE : [bond_feat(10) or 0 | temb[g] | gauss]  rows = edges of the ligand set
+//   IN_TG      : [temb[g] | gauss]                       rows = edges (atom / cross / centre sets)
+//   IN_G       : [gauss]                                 rows = edges (pseudotorque sets)
+enum MlpIn { IN_LIGNODE = 0, IN_LIGEDGE = 1, IN_TG = 2, IN_G = 3 };
+
+struct MlpArgs {
+  Mlp2 w;
+  int mode;
+  const int* n_rows_dev;   // device row count (edges) or null
+  int n_rows_max;
+  const float* temb;       // [G][EMB]
+  const int* row_graph_tab;  // batch vector indexed by tgt (edges) or by row (nodes)
+  const int* tgt;          // per-edge target (graph lookup) or null
+  const int* aux;          // bond index per edge (IN_LIGEDGE)
+  const float* dist;       // per-edge distance
+  const float* bond_feat;  // [EB][nfeat]
+  int nfeat;
+  const float* lig_node;   // [NL][nfeat_node]
+  int nnode;
+  const float* gs_offset;  // [EMB] GaussianSmearing buffers
+  const float* gs_coeff;   // [1]
+  float* out;              // [rows][NS]
+};
+
+#define MLP_ROWS 64
+#define MLP_MAXIN 80
+
+__global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
+  __shared__ float xin[MLP_ROWS][MLP_MAXIN + 1];
+  __shared__ float hid[MLP_ROWS][NS + 1];
+  __shared__ float w0[MLP_MAXIN * NS];
+  __shared__ float w1[NS * NS];
+  const int nrows = a.n_rows_dev ? min(*a.n_rows_dev, a.n_rows_max) : a.n_rows_max;
+  const int r0 = blockIdx.x * MLP_ROWS;
+  if (r0 >= nrows) return;
+  const int nr = min(MLP_ROWS, nrows - r0);
+  const int in = a.w.in;
+  for (int i = threadIdx.x; i < in * NS; i += 256) w0[i] = a.w.w0t[i];
+  for (int i = threadIdx.x; i < NS * NS; i += 256) w1[i] = a.w.w1t[i];
+  const float coeff = a.gs_coeff ? a.gs_coeff[0] : 0.f;
+  for (int i = threadIdx.x; i < MLP_ROWS * in; i += 256) {
+    int r = i / in, c = i - r * in;
+    float v = 0.f;
+    if (r < nr) {
+      int row = r0 + r;
+      int g = a.mode == IN_G ? 0 : a.row_graph_tab[a.tgt ? a.tgt[row] : row];
+      int cc = c;
+      if (a.mode == IN_LIGNODE) {
+        v = cc < a.nnode ? a.lig_node[(size_t)row * a.nnode + cc] : a.temb[g * EMB + cc - a.nnode];
+      } else {
+        if (a.mode == IN_LIGEDGE) {
+          if (cc < a.nfeat) { int k = a.aux[row]; v = k >= 0 ? a.bond_feat[(size_t)k * a.nfeat + cc] : 0.f; cc = -1; }
+          else cc -= a.nfeat;
+        }
+        if (cc >= 0) {
+          if (a.mode != IN_G && cc < EMB) v = a.temb[g * EMB + cc];
+          else {
+            int k = a.mode == IN_G ? cc : cc - EMB;
+            float d = fminf(a.dist[row], a.gs_offset[EMB - 1]) - a.gs_offset[k];
+            v = expf(coeff * (d * d));
+          }
+        }
+      }
+    }
+    xin[r][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 192) {
+    const int c = threadIdx.x % NS, eg = threadIdx.x / NS;
+    const float b = a.w.b0 ? a.w.b0[c] : 0.f;
+    for (int r = eg; r < MLP_ROWS; r += 4) {
+      float acc = b;
+      for (int i = 0; i < in; ++i) acc += w0[i * NS + c] * xin[r][i];
+      hid[r][c] = fmaxf(acc, 0.f);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 192) {
+    const int c = threadIdx.x % NS, eg = threadIdx.x / NS;
+    const float b = a.w.b1 ? a.w.b1[c] : 0.f;
+    for (int r = eg; r < nr; r += 4) {
+      float acc = b;
+      for (int i = 0; i < NS; ++i) acc += w1[i * NS + c] * hid[r][i];
+      a.out[(size_t)(r0 + r) * NS + c] = acc;
+    }
+  }
+}
+
+void launch_mlp(const MlpArgs& a, hipStream_t st) {
+  if (a.n_rows_max <= 0) return;
+  hipLaunchKernelGGL(k_mlp, dim3((a.n_rows_max + MLP_ROWS - 1) / MLP_ROWS), dim3(256), 0, st, a);
+}
+
+// AtomEncoder (equibind_encoder.py:68-88): sum of 5 categorical embeddings, then
+// x += Linear_nobias([x | temb[g]])   (scalar_dim = 0 + sigma_embed_dim)
+struct AtomEncArgs {
+  const float* pocket_feat;  // [NA][5]
+  const int* atm_batch;
+  const float* temb;
+  const float* emb[5];       // [dim_i][NS]
+  int dims[5];
+  const float* lin_t;        // [NS+EMB][NS] transposed scalar_lin.weight
+  int NA;
+  float* out;                // [NA][NS]
+};
+
+__global__ __launch_bounds__(256) void k_atom_encoder(AtomEncArgs a) {
+  __shared__ float w[(NS + EMB) * NS];
+  __shared__ float x[16][NS + EMB];
+  for (int i = threadIdx.x; i < (NS + EMB) * NS; i += 256) w[i] = a.lin_t[i];
+  const int r0 = blockIdx.x * 16;
+  for (int i = threadIdx.x; i < 16 * (NS + EMB); i += 256) {
+    int r = i / (NS + EMB), c = i % (NS + EMB);
+    int row = r0 + r;
+    float v = 0.f;
+    if (row < a.NA) {
+      if (c < NS) {
+        for (int f = 0; f < 5; ++f) {
+          int id = (int)a.pocket_feat[(size_t)row * 5 + f];
+          id = min(max(id, 0), a.dims[f] - 1);
+          v += a.emb[f][(size_t)id * NS + c];
+        }
+      } else {
+        v = a.temb[a.atm_batch[row] * EMB + c - NS];
+      }
+    }
+    x[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * NS; i += 256) {
+    int r = i / NS, c = i % NS;
+    int row = r0 + r;
+    if (row >= a.NA) continue;
+    float acc = 0.f;
+    for (int k = 0; k < NS + EMB; ++k) acc += w[k * NS + c] * x[r][k];
+    a.out[(size_t)row * NS + c] = x[r][c] + acc;
+  }
+}
+
+void launch_atom_encoder(const AtomEncArgs& a, hipStream_t st) {
+  if (a.NA <= 0) return;
+  hipLaunchKernelGGL(k_atom_encoder, dim3((a.NA + 15) / 16), dim3(256), 0, st, a);
+}

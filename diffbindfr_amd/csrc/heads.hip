@@ -1,0 +1,389 @@
+// Score heads and the on-device reverse-SDE geometry updates for gfx950.
+//
+// Replaces:
+//   build_center_conv_graph + tr/rot magnitude MLPs + sigma scaling     tpscore.py:529-543,554-558,684-710
+//   pseudotorque bond attributes, tor/sc_tor final tanh-MLPs             tpscore.py:546-571,716,741
+//   Euler-Maruyama perturbations                                         scFlex.py:154-183,197-205
+//   update_batchlig_pos -> modify_conformer (+Kabsch)                    conformer_utils.py:305-355,420-473
+//   chi update + build_pdb_from_template                                 scFlex.py:207-226; aaframe.py:778-994
+#include "common.h"
+
+#define MAX_NL 256
+
+__device__ __forceinline__ void vec_sh9(float vx, float vy, float vz, float* sh9, float* dist) {
+  float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+  float inv = 1.0f / fmaxf(nrm, 1e-12f);
+  float x = vx * inv, y = vy * inv, z = vz * inv;
+  const float s3 = 1.7320508075688772f, s15 = 3.872983346207417f, s5 = 2.23606797749979f;
+  sh9[0] = 1.0f; sh9[1] = s3 * x; sh9[2] = s3 * y; sh9[3] = s3 * z;
+  sh9[4] = s15 * x * z; sh9[5] = s15 * x * y; sh9[6] = s5 * (y * y - 0.5f * (x * x + z * z));
+  sh9[7] = s15 * y * z; sh9[8] = (s15 * 0.5f) * (z * z - x * x);
+  *dist = nrm;
+}
+
+// centre graph: one edge per ligand atom (tgt = graph, gth = atom), vec = pos - centroid
+__global__ void k_center_edges(dbfr_batch b, int* tgt, int* gth, float* dist, float* sh, int* row_start, int* row_cnt) {
+  const int g = blockIdx.x;
+  const int l0 = b.lig_ptr[g], nl = b.lig_ptr[g + 1] - l0;
+  __shared__ float c[3];
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int i = 0; i < nl; ++i) s += b.lig_pos[3 * (l0 + i) + threadIdx.x];   // index_add_ order
+    c[threadIdx.x] = s / (float)nl;
+  }
+  if (threadIdx.x == 0) { row_start[g] = l0; row_cnt[g] = nl; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+    int a = l0 + i;
+    float s9[9], d;
+    vec_sh9(b.lig_pos[3 * a] - c[0], b.lig_pos[3 * a + 1] - c[1], b.lig_pos[3 * a + 2] - c[2], s9, &d);
+    tgt[a] = g; gth[a] = a; dist[a] = d;
+    for (int k = 0; k < 9; ++k) sh[(size_t)a * SH_LD + k] = s9[k];
+  }
+}
+
+void launch_center_edges(const dbfr_batch& b, int* tgt, int* gth, float* dist, float* sh, int* row_start, int* row_cnt,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_center_edges, dim3(b.G), dim3(64), 0, st, b, tgt, gth, dist, sh, row_start, row_cnt);
+}
+
+// tr / rot heads: global_pred[G][12] = [1o_a 1o_b 1e_a 1e_b]
+struct TrRotArgs {
+  const float* gp; const float* temb; const float* tr_sigma; const float* rot_norm;
+  Mlp2 tr, rot; int G; int scale_by_sigma; float* tr_out; float* rot_out; int* err;
+};
+
+__device__ float head_mlp(const Mlp2& w, float nrm, const float* temb) {
+  float out = w.b1 ? w.b1[0] : 0.f;
+  for (int h = 0; h < w.hid; ++h) {
+    float a = w.b0 ? w.b0[h] : 0.f;
+    a += w.w0t[h] * nrm;                               // w0t [in][hid], in index 0 = norm
+    for (int i = 0; i < EMB; ++i) a += w.w0t[(1 + i) * w.hid + h] * temb[i];
+    out += w.w1t[h] * fmaxf(a, 0.f);                   // w1t [hid][1]
+  }
+  return out;
+}
+
+__global__ void k_trrot(TrRotArgs a) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.G) return;
+  const float* v = a.gp + (size_t)g * 12;
+  float tr[3] = {v[0] + v[6], v[1] + v[7], v[2] + v[8]};
+  float rt[3] = {v[3] + v[9], v[4] + v[10], v[5] + v[11]};
+  float ntr = sqrtf(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]);
+  float nrt = sqrtf(rt[0] * rt[0] + rt[1] * rt[1] + rt[2] * rt[2]);
+  float mtr = head_mlp(a.tr, ntr, a.temb + g * EMB);
+  float mrt = head_mlp(a.rot, nrt, a.temb + g * EMB);
+  for (int k = 0; k < 3; ++k) {
+    float t = tr[k] / ntr * mtr, r = rt[k] / nrt * mrt;
+    if (a.scale_by_sigma) { t = t / a.tr_sigma[g]; r = r * a.rot_norm[g]; }
+    if (!isfinite(t) || !isfinite(r)) atomicMin(a.err, (int)DBFR_ERR_NUMERIC);
+    a.tr_out[3 * g + k] = t;
+    a.rot_out[3 * g + k] = r;
+  }
+}
+
+void launch_trrot(const TrRotArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_trrot, dim3((a.G + 63) / 64), dim3(64), 0, st, a);
+}
+
+// bond_attr[k][:NS] = x[b0][:NS] + x[b1][:NS]
+__global__ void k_bond_attr(const float* x, int ldx, const int* b0, const int* b1, const int* bsel, int stride, int n,
+                            float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * NS) return;
+  int k = i / NS, c = i % NS;
+  int u, v;
+  if (bsel) { int e = bsel[k]; u = b0[e]; v = b1[e]; }
+  else { u = b0[(size_t)k * stride]; v = b0[(size_t)k * stride + 1]; }
+  out[i] = x[(size_t)u * ldx + c] + x[(size_t)v * ldx + c];
+}
+
+void launch_bond_attr(const float* x, int ldx, const int* b0, const int* b1, const int* bsel, int stride, int n,
+                      float* out, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_bond_attr, dim3((n * NS + 255) / 256), dim3(256), 0, st, x, ldx, b0, b1, bsel, stride, n, out);
+}
+
+// torsion heads: tanh-MLP(96 -> 48 -> 1, no bias) * sqrt(score_norm2)
+__global__ void k_tor_final(const float* feat, Mlp2 w, const float* norm2, int scale, int n, float* out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float* f = feat + (size_t)k * w.in;
+  float o = 0.f;
+  for (int h = 0; h < w.hid; ++h) {
+    float a = 0.f;
+    for (int i = 0; i < w.in; ++i) a += w.w0t[i * w.hid + h] * f[i];
+    o += w.w1t[h] * tanhf(a);
+  }
+  if (scale) o *= sqrtf(norm2[k]);
+  out[k] = o;
+}
+
+void launch_tor_final(const float* feat, const Mlp2& w, const float* norm2, int scale, int n, float* out,
+                      hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_tor_final, dim3((n + 63) / 64), dim3(64), 0, st, feat, w, norm2, scale, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------ SDE step
+__device__ void axis_angle_to_rot(const float* aa, float* R) {
+  // geometry_utils/utils.py:1056-1092 (quaternion, small-angle Taylor) + :672-720 (normalise, to matrix)
+  float ang = sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+  float half = ang * 0.5f;
+  float s = (fabsf(ang) < 1e-6f) ? (0.5f - (ang * ang) / 48.f) : (sinf(half) / ang);
+  float q[4] = {cosf(half), aa[0] * s, aa[1] * s, aa[2] * s};
+  float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  float w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * x * y - 2 * w * z;         R[2] = 2 * x * z + 2 * w * y;
+  R[3] = 2 * x * y + 2 * w * z;         R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * y * z - 2 * w * x;
+  R[6] = 2 * x * z - 2 * w * y;         R[7] = 2 * y * z + 2 * w * x;         R[8] = w * w - x * x - y * y + z * z;
+}
+
+// rotation of the Kabsch problem: R = V diag(1,1,sign) U^T for H = U S V^T (one-sided Jacobi, fp64)
+__device__ double kabsch_rotation(const double* Hin, double* R) {
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) A[i] = Hin[i];
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 3; ++i) { al += A[3 * i + p] * A[3 * i + p]; be += A[3 * i + q] * A[3 * i + q]; ga += A[3 * i + p] * A[3 * i + q]; }
+        off += ga * ga;
+        if (fabs(ga) <= 1e-300 || ga * ga <= 1e-32 * al * be) continue;
+        double zeta = (be - al) / (2.0 * ga);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          double ap = A[3 * i + p], aq = A[3 * i + q];
+          A[3 * i + p] = c * ap - s * aq; A[3 * i + q] = s * ap + c * aq;
+          double vp = V[3 * i + p], vq = V[3 * i + q];
+          V[3 * i + p] = c * vp - s * vq; V[3 * i + q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-60) break;
+  }
+  double sv[3], U[9];
+  int kmin = 0;
+  for (int k = 0; k < 3; ++k) {
+    sv[k] = sqrt(A[k] * A[k] + A[3 + k] * A[3 + k] + A[6 + k] * A[6 + k]);
+    if (sv[k] < sv[kmin]) kmin = k;
+  }
+  double smax = fmax(sv[0], fmax(sv[1], sv[2]));
+  for (int k = 0; k < 3; ++k)
+    for (int i = 0; i < 3; ++i) U[3 * i + k] = sv[k] > 1e-12 * smax ? A[3 * i + k] / sv[k] : 0.0;
+  if (!(sv[kmin] > 1e-12 * smax)) {  // rank deficient: complete the basis
+    int a = (kmin + 1) % 3, b = (kmin + 2) % 3;
+    U[0 + kmin] = U[3 + a] * U[6 + b] - U[6 + a] * U[3 + b];
+    U[3 + kmin] = U[6 + a] * U[0 + b] - U[0 + a] * U[6 + b];
+    U[6 + kmin] = U[0 + a] * U[3 + b] - U[3 + a] * U[0 + b];
+  }
+  auto build = [&](double sgn) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double r = 0;
+        for (int k = 0; k < 3; ++k) r += V[3 * i + k] * (k == kmin ? sgn : 1.0) * U[3 * j + k];
+        R[3 * i + j] = r;
+      }
+    return R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+  };
+  double det = build(1.0);
+  if (det < 0) det = build(-1.0);
+  return det;
+}
+
+struct SdeLigArgs {
+  dbfr_batch b;
+  const float* tr_score; const float* rot_score; const float* tor_score;
+  const float* z_tr; const float* z_rot; const float* z_tor;     // this step's slices
+  float dt, tr_g2, tr_gsdt, rot_g2, rot_gsdt, tor_g2, tor_gsdt;
+  float* traj;   // [NL,3] slice or null
+  int* err;
+};
+
+__device__ __forceinline__ float perturb(float g2, float score, float dt, float gsdt, float z) {
+  return __fadd_rn(__fmul_rn(__fmul_rn(g2, score), dt), __fmul_rn(gsdt, z));
+}
+
+__global__ __launch_bounds__(128) void k_sde_ligand(SdeLigArgs a) {
+  __shared__ float fx[MAX_NL], fy[MAX_NL], fz[MAX_NL], rx[MAX_NL], ry[MAX_NL], rz[MAX_NL];
+  __shared__ float sh_c[3], sh_R[9], sh_t[3], sh_v[3];
+  __shared__ double sh_H[9], sh_ca[3], sh_cb[3];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int l0 = a.b.lig_ptr[g], nl = a.b.lig_ptr[g + 1] - l0;
+  const int k0 = a.b.tor_ptr[g], nt = a.b.tor_ptr[g + 1] - k0;
+  for (int i = tid; i < nl; i += blockDim.x) {
+    fx[i] = a.b.lig_pos[3 * (l0 + i)]; fy[i] = a.b.lig_pos[3 * (l0 + i) + 1]; fz[i] = a.b.lig_pos[3 * (l0 + i) + 2];
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const float* p = tid == 0 ? fx : tid == 1 ? fy : fz;
+    float s = 0.f;
+    for (int i = 0; i < nl; ++i) s += p[i];
+    sh_c[tid] = s / (float)nl;
+    sh_t[tid] = perturb(a.tr_g2, a.tr_score[3 * g + tid], a.dt, a.tr_gsdt, a.z_tr[3 * g + tid]);
+  }
+  if (tid == 0) {
+    float rp[3];
+    for (int k = 0; k < 3; ++k) rp[k] = perturb(a.rot_g2, a.rot_score[3 * g + k], a.dt, a.rot_gsdt, a.z_rot[3 * g + k]);
+    axis_angle_to_rot(rp, sh_R);
+  }
+  __syncthreads();
+  for (int i = tid; i < nl; i += blockDim.x) {   // rigid = (x - c) R^T + tr + c
+    float x = fx[i] - sh_c[0], y = fy[i] - sh_c[1], z = fz[i] - sh_c[2];
+    float nx = (x * sh_R[0] + y * sh_R[1] + z * sh_R[2]) + sh_t[0] + sh_c[0];
+    float ny = (x * sh_R[3] + y * sh_R[4] + z * sh_R[5]) + sh_t[1] + sh_c[1];
+    float nz = (x * sh_R[6] + y * sh_R[7] + z * sh_R[8]) + sh_t[2] + sh_c[2];
+    fx[i] = rx[i] = nx; fy[i] = ry[i] = ny; fz[i] = rz[i] = nz;
+  }
+  __syncthreads();
+  if (nt > 0) {
+    for (int k = 0; k < nt; ++k) {   // sequential, order dependent (conformer_utils.py:313-326)
+      const float upd = perturb(a.tor_g2, a.tor_score[k0 + k], a.dt, a.tor_gsdt, a.z_tor[k0 + k]);
+      if (upd == 0.f) continue;      // uniform over the block
+      const int e = a.b.tor_bond[k0 + k];
+      const int u = a.b.bond_src[e] - l0, v = a.b.bond_dst[e] - l0;
+      if (tid == 0) {
+        float ax[3] = {fx[u] - fx[v], fy[u] - fy[v], fz[u] - fz[v]};
+        float nrm = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        float rv[3] = {ax[0] * upd / nrm, ax[1] * upd / nrm, ax[2] * upd / nrm};
+        axis_angle_to_rot(rv, sh_R);
+        sh_v[0] = fx[v]; sh_v[1] = fy[v]; sh_v[2] = fz[v];
+      }
+      __syncthreads();
+      const uint8_t* mask = a.b.rot_mask + a.b.rot_mask_off[k0 + k];
+      for (int i = tid; i < nl; i += blockDim.x)
+        if (mask[i]) {
+          float x = fx[i] - sh_v[0], y = fy[i] - sh_v[1], z = fz[i] - sh_v[2];
+          fx[i] = (x * sh_R[0] + y * sh_R[1] + z * sh_R[2]) + sh_v[0];
+          fy[i] = (x * sh_R[3] + y * sh_R[4] + z * sh_R[5]) + sh_v[1];
+          fz[i] = (x * sh_R[6] + y * sh_R[7] + z * sh_R[8]) + sh_v[2];
+        }
+      __syncthreads();
+    }
+    // Kabsch: align flexible onto rigid (superimposition.py:375-410)
+    if (tid == 0) {
+      double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+      for (int i = 0; i < nl; ++i) { ca[0] += fx[i]; ca[1] += fy[i]; ca[2] += fz[i]; cb[0] += rx[i]; cb[1] += ry[i]; cb[2] += rz[i]; }
+      for (int k = 0; k < 3; ++k) { ca[k] /= nl; cb[k] /= nl; sh_ca[k] = ca[k]; sh_cb[k] = cb[k]; }
+      double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < nl; ++i) {
+        double am[3] = {fx[i] - ca[0], fy[i] - ca[1], fz[i] - ca[2]};
+        double bm[3] = {rx[i] - cb[0], ry[i] - cb[1], rz[i] - cb[2]};
+        for (int p = 0; p < 3; ++p)
+          for (int q = 0; q < 3; ++q) H[3 * p + q] += am[p] * bm[q];
+      }
+      double R[9];
+      double det = kabsch_rotation(H, R);
+      if (fabs(det - 1.0) >= 3e-3) atomicMin(a.err, (int)DBFR_ERR_NUMERIC);
+      for (int k = 0; k < 9; ++k) sh_H[k] = R[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < nl; i += blockDim.x) {   // x R^T + t,  t = -R ca + cb
+      double x = fx[i] - sh_ca[0], y = fy[i] - sh_ca[1], z = fz[i] - sh_ca[2];
+      fx[i] = (float)(sh_H[0] * x + sh_H[1] * y + sh_H[2] * z + sh_cb[0]);
+      fy[i] = (float)(sh_H[3] * x + sh_H[4] * y + sh_H[5] * z + sh_cb[1]);
+      fz[i] = (float)(sh_H[6] * x + sh_H[7] * y + sh_H[8] * z + sh_cb[2]);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < nl; i += blockDim.x) {
+    float* o = a.b.lig_pos + 3 * (l0 + i);
+    o[0] = fx[i]; o[1] = fy[i]; o[2] = fz[i];
+    if (a.traj) { float* t = a.traj + 3 * (l0 + i); t[0] = fx[i]; t[1] = fy[i]; t[2] = fz[i]; }
+  }
+}
+
+void launch_sde_ligand(const SdeLigArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_sde_ligand, dim3(a.b.G), dim3(128), 0, st, a);
+}
+
+// chi[mask] += perturb   (scFlex.py:208-210)
+__global__ void k_sc_update(dbfr_batch b, const float* score, const float* z, float dt, float g2, float gsdt) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= b.NSC) return;
+  int rc = b.sc_res_chi[k];
+  int res = rc >> 2, chi = rc & 3;
+  float* t = b.torsion_angle + (size_t)res * 5 + 1 + chi;
+  *t = *t + perturb(g2, score[k], dt, gsdt, z[k]);
+}
+
+// side-chain rebuild: 8 rigid frames per residue -> atom14 -> compacted rec_pos
+__global__ void k_atom14(dbfr_batch b, const int* a14_group /*[21][14]*/, float* atom14_out, float* traj14) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= b.NR) return;
+  const float* ang = b.torsion_angle + (size_t)r * 5;
+  // frames: 0 bb (identity), 3 psi, 4..7 chi1..4; (sin,cos) normalised with eps 1e-6 (msc.py:295-310)
+  float Rf[8][9], tf[8][3];
+  const float* DF = b.default_frame + (size_t)r * 128;
+  for (int k = 0; k < 8; ++k) {
+    float s, c;
+    if (k == 0) { s = 0.f; c = 1.f; }
+    else if (k < 3) { s = 0.f; c = 0.f; }
+    else { s = sinf(ang[k - 3]); c = cosf(ang[k - 3]); }
+    float nrm = fmaxf(sqrtf(s * s + c * c), 1e-6f);
+    s /= nrm; c /= nrm;
+    const float* D = DF + k * 16;   // 4x4 row-major
+    // R = Rd * Rx(s,c),  Rx = [[1,0,0],[0,c,-s],[0,s,c]]
+    for (int i = 0; i < 3; ++i) {
+      float d0 = D[4 * i], d1 = D[4 * i + 1], d2 = D[4 * i + 2];
+      Rf[k][3 * i] = d0; Rf[k][3 * i + 1] = d1 * c + d2 * s; Rf[k][3 * i + 2] = -d1 * s + d2 * c;
+      tf[k][i] = D[4 * i + 3];
+    }
+  }
+  for (int k = 5; k < 8; ++k) {   // chain chi2..4 onto the previous chi frame
+    float Rn[9], tn[3];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j)
+        Rn[3 * i + j] = Rf[k - 1][3 * i] * Rf[k][j] + Rf[k - 1][3 * i + 1] * Rf[k][3 + j] + Rf[k - 1][3 * i + 2] * Rf[k][6 + j];
+      tn[i] = tf[k - 1][i] + (Rf[k - 1][3 * i] * tf[k][0] + Rf[k - 1][3 * i + 1] * tf[k][1] + Rf[k - 1][3 * i + 2] * tf[k][2]);
+    }
+    for (int i = 0; i < 9; ++i) Rf[k][i] = Rn[i];
+    for (int i = 0; i < 3; ++i) tf[k][i] = tn[i];
+  }
+  const float* Rb = b.backbone_rots + (size_t)r * 9;
+  const float* tb = b.backbone_transl + (size_t)r * 3;
+  const int aa = b.sequence[r];
+  for (int a = 0; a < 14; ++a) {
+    const int slot = b.atom14_slot[(size_t)r * 14 + a];
+    float out[3] = {0.f, 0.f, 0.f};
+    if (slot >= 0) {
+      const int k = a14_group[aa * 14 + a];
+      const float* p = b.rigid_group_positions + ((size_t)r * 14 + a) * 3;
+      // global frame = backbone o frame_k
+      float Rg[9], tg[3];
+      for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+          Rg[3 * i + j] = Rb[3 * i] * Rf[k][j] + Rb[3 * i + 1] * Rf[k][3 + j] + Rb[3 * i + 2] * Rf[k][6 + j];
+        tg[i] = tb[i] + (Rb[3 * i] * tf[k][0] + Rb[3 * i + 1] * tf[k][1] + Rb[3 * i + 2] * tf[k][2]);
+      }
+      for (int i = 0; i < 3; ++i) out[i] = (Rg[3 * i] * p[0] + Rg[3 * i + 1] * p[1] + Rg[3 * i + 2] * p[2]) + tg[i];
+      float* rp = b.rec_pos + (size_t)slot * 3;
+      rp[0] = out[0]; rp[1] = out[1]; rp[2] = out[2];
+    }
+    if (atom14_out) { float* o = atom14_out + ((size_t)r * 14 + a) * 3; o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; }
+    if (traj14) { float* o = traj14 + ((size_t)r * 14 + a) * 3; o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; }
+  }
+}
+
+void launch_sidechain(const dbfr_batch& b, const float* score, const float* z, float dt, float g2, float gsdt,
+                      const int* a14_group, float* atom14_out, float* traj14, hipStream_t st) {
+  if (b.NSC > 0) hipLaunchKernelGGL(k_sc_update, dim3((b.NSC + 255) / 256), dim3(256), 0, st, b, score, z, dt, g2, gsdt);
+  if (b.NR > 0) hipLaunchKernelGGL(k_atom14, dim3((b.NR + 63) / 64), dim3(64), 0, st, b, a14_group, atom14_out, traj14);
+}
+
+// ------------------------------------------------------------------------------------------------ small utilities
+__global__ void k_fill(float* p, float v, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill(float* p, float v, int n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(k_fill, dim3((n + 255) / 256), dim3(256), 0, st, p, v, n);
+}
+__global__ void k_set_int(int* p, int v) { *p = v; }
+void launch_set_int(int* p, int v, hipStream_t st) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, p, v); }
+__global__ void k_acc_flops(const int* n_edges, double per_edge, double* counter) { *counter += per_edge * (double)*n_edges; }
+void launch_acc_flops(const int* n_edges, double per_edge, double* counter, hipStream_t st) {
+  hipLaunchKernelGGL(k_acc_flops, dim3(1), dim3(1), 0, st, n_edges, per_edge, counter);
+}

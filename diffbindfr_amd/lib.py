@@ -1,0 +1,123 @@
+"""ctypes binding of libdbfr.so (include/dbfr.h).  Fails loudly when the HIP
+library is missing: there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdbfr.so")
+
+DBFR_OK = 0
+ERRORS = {-1: "DBFR_ERR_ARG", -2: "DBFR_ERR_HIP", -3: "DBFR_ERR_CAPACITY", -4: "DBFR_ERR_SELFTEST",
+          -5: "DBFR_ERR_NUMERIC"}
+
+i32, f32, vp = C.c_int32, C.c_float, C.c_void_p
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [(n, i32) for n in ("ns", "nv", "sh_lmax", "num_conv_layers", "lig_node_features",
+                                   "lig_edge_features", "distance_embed_dim", "sigma_embed_dim")] + \
+               [(n, f32) for n in ("emb_scale", "lig_cutoff", "atom_cutoff", "cross_cutoff", "center_max_distance")] + \
+               [(n, i32) for n in ("atom_max_neighbors", "lig_max_neighbors", "dynamic_max_cross", "scale_by_sigma",
+                                   "no_sc_torsion")]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", vp), ("numel", C.c_int64)]
+
+
+_BATCH_INTS = ("G", "NL", "NA", "NR", "EB", "NTOR", "NSC", "max_nl", "max_na", "max_nr")
+_BATCH_PTRS = ("lig_ptr", "lig_node", "lig_pos", "bond_src", "bond_dst", "bond_feat", "bond_ptr", "tor_ptr",
+               "tor_bond", "rot_mask", "rot_mask_off", "atm_ptr", "res_ptr", "pocket_feat", "rec_pos", "sequence",
+               "backbone_transl", "backbone_rots", "default_frame", "rigid_group_positions", "torsion_angle",
+               "atom14_slot", "sc_res_chi", "sc_bond", "sc_ptr")
+
+
+class Batch(C.Structure):
+    _fields_ = [(n, i32) for n in _BATCH_INTS] + [(n, vp) for n in _BATCH_PTRS]
+
+
+class Limits(C.Structure):
+    _fields_ = [("aa_avg_neighbors", i32), ("cross_avg_neighbors", i32)]
+
+
+class Cond(C.Structure):
+    _fields_ = [(n, vp) for n in ("t", "tr_sigma", "rot_score_norm", "tor_score_norm2", "sc_tor_score_norm2")]
+
+
+class Scores(C.Structure):
+    _fields_ = [(n, vp) for n in ("tr", "rot", "tor", "sc_tor")]
+
+
+class Step(C.Structure):
+    _fields_ = [(n, f32) for n in ("t", "dt", "tr_sigma", "rot_score_norm", "tor_score_norm2", "tr_g2", "tr_gsdt",
+                                   "rot_g2", "rot_gsdt", "tor_g2", "tor_gsdt", "sc_g2", "sc_gsdt")]
+
+
+class Noise(C.Structure):
+    _fields_ = [(n, vp) for n in ("z_tr", "z_rot", "z_tor", "z_sc")]
+
+
+# every symbol include/dbfr.h declares (tests check that the library exports all of them)
+SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
+           "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
+           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_reduce_ln"]
+
+_lib = None
+
+
+class DbfrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdbfr.so; raises if it has not been built (python -m diffbindfr_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DbfrError(f"{LIB_PATH} is missing: build the HIP library first "
+                        f"(python -m diffbindfr_amd.build). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.dbfr_last_error.restype = C.c_char_p
+    lib.dbfr_model_create.argtypes = [C.POINTER(ModelCfg), C.POINTER(Tensor), i32, C.POINTER(vp)]
+    lib.dbfr_model_destroy.argtypes = [vp]
+    lib.dbfr_model_destroy.restype = None
+    lib.dbfr_workspace_bytes.argtypes = [vp, C.POINTER(Batch), C.POINTER(Limits), C.POINTER(C.c_size_t)]
+    lib.dbfr_score.argtypes = [vp, C.POINTER(Batch), C.POINTER(Cond), C.POINTER(Scores), vp, C.c_size_t,
+                               C.POINTER(Limits), vp]
+    lib.dbfr_sample.argtypes = [vp, C.POINTER(Batch), C.POINTER(Step), i32, C.POINTER(Noise), vp, vp, vp, vp,
+                                C.c_size_t, C.POINTER(Limits), vp]
+    lib.dbfr_status_sync.argtypes = [vp, vp, C.POINTER(C.c_int64)]
+    lib.dbfr_wigner3j.argtypes = [i32, i32, i32, C.POINTER(C.c_double)]
+    lib.dbfr_conv_paths.argtypes = [i32, C.POINTER(i32), i32, C.POINTER(i32)]
+    lib.dbfr_profile_enable.argtypes = [vp, i32]
+    lib.dbfr_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i32]
+    lib.dbfr_workspace_layout.argtypes = [vp, C.POINTER(Batch), C.POINTER(Limits), C.c_char_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i32]
+    lib.dbfr_test_conv.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp]
+    lib.dbfr_test_reduce_ln.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp]
+    if lib.dbfr_abi_version() != 1:
+        raise DbfrError("libdbfr ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != DBFR_OK:
+        msg = load().dbfr_last_error().decode()
+        raise DbfrError(f"{ERRORS.get(rc, rc)}: {msg}")
+
+
+def workspace_views(model_handle, batch_c, limits, ws):
+    """dict name -> uint8 view of the internal buffer inside the torch workspace (tests/debug)."""
+    lib = load()
+    names = C.create_string_buffer(8192)
+    offs = (C.c_size_t * 128)()
+    nbytes = (C.c_size_t * 128)()
+    n = lib.dbfr_workspace_layout(model_handle, C.byref(batch_c), C.byref(limits), names, 8192, offs, nbytes, 128)
+    if n < 0:
+        check(n)
+    out = {}
+    for i, nm in enumerate(names.value.decode().split(";")[:n]):
+        out[nm] = ws[offs[i]:offs[i] + nbytes[i]]
+    return out

@@ -1,0 +1,88 @@
+"""mmcv-style registries: the reference's operator/plugin boundary for this path.
+
+Mirrors druglib/utils/registry.py:60-358 (``Registry.register_module(name=, force=)``,
+``Registry.build(cfg, default_args=)`` popping ``type``) and the registry objects of
+druglib/models/builder.py:7-17.  When ``druglib`` itself is importable the classes of
+this package are ALSO registered into the reference's own ``INTERACTION`` /
+``MLDOCK_BUILDER`` so that ``--cfg-options model.type=DiffBindFRHIP`` (or
+``model.diffusion_model.type=TensorProductModelHIP``) selects them from
+DiffBindFR/app/predict.py with no change to the reference.
+"""
+import copy
+
+
+class Registry:
+    def __init__(self, name):
+        self._name = name
+        self._module_dict = {}
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def module_dict(self):
+        return self._module_dict
+
+    def __contains__(self, key):
+        return key in self._module_dict
+
+    def __len__(self):
+        return len(self._module_dict)
+
+    def get(self, key):
+        return self._module_dict.get(key)
+
+    def _register(self, cls, name=None, force=False):
+        names = [name or cls.__name__] if not isinstance(name, (list, tuple)) else list(name)
+        for n in names:
+            if not force and n in self._module_dict:
+                raise KeyError(f"{n} is already registered in {self._name}")
+            self._module_dict[n] = cls
+
+    def register_module(self, name=None, force=False, module=None):
+        if module is not None:
+            self._register(module, name, force)
+            return module
+
+        def deco(cls):
+            self._register(cls, name, force)
+            return cls
+        return deco
+
+    def build(self, cfg, default_args=None):
+        if not isinstance(cfg, dict) or "type" not in cfg:
+            raise KeyError("`cfg` must be a dict containing the key 'type'")
+        args = copy.copy(dict(cfg))
+        typ = args.pop("type")
+        if default_args:
+            for k, v in default_args.items():
+                args.setdefault(k, v)
+        cls = self.get(typ) if isinstance(typ, str) else typ
+        if cls is None:
+            raise KeyError(f"{typ} is not in the {self._name} registry")
+        return cls(**args)
+
+
+INTERACTION = Registry("interaction")
+MLDOCK_BUILDER = Registry("mldock model builder")
+
+
+def build_interaction(cfg):
+    """druglib/models/builder.py:32-34."""
+    return INTERACTION.build(cfg)
+
+
+def register_into_druglib():
+    """Best effort: plug into the reference's registries when it is importable."""
+    try:
+        from druglib.models.builder import INTERACTION as REF_I, MLDOCK_BUILDER as REF_M  # noqa
+    except Exception:
+        return False
+    for reg, ref in ((INTERACTION, REF_I), (MLDOCK_BUILDER, REF_M)):
+        for n, cls in reg.module_dict.items():
+            try:
+                ref.register_module(name=n, module=cls)
+            except Exception:
+                pass
+    return True

@@ -1,0 +1,238 @@
+"""``TensorProductModelHIP``: drop-in for INTERACTION['TensorProductModel'].
+
+Level-1 boundary of SURVEY.md section 8(b): same constructor (``cfg`` = the ConfigDict of
+DiffBindFR/configs/diffbindfr_ts.py:107-142), same ``forward(data) -> (tr, rot, tor,
+sc_tor)``, same ``state_dict`` keys as druglib/models/Docking/interaction/tpscore.py:202-573
+(so ``load_checkpoint(strict=True)`` of DiffBindFR/common/engines.py:137-165 works), but
+the arithmetic runs in libdbfr.so (hand-written HIP for gfx950) through the C ABI of
+include/dbfr.h.  There is no CPU path: without the library / a GPU it raises.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import lib as L
+from .packing import PackedBatch, _get, _has
+from .registry import INTERACTION
+
+
+def cfg_get(cfg, path, default=None):
+    cur = cfg
+    for k in path.split("."):
+        if cur is None:
+            return default
+        if isinstance(cur, dict):
+            cur = cur.get(k)
+        else:
+            cur = getattr(cur, k, None)
+    return default if cur is None else cur
+
+
+class _SimpleLinear(nn.Module):
+    """Parameter container with the reference's key layout (tpscore.py:109-141)."""
+
+    def __init__(self, i, o, h=None, bias=True, act="relu"):
+        super().__init__()
+        h = h or o
+        self.lin = nn.Sequential(nn.Linear(i, h, bias=bias), nn.ReLU() if act == "relu" else nn.Tanh(),
+                                 nn.Dropout(0.0), nn.Linear(h, o, bias=bias))
+
+
+class _LayerNormParams(nn.Module):
+    def __init__(self, blocks):
+        super().__init__()
+        n = sum(m for m, l, p in blocks)
+        n0e = sum(m for m, l, p in blocks if l == 0 and p == 1)
+        ms = torch.cat([torch.ones(m) if (l == 0 and p == 1) else torch.zeros(m) for m, l, p in blocks])
+        self.mean_shift = nn.Parameter(ms.view(1, n, 1))
+        self.affine_weight = nn.Parameter(torch.ones(n))
+        self.affine_bias = nn.Parameter(torch.zeros(n0e))
+
+
+class _Conv(nn.Module):
+    def __init__(self, nef, W, out_blocks):
+        super().__init__()
+        self.fc = _SimpleLinear(nef, W, nef)
+        self.batch_norm = _LayerNormParams(out_blocks)
+
+
+class _Smearing(nn.Module):
+    def __init__(self, stop, n):
+        super().__init__()
+        off = torch.linspace(0.0, stop, n)
+        self.register_buffer("coeff", -0.5 / (off[1] - off[0]) ** 2)
+        self.register_buffer("offset", off)
+
+
+class _AtomEncoder(nn.Module):
+    def __init__(self, ns, dims, scalar_dim):
+        super().__init__()
+        self.atom_emb_list = nn.ModuleList([nn.Embedding(d, ns) for d in dims])
+        self.scalar_lin = nn.Linear(scalar_dim + ns, ns, bias=False)
+
+
+def conv_paths(kind):
+    """(weight_numel, path table) as the library derives them (dbfr_conv_paths)."""
+    lib = L.load()
+    tab = (C.c_int32 * (16 * 10))()
+    wn = C.c_int32()
+    n = lib.dbfr_conv_paths(kind, tab, 16, C.byref(wn))
+    if n < 0:
+        L.check(n)
+    return wn.value, [list(tab[10 * i:10 * i + 10]) for i in range(n)]
+
+
+@INTERACTION.register_module(name=["TensorProductModelHIP"])
+class TensorProductModelHIP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        g = lambda k, d=None: cfg_get(cfg, k, d)
+        assert g("task", "struct_gen") == "struct_gen", "only the score-matching task is on this path"
+        assert not g("use_second_order_repr", False), "use_second_order_repr=True is not supported"
+        self.no_sc_torsion = bool(g("no_sc_torsion", False))
+        ns, nv = int(g("ns", 48)), int(g("nv", 12))
+        se, de = int(g("sigma_embed_dim", 32)), int(g("distance_embed_dim", 32))
+        self.ns = ns
+        self.num_conv_layers = int(g("num_conv_layers", 6))
+        nl = int(g("features_dim.ligand_atom.node_features", 27))
+        ne = int(g("features_dim.ligand_atom.edge_features", 10))
+        feat = g("features_dim.protein_atom.feature_list", ((37, 22, 4, 21, 2), 0))
+        self.mcfg = L.ModelCfg(
+            ns=ns, nv=nv, sh_lmax=int(g("sh_lmax", 2)), num_conv_layers=self.num_conv_layers,
+            lig_node_features=nl, lig_edge_features=ne, distance_embed_dim=de, sigma_embed_dim=se,
+            emb_scale=float(g("emb_scale", 1000)), lig_cutoff=float(g("lig_cutoff", 5)),
+            atom_cutoff=float(g("atom_cutoff", 4)), cross_cutoff=float(g("cross_cutoff", 32)),
+            center_max_distance=float(g("center_max_distance", 32)),
+            atom_max_neighbors=int(g("atom_max_neighbors", 1000)), lig_max_neighbors=32,
+            dynamic_max_cross=int(bool(g("dynamic_max_cross", True))), scale_by_sigma=int(bool(g("scale_by_sigma", True))),
+            no_sc_torsion=int(self.no_sc_torsion))
+        # ---- parameters, named exactly like the reference module tree
+        self.lig_node_embedding = _SimpleLinear(nl + se, ns)
+        self.lig_edge_embedding = _SimpleLinear(ne + se + de, ns)
+        self.atom_node_embedding = _AtomEncoder(ns, tuple(feat[0]), int(feat[1]) + se)
+        self.atom_edge_embedding = _SimpleLinear(se + de, ns)
+        self.la_edge_embedding = _SimpleLinear(se + de, ns)
+        self.lig_distance_expansion = _Smearing(float(g("lig_cutoff", 5)), de)
+        self.atom_distance_expansion = _Smearing(float(g("atom_cutoff", 4)), de)
+        self.cross_distance_expansion = _Smearing(float(g("cross_cutoff", 32)), de)
+        seq = [[(ns, 0, 1)], [(ns, 0, 1), (nv, 1, -1)], [(ns, 0, 1), (nv, 1, -1), (nv, 1, 1)],
+               [(ns, 0, 1), (nv, 1, -1), (nv, 1, 1), (ns, 0, -1)]]
+        wn = [conv_paths(k)[0] for k in range(6)]
+        fams = ("lig_conv_layers", "atom_conv_layers", "cross_al_conv_layers", "cross_la_conv_layers")
+        for f in fams:
+            setattr(self, f, nn.ModuleList())
+        for l in range(self.num_conv_layers):
+            for f in fams:
+                getattr(self, f).append(_Conv(3 * ns, wn[min(l, 3)], seq[min(l + 1, 3)]))
+        self.center_distance_expansion = _Smearing(float(g("center_max_distance", 32)), de)
+        self.center_edge_embedding = _SimpleLinear(de + se, ns)
+        self.final_conv = _Conv(2 * ns, wn[4], [(2, 1, -1), (2, 1, 1)])
+        self.tr_final_layer = _SimpleLinear(1 + se, 1, ns)
+        self.rot_final_layer = _SimpleLinear(1 + se, 1, ns)
+        self.tor_edge_embedding = _SimpleLinear(de, ns)
+        self.tor_bond_conv = _Conv(3 * ns, wn[5], [(ns, 0, -1), (ns, 0, 1)])
+        self.tor_final_layer = _SimpleLinear(2 * ns, 1, ns, bias=False, act="tanh")
+        if not self.no_sc_torsion:
+            self.sc_edge_embedding = _SimpleLinear(de, ns)
+            self.sc_tor_bond_conv = _Conv(3 * ns, wn[5], [(ns, 0, -1), (ns, 0, 1)])
+            self.sc_tor_final_layer = _SimpleLinear(2 * ns, 1, ns, bias=False, act="tanh")
+        self._handle = None
+        self._ws = None
+        self.limits = L.Limits(24, 64)
+        self.ignored_keys = []
+
+    # ---- checkpoint compatibility: e3nn modules contribute buffers whose names are unknown offline
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        mine = set(self.state_dict().keys())
+        kept = {}
+        self.ignored_keys = []
+        for k, v in state_dict.items():
+            if k in mine:
+                kept[k] = v
+            elif ".tp." in k or k.startswith("final_tp_tor.") or ".final_tp_tor." in k:
+                self.ignored_keys.append(k)     # e3nn buffers: no parameters live there (shared_weights=False)
+            else:
+                kept[k] = v                     # genuinely unexpected -> let torch complain if strict
+        out = super().load_state_dict(kept, strict=strict, **kw)
+        self.release()
+        return out
+
+    def release(self):
+        if self._handle is not None:
+            L.load().dbfr_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def handle(self):
+        """Pack the current parameters into the device-resident model (once)."""
+        if self._handle is None:
+            lib = L.load()
+            sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+            arr = (L.Tensor * len(sd))()
+            for i, (k, v) in enumerate(sd.items()):
+                arr[i].name = k.encode()
+                arr[i].data = C.c_void_p(v.data_ptr())
+                arr[i].numel = v.numel()
+            h = C.c_void_p()
+            L.check(lib.dbfr_model_create(C.byref(self.mcfg), arr, len(sd), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def workspace(self, batch, device):
+        lib = L.load()
+        nbytes = C.c_size_t()
+        L.check(lib.dbfr_workspace_bytes(self.handle(), C.byref(batch.c), C.byref(self.limits), C.byref(nbytes)))
+        if self._ws is None or self._ws.numel() < nbytes.value or self._ws.device != torch.device(device):
+            self._ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        return self._ws
+
+    @staticmethod
+    def _device_of(data):
+        for k in ("lig_pos", "batch", "lig_node_batch"):
+            if _has(data, k):
+                return _get(data, k).device
+        raise KeyError("lig_pos")
+
+    @torch.no_grad()
+    def score_packed(self, pb, t, tr_sigma, rot_score_norm, tor_score_norm2, sc_tor_score_norm2, sync=True):
+        dev = pb.lig_pos.device
+        if dev.type != "cuda":
+            raise L.DbfrError("TensorProductModelHIP needs a ROCm device (no CPU path)")
+        lib = L.load()
+        f = lambda x: x.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        t, tr_sigma, rot_score_norm = f(t), f(tr_sigma), f(rot_score_norm)
+        tor_n2 = f(tor_score_norm2) if pb.dims["NTOR"] else torch.zeros(1, device=dev)
+        sc_n2 = f(sc_tor_score_norm2) if pb.dims["NSC"] else torch.zeros(1, device=dev)
+        G = pb.G
+        out = dict(tr=torch.empty(G, 3, device=dev), rot=torch.empty(G, 3, device=dev),
+                   tor=torch.empty(max(pb.dims["NTOR"], 1), device=dev), sc=torch.empty(max(pb.dims["NSC"], 1), device=dev))
+        ws = self.workspace(pb, dev)
+        cond = L.Cond(*(C.c_void_p(x.data_ptr()) for x in (t, tr_sigma, rot_score_norm, tor_n2, sc_n2)))
+        sc = L.Scores(*(C.c_void_p(out[k].data_ptr()) for k in ("tr", "rot", "tor", "sc")))
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.dbfr_score(self.handle(), C.byref(pb.c), C.byref(cond), C.byref(sc), C.c_void_p(ws.data_ptr()),
+                               ws.numel(), C.byref(self.limits), stream))
+        if sync:
+            L.check(lib.dbfr_status_sync(C.c_void_p(ws.data_ptr()), stream, None))
+        return out["tr"], out["rot"], out["tor"][:pb.dims["NTOR"]], out["sc"][:pb.dims["NSC"]]
+
+    def forward(self, data):
+        """tpscore.py:462-573.  ``data``: the batched EasyDict after set_time (scFlex.py:104-122)."""
+        dev = self._device_of(data)
+        pb = PackedBatch(data, dev)
+        scn = _get(data, "sc_tor_score_norm2")
+        scm = _get(data, "sc_torsion_edge_mask").bool()
+        if scn.shape == scm.shape:
+            scn = scn[scm.to(scn.device)]
+        tr, rot, tor, sc = self.score_packed(pb, _get(data, "t"), _get(data, "tr_sigma"), _get(data, "rot_score_norm"),
+                                             _get(data, "tor_score_norm2"), scn)
+        if self.no_sc_torsion:
+            return tr, rot, tor, None
+        return tr, rot, tor, sc

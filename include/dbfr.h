@@ -1,0 +1,226 @@
+/*
+ * dbfr.h -- C ABI of the MI355X-native DiffBindFR reverse-diffusion sampler.
+ *
+ * The reference (HBioquant/DiffBindFR) is 100% Python: it has no FFI for this
+ * path.  Its operator boundary is the mmcv-style registry + nn.Module contract
+ *   INTERACTION['TensorProductModel']   druglib/models/Docking/interaction/tpscore.py:202-573
+ *   MLDOCK_BUILDER['DiffBindFR']        druglib/models/Docking/scFlex.py:26-250
+ * (druglib/models/builder.py:7-34).  This header is the C ABI underneath the
+ * Python classes that plug into those registries (diffbindfr_amd/score_model.py,
+ * diffbindfr_amd/sampler.py); INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / hip types in signatures
+ *     (a hipStream_t travels as void*; NULL = the null stream);
+ *   - every entry point returns 0 on success or a negative dbfr_status;
+ *     dbfr_last_error() gives the message of the last failure on this thread;
+ *   - "host" pointers are read during the call and not retained; "device"
+ *     pointers must stay valid until the stream work that uses them is done;
+ *   - one model handle per device; a handle is thread-compatible, not thread-safe;
+ *   - all arithmetic is fp32 (the reference runs fp32: base.py:22 fp16 off);
+ *     indices are int32 on the device side.
+ */
+#ifndef DBFR_H
+#define DBFR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBFR_ABI_VERSION 1
+
+typedef enum {
+  DBFR_OK = 0,
+  DBFR_ERR_ARG = -1,       /* bad argument / unsupported configuration            */
+  DBFR_ERR_HIP = -2,       /* a HIP runtime call failed                           */
+  DBFR_ERR_CAPACITY = -3,  /* workspace edge capacity exceeded (see dbfr_limits)  */
+  DBFR_ERR_SELFTEST = -4,  /* built-in Clebsch-Gordan closed forms failed self-check */
+  DBFR_ERR_NUMERIC = -5    /* non-finite score / Kabsch determinant check failed  */
+} dbfr_status;
+
+typedef struct dbfr_model dbfr_model; /* packed weights resident in HBM */
+
+/* ---- model hyper-parameters (DiffBindFR/configs/diffbindfr_ts.py:107-142).
+ * Only the reference's inference configuration family is supported:
+ * ns=48, nv=12, sh_lmax=2, 32-d embeddings, use_second_order_repr=False.      */
+typedef struct {
+  int32_t ns, nv, sh_lmax;
+  int32_t num_conv_layers;
+  int32_t lig_node_features, lig_edge_features;
+  int32_t distance_embed_dim, sigma_embed_dim;
+  float   emb_scale;
+  float   lig_cutoff, atom_cutoff, cross_cutoff, center_max_distance;
+  int32_t atom_max_neighbors;  /* radius_graph cap for the pocket graph (1000)   */
+  int32_t lig_max_neighbors;   /* torch_cluster default cap (32), tpscore.py:586 */
+  int32_t dynamic_max_cross;   /* 1: cross cutoff = 0.2*tr_sigma + 5             */
+  int32_t scale_by_sigma;
+  int32_t no_sc_torsion;
+} dbfr_model_cfg;
+
+/* One named fp32 tensor of the reference state_dict (host memory, row-major,
+ * exactly the shape the reference module holds; names relative to
+ * TensorProductModel, e.g. "lig_conv_layers.3.fc.lin.3.weight").               */
+typedef struct {
+  const char*  name;
+  const float* data;
+  int64_t      numel;
+} dbfr_tensor;
+
+/* Builds the device-resident packed model (radial-MLP weights re-tiled into
+ * MFMA fragment order with the tensor-product path normalisation folded in).
+ * Replaces: TensorProductModel.__init__ + load_checkpoint(strict=True)
+ * (tpscore.py:215-410; DiffBindFR/common/engines.py:137-165).  Every tensor of
+ * SURVEY.md Appendix B.3 must be present; unknown names are an error.          */
+int dbfr_model_create(const dbfr_model_cfg* cfg, const dbfr_tensor* tensors, int32_t n_tensors,
+                      dbfr_model** out);
+void dbfr_model_destroy(dbfr_model* m);
+
+/* ---- one collated batch of G graphs (complex x pose), device pointers.
+ * Layout = the reference's batched dict with int32
+ * indices, CSR pointers instead of batch vectors, and the ragged python lists
+ * flattened.  Tensors marked in/out are advanced in place by dbfr_sample.       */
+typedef struct {
+  int32_t G;        /* graphs                                                    */
+  int32_t NL;       /* ligand heavy atoms, all graphs                            */
+  int32_t NA;       /* pocket heavy atoms, all graphs                            */
+  int32_t NR;       /* pocket residues, all graphs                               */
+  int32_t EB;       /* directed ligand bonds (both directions), sorted by src    */
+  int32_t NTOR;     /* ligand rotatable bonds (tor_edge_mask.sum())              */
+  int32_t NSC;      /* side-chain torsions (sc_torsion_edge_mask.sum())          */
+  int32_t max_nl, max_na, max_nr; /* per-graph maxima (host-known)               */
+  /* ligand */
+  const int32_t* lig_ptr;     /* [G+1]                                           */
+  const float*   lig_node;    /* [NL, lig_node_features]                         */
+  float*         lig_pos;     /* [NL,3]                               in/out     */
+  const int32_t* bond_src;    /* [EB] global ligand atom index                   */
+  const int32_t* bond_dst;    /* [EB]                                            */
+  const float*   bond_feat;   /* [EB, lig_edge_features]                         */
+  const int32_t* bond_ptr;    /* [NL+1] CSR of bonds by bond_src                 */
+  const int32_t* tor_ptr;     /* [G+1]  torsions per graph                       */
+  const int32_t* tor_bond;    /* [NTOR] index into bond_* (masked bonds, in order) */
+  const uint8_t* rot_mask;    /* rot_node_mask rows, one byte per ligand atom    */
+  const int64_t* rot_mask_off;/* [NTOR] byte offset of each row in rot_mask      */
+  /* pocket */
+  const int32_t* atm_ptr;     /* [G+1]                                           */
+  const int32_t* res_ptr;     /* [G+1]                                           */
+  const float*   pocket_feat; /* [NA,5] (atom37, coarse22, element4, aatype, is_backbone) */
+  float*         rec_pos;     /* [NA,3]                               in/out     */
+  const int32_t* sequence;    /* [NR]                                            */
+  const float*   backbone_transl; /* [NR,3]                                      */
+  const float*   backbone_rots;   /* [NR,3,3]                                    */
+  const float*   default_frame;   /* [NR,8,4,4]                                  */
+  const float*   rigid_group_positions; /* [NR,14,3]                             */
+  float*         torsion_angle;   /* [NR,5] (psi, chi1..4) radians    in/out     */
+  const int32_t* atom14_slot;     /* [NR,14] compact atom index or -1 (atom14_mask) */
+  const int32_t* sc_res_chi;      /* [NSC] res*4+k of each masked chi, row-major */
+  const int32_t* sc_bond;         /* [NSC,2] global atom ids (j,k) of the chi bond */
+  const int32_t* sc_ptr;          /* [G+1] side-chain torsions per graph         */
+} dbfr_batch;
+
+/* Capacity knobs of the per-step edge lists (graphs are rebuilt every step).    */
+typedef struct {
+  int32_t aa_avg_neighbors;     /* pocket graph: mean edges per atom budgeted (default 24)   */
+  int32_t cross_avg_neighbors;  /* non-CA/CB pocket atoms per ligand atom budgeted (default 64) */
+} dbfr_limits;
+
+/* Bytes of device workspace dbfr_score/dbfr_sample need for this batch shape.   */
+int dbfr_workspace_bytes(const dbfr_model* m, const dbfr_batch* b, const dbfr_limits* lim, size_t* bytes);
+
+/* ---- level 1: one score-network evaluation.
+ * Replaces TensorProductModel.forward (tpscore.py:462-573).  Per-graph /
+ * per-torsion conditioning arrives as device arrays exactly as set_time
+ * produces it (scFlex.py:104-122).  Outputs are device arrays.                  */
+typedef struct {
+  const float* t;                 /* [G]                                          */
+  const float* tr_sigma;          /* [G]                                          */
+  const float* rot_score_norm;    /* [G]                                          */
+  const float* tor_score_norm2;   /* [NTOR]                                       */
+  const float* sc_tor_score_norm2;/* [NSC] (already masked/compacted)             */
+} dbfr_cond;
+
+typedef struct {
+  float* tr;      /* [G,3]  */
+  float* rot;     /* [G,3]  */
+  float* tor;     /* [NTOR] */
+  float* sc_tor;  /* [NSC]  */
+} dbfr_scores;
+
+int dbfr_score(dbfr_model* m, const dbfr_batch* b, const dbfr_cond* cond, const dbfr_scores* out,
+               void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream);
+
+/* ---- level 2: the whole reverse-SDE sampler.
+ * Replaces DiffBindFR.sample (scFlex.py:124-250): `n_steps` Euler-Maruyama steps
+ * { set_time -> score net -> perturbations -> ligand rigid+torsion update + Kabsch
+ *   -> chi update + side-chain rebuild }, entirely on the device.
+ * Per-step scalars come from the host schedule (diffbindfr_amd/schedule.py mirrors
+ * scFlex.py:83-122,154-161); the N(0,1) tape is supplied by the caller (device).  */
+typedef struct {
+  float t, dt;
+  float tr_sigma, rot_score_norm, tor_score_norm2;   /* conditioning (uniform over graphs) */
+  float tr_g2, tr_gsdt;      /* g^2 and g*sqrt(dt) as the reference's fp32 ops yield them */
+  float rot_g2, rot_gsdt;
+  float tor_g2, tor_gsdt;
+  float sc_g2, sc_gsdt;
+} dbfr_step;
+
+typedef struct {
+  const float* z_tr;   /* [n_steps, G, 3]  */
+  const float* z_rot;  /* [n_steps, G, 3]  */
+  const float* z_tor;  /* [n_steps, NTOR]  */
+  const float* z_sc;   /* [n_steps, NSC]   */
+} dbfr_noise;
+
+/* atom14_out: [NR,14,3] device, masked atom14 positions after the last step
+ * (may be NULL).  traj_lig / traj_atom14: optional [n_steps,...] device buffers
+ * receiving every step (visualize=True), else NULL.                              */
+int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps,
+                const dbfr_noise* noise, float* atom14_out, float* traj_lig, float* traj_atom14,
+                void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream);
+
+/* Synchronises the stream and returns the device-side status word of the last
+ * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
+ * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last
+ * step in the order {lig, atom, cross, center, tor, sc_tor, 0, 0}.                */
+int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
+
+/* ---- introspection / test hooks */
+int         dbfr_abi_version(void);
+const char* dbfr_last_error(void);
+/* Real-basis Wigner-3j tensor the library derives (Racah formula) to self-check
+ * the closed forms baked into the kernels; out has (2l1+1)(2l2+1)(2l3+1) doubles. */
+int dbfr_wigner3j(int32_t l1, int32_t l2, int32_t l3, double* out);
+/* Path table of a conv: n_paths rows of {i1,i2,io,l1,l2,lo,mul1,mulo,w_off} int32
+ * + coeff as float bits in column 9. kind: 0..3 layer convs by depth, 4 final_conv,
+ * 5 tor convs.  Returns number of paths (<= max_paths) or a negative status.       */
+int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* weight_numel);
+/* Profiling hooks: time (ms) spent in the dominant fused conv kernel and the
+ * number of launches + edges since the last reset, measured with hip events on
+ * the launch stream when profiling is enabled.                                    */
+int dbfr_profile_enable(dbfr_model* m, int32_t on);
+int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops,
+                      int32_t reset);
+
+/* Test hook: names (';'-separated) / byte offsets / sizes of the library's internal
+ * buffers inside the workspace for this batch shape.  Returns the entry count.       */
+int dbfr_workspace_layout(const dbfr_model* m, const dbfr_batch* b, const dbfr_limits* lim, char* names,
+                          size_t names_cap, size_t* offsets, size_t* bytes, int32_t max_entries);
+
+/* Unit-test hooks: run ONE fused tensor-product conv (k_conv) / ONE segmented-mean +
+ * LayerNorm (k_reduce_ln) of the packed model on caller-supplied device buffers.
+ * layer >= 0: interaction layer, family 0 lig, 1 cross_al, 2 atom, 3 cross_la;
+ * layer -1 final_conv, -2 tor_bond_conv, -3 sc_tor_bond_conv.                          */
+int dbfr_test_conv(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,
+                   const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh, const float* tab1,
+                   int32_t ld1, const int32_t* idx1, const float* tab2, int32_t ld2, const int32_t* idx2,
+                   const float* x, int32_t ldx, float* msg, void* hip_stream);
+int dbfr_test_reduce_ln(dbfr_model* m, int32_t layer, int32_t family, const float* msg, const int32_t* row_start,
+                        const int32_t* row_cnt, int32_t n_nodes, const float* old, int32_t d_old, float* out,
+                        int32_t mode, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBFR_H */
