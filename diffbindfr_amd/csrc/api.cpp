@@ -622,9 +622,10 @@ extern "C" int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* coun
     counters[0] = ne[SET_LL]; counters[1] = ne[SET_AA]; counters[2] = ne[SET_AL]; counters[3] = ne[7];
     counters[4] = ne[SET_TOR]; counters[5] = ne[SET_SC]; counters[6] = ne[SET_LA]; counters[7] = 0;
   }
-  if (err == DBFR_ERR_CAPACITY) return fail(err, "edge capacity exceeded: raise dbfr_limits");
-  if (err == DBFR_ERR_NUMERIC) return fail(err, "non-finite score or Kabsch determinant check failed");
-  return err;
+  // device status word is a bit mask: 1 = an edge list overflowed its capacity, 2 = numeric check failed
+  if (err & 1) return fail(DBFR_ERR_CAPACITY, "edge capacity exceeded: raise dbfr_limits");
+  if (err & 2) return fail(DBFR_ERR_NUMERIC, "non-finite score or Kabsch determinant check failed");
+  return DBFR_OK;
 }
 
 extern "C" int dbfr_profile_enable(dbfr_model* m, int32_t on) {

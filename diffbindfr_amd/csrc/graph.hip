@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_edges_scan(GraphArgs A) {
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (running > S.cap) { atomicMin(A.err, (int)DBFR_ERR_CAPACITY); running = 0; }
+    if (running > S.cap) { atomicOr(A.err, 1); running = 0; }
     *S.n_edges = running;
   }
 }

@@ -77,7 +77,7 @@ __global__ void k_trrot(TrRotArgs a) {
   for (int k = 0; k < 3; ++k) {
     float t = tr[k] / ntr * mtr, r = rt[k] / nrt * mrt;
     if (a.scale_by_sigma) { t = t / a.tr_sigma[g]; r = r * a.rot_norm[g]; }
-    if (!isfinite(t) || !isfinite(r)) atomicMin(a.err, (int)DBFR_ERR_NUMERIC);
+    if (!isfinite(t) || !isfinite(r)) atomicOr(a.err, 2);
     a.tr_out[3 * g + k] = t;
     a.rot_out[3 * g + k] = r;
   }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(128) void k_sde_ligand(SdeLigArgs a) {
       }
       double R[9];
       double det = kabsch_rotation(H, R);
-      if (fabs(det - 1.0) >= 3e-3) atomicMin(a.err, (int)DBFR_ERR_NUMERIC);
+      if (fabs(det - 1.0) >= 3e-3) atomicOr(a.err, 2);
       for (int k = 0; k < 9; ++k) sh_H[k] = R[k];
     }
     __syncthreads();

@@ -145,10 +145,12 @@ def make_ligand(rng, n):
     bonds = set()
     for i in range(1, n):
         for _ in range(200):
-            p = int(rng.integers(max(0, i - 6), i))
+            p = int(rng.integers(max(0, i - 5), i))
             if deg[p] >= 3:
                 continue
-            d = rng.standard_normal(3)
+            # drug-like ligands are extended (~13 neighbours within 5 A): bias growth outwards
+            out = pos[p] - pos[:i].mean(0)
+            d = rng.standard_normal(3) + 0.6 * out / (np.linalg.norm(out) + 1e-6)
             cand = pos[p] + 1.5 * d / np.linalg.norm(d)
             dist = np.linalg.norm(pos[:i] - cand, axis=1)
             dist[p] = 9.0
@@ -187,6 +189,14 @@ def make_ligand(rng, n):
         if small_is_v and nv > 1:
             tor_mask[k] = True
             rot_masks.append(comp_v.copy())
+    # real ligands are ~half ring atoms: keep ~0.25 n of the bridge bonds rotatable, the rest rigid
+    keep_n = max(1, int(round(0.25 * n)))
+    if len(rot_masks) > keep_n:
+        idx = np.flatnonzero(tor_mask)
+        keep = np.sort(rng.choice(len(idx), size=keep_n, replace=False))
+        tor_mask[:] = False
+        tor_mask[idx[keep]] = True
+        rot_masks = [rot_masks[k] for k in keep]
     rot = np.asarray(rot_masks, bool) if rot_masks else np.zeros((0, n), bool)
     feat = np.zeros((E, 10), np.float32)
     kind = rng.integers(0, 4, size=len(und))

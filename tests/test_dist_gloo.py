@@ -1,0 +1,50 @@
+"""world_size-2 gloo test of the N>1 path (sharding + the final gather) on CPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffbindfr_amd import dist as ddist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = ddist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    parts = ddist.shard_lpt([5.0, 1.0, 3.0, 2.0, 4.0], world)
+    mine = parts[rank]
+    local = torch.tensor([[float(i), float(rank)] for i in mine])
+    allr = ddist.gather_ragged(local, len(mine))
+    fixed = ddist.gather_records(torch.full((2, 3), float(rank)))
+    mx = ddist.max_over_ranks(1.0 + rank, "cpu")
+    ddist.barrier()
+    q.put((rank, allr.tolist(), fixed.tolist(), mx))
+    dist.destroy_process_group()
+
+
+def test_gather_over_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, a0, f0, m0), (r1, a1, f1, m1) = res
+    assert a0 == a1 and f0 == f1 and m0 == m1 == 2.0
+    assert sorted(int(x[0]) for x in a0) == [0, 1, 2, 3, 4]            # every complex gathered exactly once
+    assert f0 == [[0.0] * 3] * 2 + [[1.0] * 3] * 2

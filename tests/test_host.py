@@ -1,0 +1,138 @@
+"""Host-side logic (no GPU): schedule, packing, registry, state_dict contract, library exports."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import diffbindfr_amd as dba
+from diffbindfr_amd import dist as ddist, lib as L, schedule as psched, synthetic
+from diffbindfr_amd.packing import PackedBatch
+from tests.helpers import GOLDEN
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dbfr.h")).read()
+    declared = set(re.findall(r"\b(dbfr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = L.load()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(L.SYMBOLS) == declared
+    assert lib.dbfr_abi_version() == 1
+
+
+def test_product_schedule_matches_reference_fixture():
+    z = np.load(os.path.join(GOLDEN, "schedule.npz"))
+    recs, arr = psched.steps(psched.sample_cfg())
+    assert len(recs) == 20
+    for r, row in zip(recs, z["steps"]):
+        assert [r.t, r.dt, r.tr_sigma, r.rot_sigma, r.tor_sigma, r.sc_tor_sigma] == list(row[:6])
+        assert abs(r.tr_g2 - np.float32(row[6]) ** 2) <= 1e-6 * r.tr_g2
+    for i, v in zip(z["so3_idx"], z["so3_val"]):
+        assert abs(psched.so3_exp_score_norm(int(i)) - v) <= 1e-9 * max(1.0, abs(v))
+    for i, v in zip(z["torus_idx"], z["torus_norm_seed0"]):
+        got = psched.torus_score_norm_entry(int(i), 0)
+        assert got == v or (np.isnan(got) and np.isnan(v))
+    assert recs[-1].noise_free and not recs[0].noise_free
+    assert arr[3].dt == np.float32(recs[3].dt)
+
+
+def test_product_schedule_equals_oracle_schedule():
+    from oracle import schedule as osched
+    ocfg = osched.default_sample_cfg()
+    recs, _ = psched.steps(psched.sample_cfg())
+    for i in (0, 7, 19):
+        o = osched.step_scalars(ocfg, i)
+        r = recs[i]
+        assert r.rot_score_norm == float(o.rot_score_norm) and r.tor_score_norm2 == float(o.tor_score_norm2)
+        assert r.tr_gsdt == float(o.tr_g * np.sqrt(o.dt)) and r.sc_g2 == float(o.sc_tor_g ** 2)
+
+
+def test_state_dict_contract():
+    from oracle import score_model as sm
+    shapes = sm.param_shapes(sm.default_cfg())
+    model = dba.TensorProductModelHIP({})
+    sd = model.state_dict()
+    assert sorted(sd) == sorted(shapes)                     # SURVEY.md Appendix B.3 key set
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    # e3nn buffers of a reference checkpoint are ignored and reported, anything else is rejected
+    extra = dict(sd)
+    extra["lig_conv_layers.0.tp.output_mask"] = torch.ones(3)
+    extra["final_tp_tor.weight"] = torch.zeros(0)
+    model.load_state_dict(extra, strict=True)
+    assert sorted(model.ignored_keys) == ["final_tp_tor.weight", "lig_conv_layers.0.tp.output_mask"]
+    bad = dict(sd)
+    bad["not_a_key"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(bad, strict=True)
+
+
+def test_registry_builds_like_the_reference():
+    cfg = dict(type="DiffBindFRHIP", diffusion_model=dict(type="TensorProductModelHIP", cfg=dict(ns=48, nv=12)),
+               test_cfg=dict(sample_cfg=dict(inference_steps=22, actual_steps=20)))
+    m = dba.MLDOCK_BUILDER.build(cfg, default_args=dict(train_cfg=None))
+    assert isinstance(m, dba.DiffBindFRHIP) and isinstance(m.diffusion_model, dba.TensorProductModelHIP)
+    assert "TensorProductModelHIP" in dba.INTERACTION and dba.INTERACTION.get("nope") is None
+    with pytest.raises(KeyError):
+        dba.INTERACTION.build(dict(type="nope"))
+    # the reference's own type name is redirected to the HIP class (drop-in without editing the config)
+    m2 = dba.DiffBindFRHIP(diffusion_model=dict(type="TensorProductModel", cfg={}))
+    assert isinstance(m2.diffusion_model, dba.TensorProductModelHIP)
+
+
+def test_no_cpu_fallback():
+    d = synthetic.make_batch(2, n_complex=1, poses=1, seed=0, n_atoms=40, n_lig=8)
+    model = dba.TensorProductModelHIP({})
+    d.t = torch.ones(1); d.tr_sigma = torch.ones(1); d.rot_score_norm = torch.ones(1, 1)
+    d.tor_score_norm2 = torch.ones(int(d.tor_edge_mask.sum())); d.sc_tor_score_norm2 = torch.ones(d.sc_torsion_edge_mask.shape)
+    with pytest.raises(L.DbfrError):
+        model(d)                                             # CPU tensors: must raise, never compute
+
+
+def test_packing_invariants():
+    d = synthetic.make_batch(2, n_complex=3, poses=2, seed=5, n_atoms=50, n_lig=9)
+    pb = PackedBatch(d, "cpu")
+    t, dm = pb.t, pb.dims
+    assert dm["G"] == 6 and t["lig_ptr"][-1] == dm["NL"] and t["atm_ptr"][-1] == dm["NA"] and t["res_ptr"][-1] == dm["NR"]
+    assert torch.all(t["bond_src"][1:] >= t["bond_src"][:-1])                       # CSR by source
+    assert t["bond_ptr"][-1] == dm["EB"] and t["tor_ptr"][-1] == dm["NTOR"] and t["sc_ptr"][-1] == dm["NSC"]
+    # every torsion row: bond (u,v) with u outside and v inside the rotating side
+    for k in range(dm["NTOR"]):
+        e = int(t["tor_bond"][k]); u, v = int(t["bond_src"][e]), int(t["bond_dst"][e])
+        g = int(torch.searchsorted(t["lig_ptr"].long(), torch.tensor(u), right=True)) - 1
+        l0 = int(t["lig_ptr"][g]); nl = int(t["lig_ptr"][g + 1]) - l0
+        row = t["rot_mask"][int(t["rot_mask_off"][k]): int(t["rot_mask_off"][k]) + nl]
+        assert row[v - l0] == 1 and row[u - l0] == 0
+    slot = t["atom14_slot"]
+    assert int((slot >= 0).sum()) == dm["NA"] and int(slot.max()) == dm["NA"] - 1
+    # sc bonds are pocket-atom indices of the right graph
+    assert int(t["sc_bond"].max()) < dm["NA"]
+    assert dm["max_nl"] <= 256 and dm["max_na"] <= 2048
+
+
+def test_synthetic_shapes_follow_the_data_contract():
+    d = synthetic.make_batch(5, n_complex=1, poses=2, seed=1)
+    NA, NL = d.rec_atm_pos.shape[0], d.lig_pos.shape[0]
+    assert 2 * 0.85 * 600 < NA < 2 * 1.15 * 600 + 30 and 2 * 0.8 * 80 <= NL <= 2 * 1.2 * 80
+    assert d.pocket_node_feature.shape == (NA, 5) and d.lig_node.shape == (NL, 27) and d.lig_edge_feat.shape[1] == 10
+    assert d.default_frame.shape[1:] == (8, 4, 4) and d.rigid_group_positions.shape[1:] == (14, 3)
+    assert int(d.atom14_mask.sum()) == NA and d.torsion_edge_index.shape[1:] == (4, 2)
+    a37 = d.pocket_node_feature[:, 0].long()
+    assert int(((a37 == 1) | (a37 == 3)).sum()) > 0
+    # ligand radius graph must not hit torch_cluster's 32-neighbour cap
+    from oracle.cluster import radius_graph
+    ei = radius_graph(d.lig_pos, 5.0, d.lig_node_batch, max_num_neighbors=1000)
+    assert torch.bincount(ei[1]).max() <= 32
+
+
+def test_shard_lpt_is_balanced_and_complete():
+    costs = [ddist.complex_cost(180 + 7 * (i % 9), 25 + (i % 11)) for i in range(128)]
+    parts = ddist.shard_lpt(costs, 8)
+    assert sorted(sum(parts, [])) == list(range(128))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) / min(loads) < 1.02
