@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
 
 #include "common.h"
@@ -159,29 +160,93 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
       for (int lane = 0; lane < 64; ++lane)
         for (int q = 0; q < 4; ++q)
           w1p[(((size_t)mt * KT + s4) * 64 + lane) * 4 + q] = W1[(size_t)(16 * mt + (lane & 15)) * K + 4 * (4 * s4 + q) + (lane >> 4)];
-  // lin.3 rows permuted to (path, w_out, u_in), each path padded to a multiple of 16 rows
+  // lin.3 rows re-ordered for OWNER accumulation (no atomics, reproducible):
+  //   an output channel (io, w) is a "pair"; its contributions come from every path into io, all u_in.
+  //   4 pairs with the same (type, mul1) path sequence form a group processed in lock step: tile =
+  //   4 quads (one per pair = per MFMA lane group) x the same path and u-quad => path type is tile-uniform.
+  //   A lane keeps the running message element in registers over the group's tiles and stores it once.
+  //   Groups are dealt to the 4 waves of the workgroup by LPT; tiles are laid out wave-major.
   struct Row { int orig; float scale; };
-  std::vector<Row> rows;
-  std::vector<uint32_t> quads;
-  for (auto& p : sp.paths) {
-    if (p.mul1 % 4) return fail(DBFR_ERR_ARG, "input multiplicity not a multiple of 4 in " + name);
-    const int d1 = 2 * p.l1 + 1, d_o = 2 * p.lo + 1;
-    size_t start = rows.size();
-    for (int w = 0; w < p.mulo; ++w)
-      for (int u = 0; u < p.mul1; ++u) {
-        if ((u & 3) == 0) {
-          uint32_t xo = p.in_off + u * d1, oo = p.out_off + w * d_o;
-          if (xo > 255 || oo > 255) return fail(DBFR_ERR_ARG, "irreps too wide for the quad descriptor");
-          quads.push_back(xo | (oo << 8) | ((uint32_t)p.type << 16) | ((uint32_t)p.sh_off << 20));
+  struct PairPath { const PathDesc* p; };
+  struct Pair { int io, w; std::vector<const PathDesc*> paths; };
+  std::vector<Pair> pairs;
+  for (int io = 0; io < (int)sp.out.size(); ++io)
+    for (int w = 0; w < sp.out[io].mul; ++w) {
+      Pair pr{io, w, {}};
+      for (auto& p : sp.paths) if (p.io == io) pr.paths.push_back(&p);
+      std::stable_sort(pr.paths.begin(), pr.paths.end(),
+                       [](const PathDesc* a, const PathDesc* b) { return a->type != b->type ? a->type < b->type : a->mul1 > b->mul1; });
+      pairs.push_back(pr);
+    }
+  auto sig = [](const Pair& a) {
+    std::string k;
+    for (auto* p : a.paths) k += std::to_string(p->type) + ":" + std::to_string(p->mul1) + ",";
+    return k;
+  };
+  struct Group { std::vector<int> pair_idx; int tiles; };
+  std::vector<Group> groups;
+  {
+    std::map<std::string, std::vector<int>> cls;
+    std::vector<std::string> order;
+    for (int i = 0; i < (int)pairs.size(); ++i) {
+      std::string k = sig(pairs[i]);
+      if (!cls.count(k)) order.push_back(k);
+      cls[k].push_back(i);
+    }
+    for (auto& k : order) {
+      auto& v = cls[k];
+      for (size_t i = 0; i < v.size(); i += 4) {
+        Group g;
+        for (size_t j = i; j < i + 4; ++j) g.pair_idx.push_back(j < v.size() ? v[j] : -1);
+        g.tiles = 0;
+        for (auto* p : pairs[v[i]].paths) {
+          if (p->mul1 % 4) return fail(DBFR_ERR_ARG, "input multiplicity not a multiple of 4 in " + name);
+          g.tiles += p->mul1 / 4;
         }
-        rows.push_back({p.w_off + u * p.mulo + w, p.fold});
+        groups.push_back(g);
       }
-    while ((rows.size() - start) % 16) {
-      if ((rows.size() & 3) == 0)
-        quads.push_back((uint32_t)p.in_off | ((uint32_t)p.out_off << 8) | ((uint32_t)p.type << 16) | ((uint32_t)p.sh_off << 20));
-      rows.push_back({-1, 0.f});
     }
   }
+  // LPT deal to the 4 waves
+  std::vector<int> gorder(groups.size());
+  for (size_t i = 0; i < gorder.size(); ++i) gorder[i] = (int)i;
+  std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return groups[a].tiles > groups[b].tiles; });
+  std::vector<std::vector<int>> wave_groups(4);
+  int wave_load[4] = {0, 0, 0, 0};
+  for (int gi : gorder) {
+    int best = 0;
+    for (int v = 1; v < 4; ++v) if (wave_load[v] < wave_load[best]) best = v;
+    wave_groups[best].push_back(gi);
+    wave_load[best] += groups[gi].tiles;
+  }
+  std::vector<Row> rows;
+  std::vector<uint32_t> quads;
+  int wave_tile0[5] = {0, 0, 0, 0, 0};
+  for (int v = 0; v < 4; ++v) {
+    std::sort(wave_groups[v].begin(), wave_groups[v].end());
+    wave_tile0[v] = (int)rows.size() / 16;
+    for (int gi : wave_groups[v]) {
+      const Group& G = groups[gi];
+      const Pair& lead = pairs[G.pair_idx[0]];
+      int tile_in_group = 0;
+      for (size_t pi = 0; pi < lead.paths.size(); ++pi)
+        for (int u0 = 0; u0 < lead.paths[pi]->mul1; u0 += 4, ++tile_in_group) {
+          uint32_t flags = (tile_in_group == 0 ? 1u : 0u) | (tile_in_group == G.tiles - 1 ? 2u : 0u);
+          for (int g = 0; g < 4; ++g) {
+            const int pidx = G.pair_idx[g];
+            const PathDesc* p = pidx >= 0 ? pairs[pidx].paths[pi] : lead.paths[pi];
+            const int d1 = 2 * p->l1 + 1, d_o = 2 * p->lo + 1;
+            uint32_t xo = p->in_off + u0 * d1;
+            uint32_t oo = pidx >= 0 ? p->out_off + pairs[pidx].w * d_o : (uint32_t)sp.D_out;  // dummy -> trash column
+            if (xo > 255 || oo > 255) return fail(DBFR_ERR_ARG, "irreps too wide for the quad descriptor");
+            quads.push_back(xo | (oo << 8) | ((uint32_t)p->type << 16) | ((uint32_t)p->sh_off << 20) | (flags << 24));
+            for (int r = 0; r < 4; ++r)
+              rows.push_back(pidx >= 0 ? Row{p->w_off + (u0 + r) * p->mulo + pairs[pidx].w, p->fold} : Row{-1, 0.f});
+          }
+        }
+    }
+  }
+  wave_tile0[4] = (int)rows.size() / 16;
   const int n_tiles = (int)rows.size() / 16;
   std::vector<float> w2p((size_t)n_tiles * KT * 64 * 4), b2p((size_t)n_tiles * 16);
   for (int t = 0; t < n_tiles; ++t) {
@@ -195,6 +260,7 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
       }
   }
   o->K = K; o->D_in = sp.D_in; o->D_out = sp.D_out; o->n_tiles = n_tiles; o->W = sp.W;
+  for (int v = 0; v < 5; ++v) o->wave_tile0[v] = wave_tile0[v];
   o->W1p = upload(m, w1p, &rc);
   o->b1 = upload(m, std::vector<float>(B1, B1 + K), &rc);
   o->W2p = upload(m, w2p, &rc);

@@ -50,6 +50,7 @@ struct LNDesc {            // equivariant LayerNorm over the out irreps (tpscore
 
 struct ConvW {             // one TensorProductConvLayer, device resident
   int K, D_in, D_out, n_tiles, W;
+  int wave_tile0[5];  // tiles [wave_tile0[v], wave_tile0[v+1]) belong to wave v of the workgroup
   const float* W1p;   // [K/16][K/16][64][4]   lin.0 weight in MFMA A-fragment order
   const float* b1;    // [K]
   const float* W2p;   // [n_tiles][K/16][64][4] lin.3 weight rows permuted (path, w, u), path norm folded

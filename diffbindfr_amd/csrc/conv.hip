@@ -12,33 +12,77 @@
 //   k_reduce_ln    wavefront segmented mean over the CSR-grouped messages of each target node
 //                  (fixed order => reproducible), equivariant LayerNorm, residual accumulate.
 //
-// k_conv work decomposition (one workgroup = 256 threads = 4 waves = TE=32 edges):
+// k_conv work decomposition (one workgroup = 256 threads = 4 waves = TE = 16 NB edges, NB = 3 by default):
 //   phase A  gather edge_attr_ = [edge_emb | tab1[idx1][:48] | tab2[idx2][:48]] and x[gth] into LDS
-//   phase B  h = relu(W1 a + b1): (K/16 row tiles) x (2 edge blocks) MFMA jobs split over the waves;
+//   phase B  h = relu(W1 a + b1): (K/16 row tiles) x (NB edge blocks) MFMA jobs split over the waves;
 //            MFMA orientation D[row = weight row, col = edge]  => lane (g = lane>>4, n = lane&15)
 //            owns ONE edge n for its whole life and 4 consecutive weight rows 4g..4g+3 per tile
 //   phase C  every wave loads the full h^T as its MFMA B operand (K/4 VGPRs per 16-edge block)
-//   phase D  wave w walks W2 row tiles t = w, w+4, ...; rows are pre-permuted (path, w_out, u_in) with
-//            U in {12,48} so every 4-row quad shares one output channel: the lane contracts its 4
-//            weights with x[u0..u0+3] (LDS) and the edge's harmonics through the closed-form CG of the
-//            path and adds the result into the LDS message tile with ds_add_f32
+//   phase D  every wave walks ITS OWN contiguous range of W2 row tiles.  Rows are pre-ordered at model
+//            creation (api.cpp: pack_conv) so that a lane group (16 lanes = 16 edges x 4 rows) stays on ONE
+//            output channel (io, w_out) for a run of tiles covering all paths and all u_in of that channel:
+//            the lane contracts its 4 weights with x[u0..u0+3] (LDS) and the edge's harmonics through the
+//            closed-form CG of the path, keeps the running message element in registers and stores it to the
+//            LDS message tile exactly once -- no atomics, fixed summation order (bit-reproducible)
 //   phase E  coalesced store of the [TE, D_out] message tile
+#include <cstdlib>
+
 #include "common.h"
 
-#define TE 32
-#define XS_LD (MAXD + 1)
+#define XS_LD (MAXD + 4)   // 172: rows 16-B aligned (ds_read_b128), 16 consecutive rows hit 16 distinct 16-B slots
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int K>
+// closed-form Clebsch-Gordan contraction of one 4-row quad (must mirror so3_host.cpp: closed_form)
+__device__ __forceinline__ void quad_contract(int type, const f32x4 v, const float* __restrict__ xr,
+                                              const float* __restrict__ sp, float& p0, float& p1, float& p2) {
+  p0 = 0.f; p1 = 0.f; p2 = 0.f;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(xr);   // x_off and the row stride are multiples of 4 floats
+  const f32x4 xa = x4[0];
+  if (type == PT_SS || type == PT_SV) {
+    const float z = v[0] * xa[0] + v[1] * xa[1] + v[2] * xa[2] + v[3] * xa[3];
+    if (type == PT_SS) {
+      p0 = z * sp[0];
+    } else {
+      p0 = z * sp[0]; p1 = z * sp[1]; p2 = z * sp[2];
+    }
+  } else {
+    const f32x4 xb = x4[1], xc = x4[2];   // [u0..u0+3][3] = 12 consecutive floats
+    const float z0 = v[0] * xa[0] + v[1] * xa[3] + v[2] * xb[2] + v[3] * xc[1];
+    const float z1 = v[0] * xa[1] + v[1] * xb[0] + v[2] * xb[3] + v[3] * xc[2];
+    const float z2 = v[0] * xa[2] + v[1] * xb[1] + v[2] * xc[0] + v[3] * xc[3];
+    if (type == PT_VS) {
+      const float s0 = sp[0];
+      p0 = z0 * s0; p1 = z1 * s0; p2 = z2 * s0;
+    } else if (type == PT_VVS) {
+      p0 = z0 * sp[0] + z1 * sp[1] + z2 * sp[2];
+    } else if (type == PT_VVV) {
+      const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
+      p0 = z1 * s2 - z2 * s1; p1 = z2 * s0 - z0 * s2; p2 = z0 * s1 - z1 * s0;
+    } else {  // PT_VTV
+      const float r3 = 1.7320508075688772f;
+      const float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+      const float m00 = -s2 - r3 * s4, m01 = r3 * s1, m02 = r3 * s0, m11 = 2.f * s2, m12 = r3 * s3,
+                  m22 = -s2 + r3 * s4;
+      p0 = m00 * z0 + m01 * z1 + m02 * z2;
+      p1 = m01 * z0 + m11 * z1 + m12 * z2;
+      p2 = m02 * z0 + m12 * z1 + m22 * z2;
+    }
+  }
+}
+
+// K: radial-MLP width (144 / 96); NB: 16-edge blocks per workgroup (TE = 16 NB edges share every A fragment
+// fetched from L2 -- the L2->CU fabric, not HBM, is what the weight stream loads); ABL: developer ablations.
+template <int K, int NB, int ABL>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+  constexpr int TE = 16 * NB;
   constexpr int KT = K / 16;  // 16-wide tiles along the MLP input/hidden dim
   constexpr int KS = K / 4;   // MFMA k-steps
   constexpr int A_LD = K + 1;
   constexpr int H_LD = TE + 1;
-  constexpr int UN = (TE * XS_LD > K * H_LD) ? TE * XS_LD : K * H_LD;
-  __shared__ float xs[TE * XS_LD];
-  __shared__ float un[UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][D_out+1]
+  constexpr int UN = (TE * (MAXD + 5) > K * H_LD) ? TE * (MAXD + 5) : K * H_LD;
+  __shared__ __attribute__((aligned(16))) float xs[TE * XS_LD];
+  __shared__ float un[UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][D_out+5]
   __shared__ float shs[TE * 10];
   __shared__ int s_gth[TE], s_i1[TE], s_i2[TE];
 
@@ -49,7 +93,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int D_in = a.w.D_in, D_out = a.w.D_out;
-  const int O_LD = D_out + 1;
+  const int O_LD = D_out + 5;   // +3 trash columns for padded (dummy) channels, odd stride vs banks
 
   if (tid < TE) {
     int e = tile0 + min(tid, ne - 1);
@@ -73,13 +117,11 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   }
   for (int i = tid; i < TE * SH_LD; i += 256) {
     int e = i / SH_LD, c = i - e * SH_LD;
-    float v = a.sh[(size_t)(tile0 + min(e, ne - 1)) * SH_LD + c];
-    if (c >= 1 && c <= 3) v *= a.sh_sign;
-    shs[e * 10 + c] = v;
+    shs[e * 10 + c] = a.sh[(size_t)(tile0 + min(e, ne - 1)) * SH_LD + c];
   }
   __syncthreads();
   // ---------------- phase B: hidden layer on the matrix cores
-  constexpr int NJOB = KT * 2;
+  constexpr int NJOB = KT * NB;
   constexpr int JPW = (NJOB + 3) / 4;
   f32x4 hacc[JPW];
 #pragma unroll
@@ -87,7 +129,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     int job = wave + 4 * jj;
     hacc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (job < NJOB) {
-      int m = job >> 1, b = job & 1;
+      int m = job / NB, b = job - m * NB;
       const f32x4* Ap = reinterpret_cast<const f32x4*>(a.w.W1p) + (size_t)m * KT * 64 + lane;
       const float* Bp = un + (16 * b + n) * A_LD + g;
 #pragma unroll
@@ -104,7 +146,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   for (int jj = 0; jj < JPW; ++jj) {
     int job = wave + 4 * jj;
     if (job < NJOB) {
-      int m = job >> 1, b = job & 1;
+      int m = job / NB, b = job - m * NB;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 16 * m + 4 * g + r;
@@ -114,76 +156,79 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   }
   __syncthreads();
   // ---------------- phase C: B operand (h^T) into registers
-  float B0[KS], B1[KS];
+  float Bv[NB][KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    B0[s] = un[(4 * s + g) * H_LD + n];
-    B1[s] = un[(4 * s + g) * H_LD + 16 + n];
-  }
-  __syncthreads();
-  for (int i = tid; i < TE * O_LD; i += 256) un[i] = 0.f;
-  __syncthreads();
-  // ---------------- phase D: W2 row tiles
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) Bv[b][s] = un[(4 * s + g) * H_LD + 16 * b + n];
+  __syncthreads();   // hs is dead: the region becomes the message tile (every element is stored exactly once)
+  // ---------------- phase D: W2 row tiles of this wave (channel-owner order, see api.cpp pack_conv)
   const f32x4* W2 = reinterpret_cast<const f32x4*>(a.w.W2p);
-  for (int t = wave; t < a.w.n_tiles; t += 4) {
-    const f32x4* Ap = W2 + (size_t)t * KT * 64 + lane;
-    f32x4 A[KT];
+  const int t_begin = a.w.wave_tile0[wave], t_end = a.w.wave_tile0[wave + 1];
+  // A fragments of the current tile live in A[]; each register is re-loaded with the NEXT tile's fragment
+  // right after its last MFMA, so a whole tile of matrix work hides the L2 latency with one register set.
+  // The quad descriptor + bias are prefetched one tile ahead the same way (vector loads retire in order:
+  // every wait then refers to a load issued a whole tile of matrix work earlier).
+  f32x4 A[KT];
+  uint32_t qd_n = 0;
+  f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
+  if (t_begin < t_end) {
+    const f32x4* Ap0 = W2 + (size_t)t_begin * KT * 64 + lane;
 #pragma unroll
-    for (int s4 = 0; s4 < KT; ++s4) A[s4] = Ap[s4 * 64];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s4 = 0; s4 < KT; ++s4) A[s4] = Ap0[s4 * 64];
+    qd_n = a.w.quads[t_begin * 4 + g];
+    bias_n = reinterpret_cast<const f32x4*>(a.w.b2p)[t_begin * 4 + g];
+  }
+  float oacc[NB][3];   // running message element(s) of this lane's channel, per edge block
+#pragma unroll
+  for (int b = 0; b < NB; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool has_next = t + 1 < t_end;
+    const int tn = has_next ? t + 1 : t;
+    const f32x4* Apn = W2 + (size_t)tn * KT * 64 + lane;
+    const uint32_t qd = qd_n;
+    const f32x4 bias = bias_n;
+    qd_n = a.w.quads[tn * 4 + g];
+    bias_n = reinterpret_cast<const f32x4*>(a.w.b2p)[tn * 4 + g];
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s4 = 0; s4 < KT; ++s4) {
+      const f32x4 av = A[s4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4][q], B0[4 * s4 + q], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4][q], B1[4 * s4 + q], acc1, 0, 0, 0);
-      }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bv[b][4 * s4 + q], acc[b], 0, 0, 0);
+      if (!(ABL & 2) && !((ABL & 4) && (t & 1))) A[s4] = Apn[s4 * 64];
     }
-    const uint32_t qd = a.w.quads[t * 4 + g];
-    const int x_off = qd & 0xff, o_off = (qd >> 8) & 0xff, sh_off = (qd >> 20) & 0xf;
-    const int type = __builtin_amdgcn_readfirstlane((qd >> 16) & 0xf);  // uniform per tile
-    const f32x4 bias = reinterpret_cast<const f32x4*>(a.w.b2p)[t * 4 + g];
+    if (ABL & 1) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(acc[b]));
+      continue;
+    }
+    const int x_off = qd & 0xff, o_off = (qd >> 8) & 0xff, sh_off = (qd >> 20) & 0xf;
+    const int type = __builtin_amdgcn_readfirstlane((qd >> 16) & 0xf);   // uniform per tile
+    const int flags = __builtin_amdgcn_readfirstlane(qd >> 24);          // bit0 first / bit1 last tile of the group
+    if (flags & 1) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
       const int e = 16 * b + n;
-      f32x4 v = (b == 0 ? acc0 : acc1) + bias;
-      const float* xr = xs + e * XS_LD + x_off;
-      const float* sp = shs + e * 10 + sh_off;
-      float* op = un + e * O_LD + o_off;
-      if (type == PT_SS || type == PT_SV) {
-        float z = v[0] * xr[0] + v[1] * xr[1] + v[2] * xr[2] + v[3] * xr[3];
-        if (type == PT_SS) {
-          atomicAdd(op, z * sp[0]);
-        } else {
-          atomicAdd(op + 0, z * sp[0]);
-          atomicAdd(op + 1, z * sp[1]);
-          atomicAdd(op + 2, z * sp[2]);
-        }
-      } else {
-        float z0 = v[0] * xr[0] + v[1] * xr[3] + v[2] * xr[6] + v[3] * xr[9];
-        float z1 = v[0] * xr[1] + v[1] * xr[4] + v[2] * xr[7] + v[3] * xr[10];
-        float z2 = v[0] * xr[2] + v[1] * xr[5] + v[2] * xr[8] + v[3] * xr[11];
-        if (type == PT_VS) {
-          float s0 = sp[0];
-          atomicAdd(op + 0, z0 * s0);
-          atomicAdd(op + 1, z1 * s0);
-          atomicAdd(op + 2, z2 * s0);
-        } else if (type == PT_VVS) {
-          atomicAdd(op, z0 * sp[0] + z1 * sp[1] + z2 * sp[2]);
-        } else if (type == PT_VVV) {
-          float s0 = sp[0], s1 = sp[1], s2 = sp[2];
-          atomicAdd(op + 0, z1 * s2 - z2 * s1);
-          atomicAdd(op + 1, z2 * s0 - z0 * s2);
-          atomicAdd(op + 2, z0 * s1 - z1 * s0);
-        } else {  // PT_VTV
-          const float r3 = 1.7320508075688772f;
-          float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-          float m00 = -s2 - r3 * s4, m01 = r3 * s1, m02 = r3 * s0, m11 = 2.f * s2, m12 = r3 * s3,
-                m22 = -s2 + r3 * s4;
-          atomicAdd(op + 0, m00 * z0 + m01 * z1 + m02 * z2);
-          atomicAdd(op + 1, m01 * z0 + m11 * z1 + m12 * z2);
-          atomicAdd(op + 2, m02 * z0 + m12 * z1 + m22 * z2);
-        }
+      float p0, p1, p2;
+      quad_contract(type, acc[b] + bias, xs + e * XS_LD + x_off, shs + e * 10 + sh_off, p0, p1, p2);
+      oacc[b][0] += p0; oacc[b][1] += p1; oacc[b][2] += p2;
+    }
+    if (flags & 2) {   // last tile of the group: this lane owns out[(e), o_off .. o_off+k)
+      const bool vec = !(type == PT_SS || type == PT_VVS);   // output irrep l=1 (3 components) or l=0
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float* op = un + (16 * b + n) * O_LD + o_off;
+        op[0] = oacc[b][0];
+        if (vec) { op[1] = oacc[b][1]; op[2] = oacc[b][2]; }
       }
     }
   }
@@ -195,13 +240,25 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   }
 }
 
+#define CONV_NB 3
+
 void launch_conv(const ConvArgs& a, hipStream_t st) {
-  int blocks = (a.max_edges + TE - 1) / TE;
+  static int abl = -1, nb = -1;   // developer knobs: DBFR_CONV_ABL (1 no epilogue, 2 no A reload, 4 half A), DBFR_CONV_NB
+  if (abl < 0) { const char* e = getenv("DBFR_CONV_ABL"); abl = e ? atoi(e) : 0; }
+  if (nb < 0) { const char* e = getenv("DBFR_CONV_NB"); nb = e ? atoi(e) : CONV_NB; }
+  const int te = 16 * nb;
+  int blocks = (a.max_edges + te - 1) / te;
   if (blocks <= 0) return;
-  if (a.w.K == 144)
-    hipLaunchKernelGGL(k_conv<144>, dim3(blocks), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(k_conv<96>, dim3(blocks), dim3(256), 0, st, a);
+#define LAUNCH(KK, NBB, AB) hipLaunchKernelGGL((k_conv<KK, NBB, AB>), dim3(blocks), dim3(256), 0, st, a)
+  if (a.w.K != 144) { if (nb == 2) LAUNCH(96, 2, 0); else LAUNCH(96, 3, 0); return; }
+  if (nb == 2) {
+    switch (abl) { case 1: LAUNCH(144, 2, 1); break; case 2: LAUNCH(144, 2, 2); break; case 3: LAUNCH(144, 2, 3); break;
+                   default: LAUNCH(144, 2, 0); }
+  } else {
+    switch (abl) { case 1: LAUNCH(144, 3, 1); break; case 2: LAUNCH(144, 3, 2); break; case 3: LAUNCH(144, 3, 3); break;
+                   default: LAUNCH(144, 3, 0); }
+  }
+#undef LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------------
