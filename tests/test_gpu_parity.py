@@ -260,3 +260,34 @@ def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name):
     L.check(lib.dbfr_test_reduce_ln(h, layer, fam, ptr(mrefd), ptr(rs), ptr(cntd), Nt, None, 0, ptr(outd), 2, None))
     torch.cuda.synchronize()
     assert rel_err(outd, out_ref) < 1e-5
+
+
+def test_bitwise_reproducible(setup, dev):
+    """No atomics anywhere on the path: edge lists, channel-owner accumulation in k_conv and the
+    segmented reductions all have a fixed order, so two runs must agree bit for bit."""
+    mcfg, params, model = setup
+    d = synthetic.make_batch(2, n_complex=2, poses=3, seed=31)
+    sc = osched.step_scalars(osched.default_sample_cfg(), 4)
+    dd = osampler.set_time(copy.deepcopy(d), sc, d.num_graphs)
+    a = [x.clone() for x in hip_scores(model, dd, dev)]
+    b = hip_scores(model, dd, dev)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_rigid_receptor_model_no_sc_torsion(dev):
+    """cfg.no_sc_torsion=True (tpscore.py:390, :560-573): no side-chain head, sc_tor is None."""
+    mcfg = sm.default_cfg(no_sc_torsion=True)
+    params = sm.init_params(mcfg, seed=2)
+    assert not any(k.startswith("sc_") for k in params)
+    model = dba.TensorProductModelHIP({"no_sc_torsion": True}).to(dev)
+    model.load_state_dict(params, strict=True)
+    d = synthetic.make_batch(2, n_complex=1, poses=2, seed=9, n_atoms=60, n_lig=10)
+    sc = osched.step_scalars(osched.default_sample_cfg(), 8)
+    dd = osampler.set_time(copy.deepcopy(d), sc, d.num_graphs)
+    ref = sm.forward(params, mcfg, copy.deepcopy(dd))
+    out = model(namespace_to(dd, dev))
+    assert out[3] is None and ref[3] is None
+    for a, b in zip(out[:3], ref[:3]):
+        assert rel_err(a, b) < SCORE_RTOL
+    model.release()
