@@ -243,21 +243,17 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #define CONV_NB 3
 
 void launch_conv(const ConvArgs& a, hipStream_t st) {
-  static int abl = -1, nb = -1;   // developer knobs: DBFR_CONV_ABL (1 no epilogue, 2 no A reload, 4 half A), DBFR_CONV_NB
-  if (abl < 0) { const char* e = getenv("DBFR_CONV_ABL"); abl = e ? atoi(e) : 0; }
-  if (nb < 0) { const char* e = getenv("DBFR_CONV_NB"); nb = e ? atoi(e) : CONV_NB; }
+  static int nb_env = -1;   // developer knob DBFR_CONV_NB (1, 2 or 3); 0 = automatic
+  if (nb_env < 0) { const char* e = getenv("DBFR_CONV_NB"); nb_env = e ? atoi(e) : 0; }
+  // 48-edge workgroups: each A fragment fetched from L2 feeds 3 edge blocks.  (16-edge workgroups fill the chip
+  // better for a handful of poses but stream W2 3x as often from L2: measured a wash)
+  const int nb = nb_env ? nb_env : CONV_NB;
   const int te = 16 * nb;
   int blocks = (a.max_edges + te - 1) / te;
   if (blocks <= 0) return;
-#define LAUNCH(KK, NBB, AB) hipLaunchKernelGGL((k_conv<KK, NBB, AB>), dim3(blocks), dim3(256), 0, st, a)
-  if (a.w.K != 144) { if (nb == 2) LAUNCH(96, 2, 0); else LAUNCH(96, 3, 0); return; }
-  if (nb == 2) {
-    switch (abl) { case 1: LAUNCH(144, 2, 1); break; case 2: LAUNCH(144, 2, 2); break; case 3: LAUNCH(144, 2, 3); break;
-                   default: LAUNCH(144, 2, 0); }
-  } else {
-    switch (abl) { case 1: LAUNCH(144, 3, 1); break; case 2: LAUNCH(144, 3, 2); break; case 3: LAUNCH(144, 3, 3); break;
-                   default: LAUNCH(144, 3, 0); }
-  }
+#define LAUNCH(KK, NBB) hipLaunchKernelGGL((k_conv<KK, NBB, 0>), dim3(blocks), dim3(256), 0, st, a)
+  if (a.w.K != 144) { if (nb == 1) LAUNCH(96, 1); else if (nb == 2) LAUNCH(96, 2); else LAUNCH(96, 3); }
+  else { if (nb == 1) LAUNCH(144, 1); else if (nb == 2) LAUNCH(144, 2); else LAUNCH(144, 3); }
 #undef LAUNCH
 }
 

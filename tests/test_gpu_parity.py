@@ -291,3 +291,22 @@ def test_rigid_receptor_model_no_sc_torsion(dev):
     for a, b in zip(out[:3], ref[:3]):
         assert rel_err(a, b) < SCORE_RTOL
     model.release()
+
+
+def test_model_create_reports_missing_and_misshaped_tensors(dev):
+    params = sm.init_params(sm.default_cfg(), seed=1)
+    model = dba.TensorProductModelHIP({}).to(dev)
+    model.load_state_dict(params, strict=True)
+    # sabotage the host-side dict handed to the C ABI
+    sd = {k: v for k, v in model.state_dict().items()}
+    import unittest.mock as mock
+    bad = dict(sd)
+    del bad["atom_conv_layers.3.fc.lin.3.bias"]
+    with mock.patch.object(type(model), "state_dict", lambda self, *a, **k: bad):
+        with pytest.raises(L.DbfrError, match="atom_conv_layers.3.fc.lin.3.bias"):
+            model.handle()
+    bad2 = dict(sd)
+    bad2["tr_final_layer.lin.0.weight"] = torch.zeros(5, 5)
+    with mock.patch.object(type(model), "state_dict", lambda self, *a, **k: bad2):
+        with pytest.raises(L.DbfrError, match="tr_final_layer.lin.0.weight"):
+            model.handle()

@@ -136,3 +136,33 @@ def test_shard_lpt_is_balanced_and_complete():
     assert sorted(sum(parts, [])) == list(range(128))
     loads = [sum(costs[i] for i in p) for p in parts]
     assert max(loads) / min(loads) < 1.02
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/dbfr.h must compile as C (no C++/torch/hip types in the ABI)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "dbfr.h"\nint main(void){ dbfr_batch b; dbfr_step s; (void)b; (void)s; return sizeof(dbfr_model_cfg) > 0 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """sizeof / field offsets of the ctypes mirrors == what a C compiler lays out for include/dbfr.h."""
+    import ctypes as C
+    import subprocess
+    fields = {"dbfr_batch": ["G", "max_nr", "lig_ptr", "rot_mask_off", "sc_ptr"], "dbfr_step": ["t", "sc_gsdt"],
+              "dbfr_model_cfg": ["ns", "emb_scale", "no_sc_torsion"], "dbfr_tensor": ["numel"], "dbfr_noise": ["z_sc"]}
+    body = "".join(f'printf("{s} %zu\\n", sizeof({s}));' + "".join(f'printf("{s}.{f} %zu\\n", offsetof({s},{f}));' for f in fs)
+                   for s, fs in fields.items())
+    src = tmp_path / "o.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dbfr.h"\nint main(void){' + body + 'return 0;}\n')
+    exe = tmp_path / "o"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    mirror = {"dbfr_batch": L.Batch, "dbfr_step": L.Step, "dbfr_model_cfg": L.ModelCfg, "dbfr_tensor": L.Tensor, "dbfr_noise": L.Noise}
+    for s, cls in mirror.items():
+        assert int(out[s]) == C.sizeof(cls), s
+        for f in fields[s]:
+            assert int(out[f"{s}.{f}"]) == getattr(cls, f).offset, (s, f)
