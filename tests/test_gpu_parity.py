@@ -310,3 +310,61 @@ def test_model_create_reports_missing_and_misshaped_tensors(dev):
     with mock.patch.object(type(model), "state_dict", lambda self, *a, **k: bad2):
         with pytest.raises(L.DbfrError, match="tr_final_layer.lin.0.weight"):
             model.handle()
+
+
+def test_pocket_without_side_chain_torsions(setup, dev):
+    """All-ALA/GLY pocket: NSC = 0, the side-chain head and chi update are skipped, sampler still runs."""
+    mcfg, params, model = setup
+    rng = np.random.default_rng(17)
+    T = synthetic.residue_tables()
+    orig = rng.integers
+    pk = None
+    for _ in range(50):                      # draw pockets until one is made of residues without chi angles
+        cand = synthetic.make_pocket(rng, 30)
+        if not cand["sc_torsion_edge_mask"].any():
+            pk = cand
+            break
+    if pk is None:                           # force it: rebuild a pocket and overwrite with ALA (aatype 0)
+        pk = synthetic.make_pocket(rng, 30)
+        n = len(pk["sequence"])
+        pk["sequence"][:] = 0
+        m = T["atom14_mask"][pk["sequence"]].astype(bool)
+        pk["atom14_mask"] = m
+        pk["sc_torsion_edge_mask"] = np.zeros((n, 4), bool)
+        pk["torsion_edge_index"] = np.zeros((n, 4, 2), np.int64)
+        pk["default_frame"] = T["default_frame"][pk["sequence"]].astype(np.float32)
+        pk["rigid_group_positions"] = T["atom14_lit_pos"][pk["sequence"]].astype(np.float32)
+        a37 = T["atom14_to_atom37"][pk["sequence"]]
+        feat = np.stack([a37, T["atom37_to_coarse"][a37], T["atom37_to_element"][a37], np.zeros_like(a37),
+                         (np.arange(14)[None] < 4).repeat(n, 0)], -1).astype(np.float32) * m[..., None]
+        pk["pocket_node_feature"] = feat[m]
+        pk["n_atoms"] = int(m.sum())
+    lg = synthetic.make_ligand(rng, 9)
+    d = synthetic.collate([(pk, lg) + synthetic.init_pose(rng, pk, lg, tr_sigma=2.0) for _ in range(2)])
+    assert int(d.sc_torsion_edge_mask.sum()) == 0
+    sc = osched.step_scalars(osched.default_sample_cfg(), 5)
+    dd = osampler.set_time(copy.deepcopy(d), sc, 2)
+    # The reference (and hence the oracle) cannot run its side-chain head on zero torsions: `out_nodes or N`
+    # (tpscore.py:189) turns out_nodes=0 into N.  The other three scores do not depend on that head, so they
+    # are checked against the oracle evaluated without it; the HIP path simply skips the empty head.
+    rigid = sm.default_cfg(no_sc_torsion=True)
+    ref = sm.forward({k: v for k, v in params.items() if not k.startswith("sc_")}, rigid, copy.deepcopy(dd))
+    out = hip_scores(model, dd, dev)
+    assert out[3].numel() == 0
+    for a, b in zip(out[:3], ref[:3]):
+        assert rel_err(a, b) < SCORE_RTOL
+    samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
+    res = samp(namespace_to(d, dev), mode="test")
+    assert len(res) == 2 and all(torch.isfinite(l).all() and torch.isfinite(a).all() for l, a in res)
+
+
+def test_oversized_inputs_are_rejected(setup, dev):
+    mcfg, params, model = setup
+    rng = np.random.default_rng(23)
+    pk, lg = synthetic.make_pocket(rng, 40), synthetic.make_ligand(rng, 300)      # > 256 ligand heavy atoms
+    lg["tor_edge_mask"][:] = False
+    lg["rot_node_mask"] = np.zeros((0, 300), bool)
+    d = synthetic.collate([(pk, lg) + synthetic.init_pose(rng, pk, lg)])
+    sc = osched.step_scalars(osched.default_sample_cfg(), 0)
+    with pytest.raises(L.DbfrError, match="256"):
+        model(namespace_to(osampler.set_time(d, sc, 1), dev))
