@@ -219,6 +219,32 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
     wave_groups[best].push_back(gi);
     wave_load[best] += groups[gi].tiles;
   }
+  // local search on top of LPT: move / swap groups between the heaviest wave and the others while that lowers the
+  // maximum (e.g. W=7776: 24 groups of 15 tiles + 6 of 21 => LPT 126/126/117/117, after refinement 123/123/120/120)
+  for (int iter = 0; iter < 64; ++iter) {
+    int hi = 0;
+    for (int v = 1; v < 4; ++v) if (wave_load[v] > wave_load[hi]) hi = v;
+    bool improved = false;
+    for (int v = 0; v < 4 && !improved; ++v) {
+      if (v == hi) continue;
+      for (size_t i = 0; i < wave_groups[hi].size() && !improved; ++i) {
+        const int gi = wave_groups[hi][i], ti = groups[gi].tiles;
+        // move
+        if (std::max(wave_load[hi] - ti, wave_load[v] + ti) < wave_load[hi]) {
+          wave_groups[v].push_back(gi); wave_groups[hi].erase(wave_groups[hi].begin() + i);
+          wave_load[hi] -= ti; wave_load[v] += ti; improved = true; break;
+        }
+        for (size_t j = 0; j < wave_groups[v].size(); ++j) {   // swap
+          const int gj = wave_groups[v][j], tj = groups[gj].tiles;
+          if (tj < ti && std::max(wave_load[hi] - ti + tj, wave_load[v] + ti - tj) < wave_load[hi]) {
+            std::swap(wave_groups[hi][i], wave_groups[v][j]);
+            wave_load[hi] += tj - ti; wave_load[v] += ti - tj; improved = true; break;
+          }
+        }
+      }
+    }
+    if (!improved) break;
+  }
   std::vector<Row> rows;
   std::vector<uint32_t> quads;
   int wave_tile0[5] = {0, 0, 0, 0, 0};

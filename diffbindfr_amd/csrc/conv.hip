@@ -251,6 +251,14 @@ void launch_conv(const ConvArgs& a, hipStream_t st) {
   const int te = 16 * nb;
   int blocks = (a.max_edges + te - 1) / te;
   if (blocks <= 0) return;
+  static int abl = -1;
+  if (abl < 0) { const char* e = getenv("DBFR_CONV_ABL"); abl = e ? atoi(e) : 0; }
+  if (abl && a.w.K == 144 && nb == 3) {   // developer ablations of the hot loop: 1 no epilogue, 2 no A re-load, 3 both
+    if (abl == 1) hipLaunchKernelGGL((k_conv<144, 3, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else if (abl == 2) hipLaunchKernelGGL((k_conv<144, 3, 2>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv<144, 3, 3>), dim3(blocks), dim3(256), 0, st, a);
+    return;
+  }
 #define LAUNCH(KK, NBB) hipLaunchKernelGGL((k_conv<KK, NBB, 0>), dim3(blocks), dim3(256), 0, st, a)
   if (a.w.K != 144) { if (nb == 1) LAUNCH(96, 1); else if (nb == 2) LAUNCH(96, 2); else LAUNCH(96, 3); }
   else { if (nb == 1) LAUNCH(144, 1); else if (nb == 2) LAUNCH(144, 2); else LAUNCH(144, 3); }
