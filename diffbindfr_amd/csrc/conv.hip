@@ -33,6 +33,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SKEW
+#define SKEW 59   // s_sleep units of 64 cycles: ~half of a (shared-pipe MFMA phase + epilogue) period
+#endif
+
 // closed-form Clebsch-Gordan contraction of one 4-row quad (must mirror so3_host.cpp: closed_form)
 __device__ __forceinline__ void quad_contract(int type, const f32x4 v, const float* __restrict__ xr,
                                               const float* __restrict__ sp, float& p0, float& p1, float& p2) {
@@ -73,24 +77,38 @@ __device__ __forceinline__ void quad_contract(int type, const f32x4 v, const flo
 
 // K: radial-MLP width (144 / 96); NB: 16-edge blocks per workgroup (TE = 16 NB edges share every A fragment
 // fetched from L2 -- the L2->CU fabric, not HBM, is what the weight stream loads); ABL: developer ablations.
-template <int K, int NB, int ABL>
-__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+template <int K, int NB, int ABL, int NH>
+__global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
   constexpr int TE = 16 * NB;
   constexpr int KT = K / 16;  // 16-wide tiles along the MLP input/hidden dim
   constexpr int KS = K / 4;   // MFMA k-steps
   constexpr int A_LD = K + 1;
   constexpr int H_LD = TE + 1;
   constexpr int UN = (TE * (MAXD + 5) > K * H_LD) ? TE * (MAXD + 5) : K * H_LD;
-  __shared__ __attribute__((aligned(16))) float xs[TE * XS_LD];
-  __shared__ float un[UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][D_out+5]
-  __shared__ float shs[TE * 10];
-  __shared__ int s_gth[TE], s_i1[TE], s_i2[TE];
+  // Two independent 4-wave halves per workgroup (512 threads): half h works on edge tile 2*blockIdx+h.  A 512-thread
+  // workgroup puts waves w and w+4 on the same SIMD, i.e. the two waves that share a matrix pipe are the SAME wave
+  // slot of the two halves and walk the SAME W2 tile range.  Half 1 is started half an MFMA phase late, so that
+  //  (1) its epilogues fall into the other wave's MFMA phase instead of colliding with its epilogues every tile
+  //      (two co-resident 4-wave workgroups start and finish together and stay in phase for their whole life), and
+  //  (2) its W2 fragment loads find the lines its partner fetched a moment earlier still in the CU's L1.
+  __shared__ __attribute__((aligned(16))) float xs_all[NH * TE * XS_LD];
+  __shared__ float un_all[NH * UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][D_out+5]
+  __shared__ float shs_all[NH * TE * 10];
+  __shared__ int s_idx[NH * 3 * TE];
 
   const int E = min(*a.n_edges, a.max_edges);
-  const int tile0 = blockIdx.x * TE;
-  if (tile0 >= E) return;
+  if (blockIdx.x * NH * TE >= E) return;
+  const int half = threadIdx.x >> 8;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const bool active = (blockIdx.x * NH + half) * TE < E;     // an inactive half shadows half 0 and stores nothing
+  const int tile0 = (blockIdx.x * NH + (active ? half : 0)) * TE;
   const int ne = min(TE, E - tile0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* xs = xs_all + half * TE * XS_LD;
+  float* un = un_all + half * UN;
+  float* shs = shs_all + half * TE * 10;
+  int* s_gth = s_idx + half * 3 * TE;
+  int* s_i1 = s_gth + TE;
+  int* s_i2 = s_i1 + TE;
   const int n = lane & 15, g = lane >> 4;
   const int D_in = a.w.D_in, D_out = a.w.D_out;
   const int O_LD = D_out + 5;   // +3 trash columns for padded (dummy) channels, odd stride vs banks
@@ -102,22 +120,59 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     s_i2[tid] = (K == 144) ? a.idx2[e] : 0;
   }
   __syncthreads();
-  // ---------------- phase A
-  for (int i = tid; i < TE * NS; i += 256) {
-    int e = i / NS, c = i - e * NS;
-    int ge = tile0 + min(e, ne - 1);
-    float live = e < ne ? 1.f : 0.f;
-    un[e * A_LD + c] = live * a.emb[(size_t)ge * NS + c];
-    un[e * A_LD + NS + c] = live * a.tab1[(size_t)s_i1[e] * a.ld1 + c];
-    if (K == 144) un[e * A_LD + 2 * NS + c] = live * a.tab2[(size_t)s_i2[e] * a.ld2 + c];
-  }
-  for (int i = tid; i < TE * D_in; i += 256) {
-    int e = i / D_in, c = i - e * D_in;
-    xs[e * XS_LD + c] = e < ne ? a.x[(size_t)s_gth[e] * a.ldx + c] : 0.f;
-  }
-  for (int i = tid; i < TE * SH_LD; i += 256) {
-    int e = i / SH_LD, c = i - e * SH_LD;
-    shs[e * 10 + c] = a.sh[(size_t)(tile0 + min(e, ne - 1)) * SH_LD + c];
+  // ---------------- phase A: gather edge_attr_ and x[gth] into LDS.  All 16-byte loads of a thread are issued
+  // before the first LDS store so that one round of L2 latency covers the whole gather.
+  {
+    constexpr int NPART = (K == 144) ? 3 : 2;
+    constexpr int P4 = NS / 4;                                   // float4 per 48-float part
+    constexpr int NA4 = TE * NPART * P4, JA = (NA4 + 255) / 256;
+    f32x4 va[JA];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const int i = tid + 256 * j;
+      va[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < NA4) {
+        const int e = i / (NPART * P4), r = i - e * (NPART * P4), part = r / P4, c4 = r - part * P4;
+        if (e < ne) {
+          const float* src = part == 0 ? a.emb + (size_t)(tile0 + e) * NS
+                           : part == 1 ? a.tab1 + (size_t)s_i1[e] * a.ld1 : a.tab2 + (size_t)s_i2[e] * a.ld2;
+          va[j] = *reinterpret_cast<const f32x4*>(src + 4 * c4);
+        }
+      }
+    }
+    const int d4 = D_in >> 2, NX4 = TE * d4;
+    constexpr int JX = (TE * (MAXD / 4) + 255) / 256;
+    f32x4 vx[JX];
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int i = tid + 256 * j;
+      vx[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < NX4) {
+        const int e = i / d4, c4 = i - e * d4;
+        if (e < ne) vx[j] = *reinterpret_cast<const f32x4*>(a.x + (size_t)s_gth[e] * a.ldx + 4 * c4);
+      }
+    }
+    for (int i = tid; i < TE * SH_LD; i += 256) {
+      int e = i / SH_LD, c = i - e * SH_LD;
+      shs[e * 10 + c] = a.sh[(size_t)(tile0 + min(e, ne - 1)) * SH_LD + c];
+    }
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      const int i = tid + 256 * j;
+      if (i < NA4) {
+        const int e = i / (NPART * P4), r = i - e * (NPART * P4);
+        float* dst = un + e * A_LD + 4 * r;
+        dst[0] = va[j][0]; dst[1] = va[j][1]; dst[2] = va[j][2]; dst[3] = va[j][3];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int i = tid + 256 * j;
+      if (i < NX4) {
+        const int e = i / d4, c4 = i - e * d4;
+        *reinterpret_cast<f32x4*>(xs + e * XS_LD + 4 * c4) = vx[j];
+      }
+    }
   }
   __syncthreads();
   // ---------------- phase B: hidden layer on the matrix cores
@@ -162,6 +217,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) Bv[b][s] = un[(4 * s + g) * H_LD + 16 * b + n];
   __syncthreads();   // hs is dead: the region becomes the message tile (every element is stored exactly once)
+  if (NH == 2 && half) {        // start half 1 ~half an MFMA phase behind its SIMD partner (see the kernel header)
+    __builtin_amdgcn_s_sleep(SKEW);
+  }
   // ---------------- phase D: W2 row tiles of this wave (channel-owner order, see api.cpp pack_conv)
   const f32x4* W2 = reinterpret_cast<const f32x4*>(a.w.W2p);
   const int t_begin = a.w.wave_tile0[wave], t_end = a.w.wave_tile0[wave + 1];
@@ -182,7 +240,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   float oacc[NB][3];   // running message element(s) of this lane's channel, per edge block
 #pragma unroll
   for (int b = 0; b < NB; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
-  for (int t = t_begin; t < t_end; ++t) {
+  for (int t = t_begin; t < ((ABL & 8) ? t_begin : t_end); ++t) {
     const bool has_next = t + 1 < t_end;
     const int tn = has_next ? t + 1 : t;
     const f32x4* Apn = W2 + (size_t)tn * KT * 64 + lane;
@@ -234,34 +292,28 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   }
   __syncthreads();
   // ---------------- phase E
-  for (int i = tid; i < ne * D_out; i += 256) {
-    int e = i / D_out, c = i - e * D_out;
-    a.msg[(size_t)(tile0 + e) * D_out + c] = un[e * O_LD + c];
-  }
+  if (active)
+    for (int i = tid; i < ne * D_out; i += 256) {
+      int e = i / D_out, c = i - e * D_out;
+      a.msg[(size_t)(tile0 + e) * D_out + c] = un[e * O_LD + c];
+    }
 }
 
 #define CONV_NB 3
+#define CONV_NH 1   // 2 = two skewed halves per 512-thread workgroup (hides the epilogue but exposes the prologue: slower)
+
 
 void launch_conv(const ConvArgs& a, hipStream_t st) {
-  static int nb_env = -1;   // developer knob DBFR_CONV_NB (1, 2 or 3); 0 = automatic
-  if (nb_env < 0) { const char* e = getenv("DBFR_CONV_NB"); nb_env = e ? atoi(e) : 0; }
-  // 48-edge workgroups: each A fragment fetched from L2 feeds 3 edge blocks.  (16-edge workgroups fill the chip
-  // better for a handful of poses but stream W2 3x as often from L2: measured a wash)
-  const int nb = nb_env ? nb_env : CONV_NB;
-  const int te = 16 * nb;
-  int blocks = (a.max_edges + te - 1) / te;
-  if (blocks <= 0) return;
-  static int abl = -1;
+  static int nh = -1, abl = -1;   // developer knobs: DBFR_CONV_NH (1 | 2 halves per workgroup), DBFR_CONV_ABL (ablations)
+  if (nh < 0) { const char* e = getenv("DBFR_CONV_NH"); nh = e ? atoi(e) : CONV_NH; }
   if (abl < 0) { const char* e = getenv("DBFR_CONV_ABL"); abl = e ? atoi(e) : 0; }
-  if (abl && a.w.K == 144 && nb == 3) {   // developer ablations of the hot loop: 1 no epilogue, 2 no A re-load, 3 both
-    if (abl == 1) hipLaunchKernelGGL((k_conv<144, 3, 1>), dim3(blocks), dim3(256), 0, st, a);
-    else if (abl == 2) hipLaunchKernelGGL((k_conv<144, 3, 2>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_conv<144, 3, 3>), dim3(blocks), dim3(256), 0, st, a);
-    return;
-  }
-#define LAUNCH(KK, NBB) hipLaunchKernelGGL((k_conv<KK, NBB, 0>), dim3(blocks), dim3(256), 0, st, a)
-  if (a.w.K != 144) { if (nb == 1) LAUNCH(96, 1); else if (nb == 2) LAUNCH(96, 2); else LAUNCH(96, 3); }
-  else { if (nb == 1) LAUNCH(144, 1); else if (nb == 2) LAUNCH(144, 2); else LAUNCH(144, 3); }
+  const int te = 16 * CONV_NB;
+  const int tiles = (a.max_edges + te - 1) / te;
+  if (tiles <= 0) return;
+#define LAUNCH(KK, AB, NHH) hipLaunchKernelGGL((k_conv<KK, CONV_NB, AB, NHH>), dim3((tiles + NHH - 1) / NHH), dim3(256 * NHH), 0, st, a)
+  if (a.w.K != 144) { if (nh == 2) LAUNCH(96, 0, 2); else LAUNCH(96, 0, 1); return; }
+  if (nh == 2) { switch (abl) { case 1: LAUNCH(144, 1, 2); break; case 8: LAUNCH(144, 8, 2); break; default: LAUNCH(144, 0, 2); } }
+  else { switch (abl) { case 1: LAUNCH(144, 1, 1); break; case 8: LAUNCH(144, 8, 1); break; default: LAUNCH(144, 0, 1); } }
 #undef LAUNCH
 }
 
