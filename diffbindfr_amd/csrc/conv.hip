@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
   constexpr int KS = K / 4;   // MFMA k-steps
   constexpr int A_LD = K + 1;
   constexpr int H_LD = TE + 1;
-  constexpr int UN = (TE * (MAXD + 5) > K * H_LD) ? TE * (MAXD + 5) : K * H_LD;
+  constexpr int UN = (TE * (MAXD + 8) > K * H_LD) ? TE * (MAXD + 8) : K * H_LD;
   // Two independent 4-wave halves per workgroup (512 threads): half h works on edge tile 2*blockIdx+h.  A 512-thread
   // workgroup puts waves w and w+4 on the same SIMD, i.e. the two waves that share a matrix pipe are the SAME wave
   // slot of the two halves and walk the SAME W2 tile range.  Half 1 is started half an MFMA phase late, so that
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
   //      (two co-resident 4-wave workgroups start and finish together and stay in phase for their whole life), and
   //  (2) its W2 fragment loads find the lines its partner fetched a moment earlier still in the CU's L1.
   __shared__ __attribute__((aligned(16))) float xs_all[NH * TE * XS_LD];
-  __shared__ float un_all[NH * UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][D_out+5]
+  __shared__ __attribute__((aligned(16))) float un_all[NH * UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][D_out+5]
   __shared__ float shs_all[NH * TE * 10];
   __shared__ int s_idx[NH * 3 * TE];
 
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
   int* s_i2 = s_i1 + TE;
   const int n = lane & 15, g = lane >> 4;
   const int D_in = a.w.D_in, D_out = a.w.D_out;
-  const int O_LD = D_out + 5;   // +3 trash columns for padded (dummy) channels, odd stride vs banks
+  const int O_LD = ((D_out + 3) & ~3) + 4;   // 16-B aligned rows (phase E moves float4s) + trash columns for padded channels
 
   if (tid < TE) {
     int e = tile0 + min(tid, ne - 1);
@@ -175,38 +175,51 @@ __global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
     }
   }
   __syncthreads();
-  // ---------------- phase B: hidden layer on the matrix cores
-  constexpr int NJOB = KT * NB;
-  constexpr int JPW = (NJOB + 3) / 4;
-  f32x4 hacc[JPW];
+  // ---------------- phase B: hidden layer on the matrix cores.  A job = one 16-row tile of W1 against all NB edge
+  // blocks (each W1 fragment feeds NB MFMAs, NB independent accumulator chains); the next job's fragments are
+  // requested before the current job's MFMAs.
+  constexpr int JPW = (KT + 3) / 4;        // row tiles per wave
+  f32x4 hacc[JPW][NB];
+  {
+    const f32x4* W1 = reinterpret_cast<const f32x4*>(a.w.W1p) + lane;
+    f32x4 A1[KT];
+    if (wave < KT) {
 #pragma unroll
-  for (int jj = 0; jj < JPW; ++jj) {
-    int job = wave + 4 * jj;
-    hacc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (job < NJOB) {
-      int m = job / NB, b = job - m * NB;
-      const f32x4* Ap = reinterpret_cast<const f32x4*>(a.w.W1p) + (size_t)m * KT * 64 + lane;
-      const float* Bp = un + (16 * b + n) * A_LD + g;
+      for (int s4 = 0; s4 < KT; ++s4) A1[s4] = W1[((size_t)wave * KT + s4) * 64];
+    }
 #pragma unroll
-      for (int s4 = 0; s4 < KT; ++s4) {
-        f32x4 A4 = Ap[s4 * 64];
+    for (int jj = 0; jj < JPW; ++jj) {
+      const int m = wave + 4 * jj;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          hacc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[q], Bp[4 * (4 * s4 + q)], hacc[jj], 0, 0, 0);
+      for (int b = 0; b < NB; ++b) hacc[jj][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < KT) {
+        const int mn = (m + 4 < KT) ? m + 4 : m;
+        const float* Bp = un + n * A_LD + g;
+#pragma unroll
+        for (int s4 = 0; s4 < KT; ++s4) {
+          const f32x4 av = A1[s4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+              hacc[jj][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bp[16 * b * A_LD + 4 * (4 * s4 + q)], hacc[jj][b], 0, 0, 0);
+          A1[s4] = W1[((size_t)mn * KT + s4) * 64];
+        }
       }
     }
   }
   __syncthreads();  // everyone is done reading a1
 #pragma unroll
   for (int jj = 0; jj < JPW; ++jj) {
-    int job = wave + 4 * jj;
-    if (job < NJOB) {
-      int m = job / NB, b = job - m * NB;
+    const int m = wave + 4 * jj;
+    if (m < KT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = 16 * m + 4 * g + r;
-        un[row * H_LD + 16 * b + n] = fmaxf(hacc[jj][r] + a.w.b1[row], 0.f);
-      }
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * m + 4 * g + r;
+          un[row * H_LD + 16 * b + n] = fmaxf(hacc[jj][b][r] + a.w.b1[row], 0.f);
+        }
     }
   }
   __syncthreads();
@@ -292,11 +305,14 @@ __global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
   }
   __syncthreads();
   // ---------------- phase E
-  if (active)
-    for (int i = tid; i < ne * D_out; i += 256) {
-      int e = i / D_out, c = i - e * D_out;
-      a.msg[(size_t)(tile0 + e) * D_out + c] = un[e * O_LD + c];
+  if (active) {
+    const int d4 = D_out >> 2;             // D_out is a multiple of 4 for every conv (84, 120, 168, 12, 96)
+    for (int i = tid; i < ne * d4; i += 256) {
+      const int e = i / d4, c4 = i - e * d4;
+      *reinterpret_cast<f32x4*>(a.msg + (size_t)(tile0 + e) * D_out + 4 * c4) =
+          *reinterpret_cast<const f32x4*>(un + e * O_LD + 4 * c4);
     }
+  }
 }
 
 #define CONV_NB 3
