@@ -89,6 +89,10 @@ struct dbfr_model {
   size_t ev_used;
   double* flops_dev;
   double conv_ms_acc; int64_t conv_launches_acc;
+  // side streams for small batches: the four convs of an interaction layer (and the three heads) are independent
+  hipStream_t side[3];
+  hipEvent_t ev_fork, ev_a, ev_b, ev_join[3];
+  bool streams_ready;
 };
 
 template <typename T>
@@ -348,6 +352,7 @@ extern "C" int dbfr_model_create(const dbfr_model_cfg* cfg, const dbfr_tensor* t
   dbfr_model* m = new dbfr_model();
   m->cfg = *cfg;
   m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
+  m->streams_ready = false;
   const char* fam[4] = {"lig_conv_layers", "cross_al_conv_layers", "atom_conv_layers", "cross_la_conv_layers"};
   for (int l = 0; l < cfg->num_conv_layers && !rc; ++l)
     for (int f = 0; f < 4 && !rc; ++f)
@@ -400,6 +405,10 @@ extern "C" void dbfr_model_destroy(dbfr_model* m) {
   if (!m) return;
   for (void* p : m->allocs) (void)hipFree(p);
   for (auto e : m->ev) (void)hipEventDestroy(e);
+  if (m->streams_ready) {
+    for (int i = 0; i < 3; ++i) { (void)hipStreamDestroy(m->side[i]); (void)hipEventDestroy(m->ev_join[i]); }
+    (void)hipEventDestroy(m->ev_fork); (void)hipEventDestroy(m->ev_a); (void)hipEventDestroy(m->ev_b);
+  }
   delete m;
 }
 
@@ -427,7 +436,7 @@ struct Ws {
   EdgeSet set[N_SETS]; int n_edges_store_dummy;
   // centre set
   int *c_tgt, *c_gth, *c_row_start, *c_row_cnt, *c_n; float *c_dist, *c_sh, *c_emb;
-  float* msg; float* gp; float *tor_attr, *sc_attr, *tor_feat, *sc_feat;
+  float* msg[4]; int multi; float* gp; float *tor_attr, *sc_attr, *tor_feat, *sc_feat;
   int* n_edges6;  // [8] device counters
 };
 
@@ -473,7 +482,11 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   w->c_tgt = b.take<int>(NL); w->c_gth = b.take<int>(NL); w->c_dist = b.take<float>(NL); w->c_sh = b.take<float>((size_t)NL * SH_LD, "center.sh");
   w->c_emb = b.take<float>((size_t)NL * NS, "center.emb"); w->c_row_start = b.take<int>(G); w->c_row_cnt = b.take<int>(G);
   w->c_n = w->n_edges6 ? w->n_edges6 + 6 : nullptr;
-  w->msg = b.take<float>((size_t)maxcap * MAXD, "msg");
+  // small batches: one message buffer per concurrent conv (4 independent convs per layer run on 4 streams so that
+  // launches of a few hundred workgroups still fill 256 CUs); large batches: one buffer, one stream
+  static const long multi_edges = getenv("DBFR_MULTI_EDGES") ? atol(getenv("DBFR_MULTI_EDGES")) : 512 * 1024;
+  w->multi = maxcap <= multi_edges;
+  for (int i = 0; i < 4; ++i) w->msg[i] = (i == 0 || w->multi) ? b.take<float>((size_t)maxcap * MAXD, i == 0 ? "msg" : nullptr) : nullptr;
   w->gp = b.take<float>((size_t)G * 12, "gp");
   w->tor_attr = b.take<float>((size_t)(B->NTOR + 1) * NS, "tor_attr"); w->sc_attr = b.take<float>((size_t)(B->NSC + 1) * NS);
   w->tor_feat = b.take<float>((size_t)(B->NTOR + 1) * 2 * NS, "tor_feat"); w->sc_feat = b.take<float>((size_t)(B->NSC + 1) * 2 * NS);
@@ -571,14 +584,37 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
     float *lnew = w.lig_x[cur ^ 1], *anew = w.atom_x[cur ^ 1];
     const EdgeSet &LL = w.set[SET_LL], &AA = w.set[SET_AA], &AL = w.set[SET_AL], &LA = w.set[SET_LA];
-    conv_call(m, m->layer[l][0], LL.n_edges, LL.cap, LL.tgt, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg, st);
-    launch_reduce_ln(w.msg, LL.row_start, LL.row_cnt, NL, Do, m->layer[l][0].ln, lx, Di, lnew, Do, 0, st);
-    conv_call(m, m->layer[l][1], AL.n_edges, AL.cap, AL.tgt, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg, st);
-    launch_reduce_ln(w.msg, AL.row_start, AL.row_cnt, NL, Do, m->layer[l][1].ln, nullptr, 0, lnew, Do, 1, st);
-    conv_call(m, m->layer[l][2], AA.n_edges, AA.cap, AA.tgt, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg, st);
-    launch_reduce_ln(w.msg, AA.row_start, AA.row_cnt, NA, Do, m->layer[l][2].ln, ax, Di, anew, Do, 0, st);
-    conv_call(m, m->layer[l][3], LA.n_edges, LA.cap, LA.tgt, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg, st);
-    launch_reduce_ln(w.msg, LA.row_start, LA.row_cnt, NA, Do, m->layer[l][3].ln, nullptr, 0, anew, Do, 1, st);
+    if (!w.multi || m->profile) {   // profiling times each conv alone on the main stream
+      conv_call(m, m->layer[l][0], LL.n_edges, LL.cap, LL.tgt, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0], st);
+      launch_reduce_ln(w.msg[0], LL.row_start, LL.row_cnt, NL, Do, m->layer[l][0].ln, lx, Di, lnew, Do, 0, st);
+      conv_call(m, m->layer[l][1], AL.n_edges, AL.cap, AL.tgt, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[0], st);
+      launch_reduce_ln(w.msg[0], AL.row_start, AL.row_cnt, NL, Do, m->layer[l][1].ln, nullptr, 0, lnew, Do, 1, st);
+      conv_call(m, m->layer[l][2], AA.n_edges, AA.cap, AA.tgt, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg[0], st);
+      launch_reduce_ln(w.msg[0], AA.row_start, AA.row_cnt, NA, Do, m->layer[l][2].ln, ax, Di, anew, Do, 0, st);
+      conv_call(m, m->layer[l][3], LA.n_edges, LA.cap, LA.tgt, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[0], st);
+      launch_reduce_ln(w.msg[0], LA.row_start, LA.row_cnt, NA, Do, m->layer[l][3].ln, nullptr, 0, anew, Do, 1, st);
+    } else {
+      // fork: all four convs read the OLD features; the two reductions into one node set stay ordered by an event
+      hipStream_t s0 = m->side[0], s1 = m->side[1], s2 = m->side[2];
+      HIPCHECK(hipEventRecord(m->ev_fork, st));
+      for (int i = 0; i < 3; ++i) HIPCHECK(hipStreamWaitEvent(m->side[i], m->ev_fork, 0));
+      conv_call(m, m->layer[l][0], LL.n_edges, LL.cap, LL.tgt, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0], st);
+      conv_call(m, m->layer[l][1], AL.n_edges, AL.cap, AL.tgt, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[1], s0);
+      conv_call(m, m->layer[l][2], AA.n_edges, AA.cap, AA.tgt, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg[2], s1);
+      conv_call(m, m->layer[l][3], LA.n_edges, LA.cap, LA.tgt, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3], s2);
+      launch_reduce_ln(w.msg[0], LL.row_start, LL.row_cnt, NL, Do, m->layer[l][0].ln, lx, Di, lnew, Do, 0, st);
+      HIPCHECK(hipEventRecord(m->ev_a, st));
+      HIPCHECK(hipStreamWaitEvent(s0, m->ev_a, 0));
+      launch_reduce_ln(w.msg[1], AL.row_start, AL.row_cnt, NL, Do, m->layer[l][1].ln, nullptr, 0, lnew, Do, 1, s0);
+      launch_reduce_ln(w.msg[2], AA.row_start, AA.row_cnt, NA, Do, m->layer[l][2].ln, ax, Di, anew, Do, 0, s1);
+      HIPCHECK(hipEventRecord(m->ev_b, s1));
+      HIPCHECK(hipStreamWaitEvent(s2, m->ev_b, 0));
+      launch_reduce_ln(w.msg[3], LA.row_start, LA.row_cnt, NA, Do, m->layer[l][3].ln, nullptr, 0, anew, Do, 1, s2);
+      HIPCHECK(hipEventRecord(m->ev_join[0], s0));
+      HIPCHECK(hipEventRecord(m->ev_join[2], s2));
+      HIPCHECK(hipStreamWaitEvent(st, m->ev_join[0], 0));
+      HIPCHECK(hipStreamWaitEvent(st, m->ev_join[2], 0));
+    }
     cur ^= 1;
   }
   const int D = dims[std::min(cfg.num_conv_layers, 3)];
@@ -592,8 +628,8 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     a.dist = w.c_dist; a.gs_offset = m->gs_center_off; a.gs_coeff = m->gs_center_c; a.out = w.c_emb;
     launch_mlp(a, st);
   }
-  conv_call(m, m->final_conv, w.n_edges6 + 7, NL, w.c_tgt, w.c_gth, w.c_emb, w.c_sh, lx, D, w.c_gth, nullptr, 0, w.c_gth, lx, D, w.msg, st);
-  launch_reduce_ln(w.msg, w.c_row_start, w.c_row_cnt, G, 12, m->final_conv.ln, nullptr, 0, w.gp, 12, 2, st);
+  conv_call(m, m->final_conv, w.n_edges6 + 7, NL, w.c_tgt, w.c_gth, w.c_emb, w.c_sh, lx, D, w.c_gth, nullptr, 0, w.c_gth, lx, D, w.msg[0], st);
+  launch_reduce_ln(w.msg[0], w.c_row_start, w.c_row_cnt, G, 12, m->final_conv.ln, nullptr, 0, w.gp, 12, 2, st);
   {
     TrRotArgs a; a.gp = w.gp; a.temb = w.temb; a.tr_sigma = c->tr_sigma; a.rot_norm = c->rot_score_norm;
     a.tr = m->tr_final; a.rot = m->rot_final; a.G = G; a.scale_by_sigma = cfg.scale_by_sigma; a.tr_out = out->tr;
@@ -610,8 +646,8 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_lig_off; a.gs_coeff = m->gs_lig_c; a.out = T.emb;
       launch_mlp(a, st);
     }
-    conv_call(m, m->tor_conv, T.n_edges, T.cap, T.tgt, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg, st);
-    launch_reduce_ln(w.msg, T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
+    conv_call(m, m->tor_conv, T.n_edges, T.cap, T.tgt, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg[0], st);
+    launch_reduce_ln(w.msg[0], T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
     launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, st);
   }
   // ---- side-chain torsion head
@@ -624,8 +660,8 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_atom_off; a.gs_coeff = m->gs_atom_c; a.out = S.emb;
       launch_mlp(a, st);
     }
-    conv_call(m, m->sc_conv, S.n_edges, S.cap, S.tgt, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg, st);
-    launch_reduce_ln(w.msg, S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, st);
+    conv_call(m, m->sc_conv, S.n_edges, S.cap, S.tgt, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg[0], st);
+    launch_reduce_ln(w.msg[0], S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, st);
     launch_tor_final(w.sc_feat, m->sc_final, c->sc_tor_score_norm2, cfg.scale_by_sigma, B->NSC, out->sc_tor, st);
   }
   return DBFR_OK;
@@ -641,6 +677,16 @@ static int begin(dbfr_model* m, const dbfr_batch* B, void* workspace, size_t wby
   rc = plan(m, B, lim, (char*)workspace, wbytes, w, &needb);
   if (rc) return rc;
   if (needb > wbytes) return fail(DBFR_ERR_ARG, "workspace too small: need " + std::to_string(needb) + " bytes");
+  if (w->multi && !m->streams_ready) {
+    for (int i = 0; i < 3; ++i) {
+      HIPCHECK(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&m->ev_a, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&m->ev_b, hipEventDisableTiming));
+    m->streams_ready = true;
+  }
   HIPCHECK(hipMemsetAsync(workspace, 0, 1024, st));   // err @0, counters @256, n_edges6 @512
   launch_set_int(w->n_edges6 + 7, B->NL, st);           // the centre set has exactly one edge per ligand atom
   launch_batch_vectors(*B, w->lig_batch, w->atm_batch, w->is_cab, w->n_cab, w->tor_batch, w->sc_batch, st);

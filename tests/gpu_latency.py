@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 model = bench.seeded_params().to(dev)
 samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
 recs, _ = samp.schedule()
-for cfg_id, nc, np_ in ((1, 1, 4), (2, 1, 16), (2, 1, 40)):
+for cfg_id, nc, np_ in ((1, 1, 4), (2, 1, 16), (2, 1, 40), (2, 2, 40), (2, 4, 40)):
     d = synthetic.make_batch(cfg_id, n_complex=nc, poses=np_, seed=1)
     for k, v in vars(d).items():
         if torch.is_tensor(v): setattr(d, k, v.to(dev))
