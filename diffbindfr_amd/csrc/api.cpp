@@ -56,7 +56,8 @@ void launch_sidechain(const dbfr_batch& b, const float* score, const float* z, f
                       const int* a14_group, float* atom14_out, float* traj14, hipStream_t st);
 void launch_fill(float* p, float v, int n, hipStream_t st);
 void launch_set_int(int* p, int v, hipStream_t st);
-void launch_acc_flops(const int* n_edges, double per_edge, double* counter, hipStream_t st);
+void launch_init_poses(const dbfr_batch& b, const dbfr_init_tape& z, const int* a14_group, float* atom14_out, hipStream_t st);
+void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st);
 
 // restype_atom14_to_rigid_group (AF2 constant table; reference protein_constants.py:1177, data only)
 static const int kAtom14ToGroup[21 * 14] = {
@@ -395,7 +396,7 @@ extern "C" int dbfr_model_create(const dbfr_model_cfg* cfg, const dbfr_tensor* t
     if (!rc) { *gs[i].off = upload(m, std::vector<float>(off, off + EMB), &rc); *gs[i].c = upload(m, std::vector<float>(c, c + 1), &rc); }
   }
   if (!rc) m->a14_group = upload(m, std::vector<int>(kAtom14ToGroup, kAtom14ToGroup + 21 * 14), &rc);
-  if (!rc) { m->flops_dev = upload(m, std::vector<double>(1, 0.0), &rc); }
+  if (!rc) { m->flops_dev = upload(m, std::vector<double>(2, 0.0), &rc); }
   if (rc) { dbfr_model_destroy(m); return rc; }
   *out = m;
   return DBFR_OK;
@@ -533,7 +534,9 @@ static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int ma
   if (m->profile) {
     (void)hipEventRecord(e1, st);
     // algorithmic flops per edge: radial MLP 2K(K + W) + tensor-product contraction 2*(sum_paths mul1*mulo*dim_o)
-    launch_acc_flops(n_edges, 2.0 * cw.K * ((double)cw.K + cw.W), m->flops_dev, st);
+    // second counter: HBM bytes the reference's two-kernel form moves per edge (the [E,W] weights once,
+    // gathered irreps, harmonics, two int64 indices); the fused kernel never materialises them
+    launch_acc_flops(n_edges, 2.0 * cw.K * ((double)cw.K + cw.W), 4.0 * (cw.W + cw.D_in + 9) + 16.0, m->flops_dev, st);
   }
 }
 
@@ -766,6 +769,17 @@ extern "C" int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* coun
   return DBFR_OK;
 }
 
+extern "C" int dbfr_init_poses(const dbfr_model* m, const dbfr_batch* b, const dbfr_init_tape* tape, float* atom14_out,
+                               void* hip_stream) {
+  int rc = check_batch(m, b);
+  if (rc) return rc;
+  if (!tape || !tape->rot || !tape->tr || !tape->sc_u || (b->NTOR > 0 && !tape->tor_u))
+    return fail(DBFR_ERR_ARG, "null init tape");
+  launch_init_poses(*b, *tape, m->a14_group, atom14_out, (hipStream_t)hip_stream);
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
 extern "C" int dbfr_profile_enable(dbfr_model* m, int32_t on) {
   if (!m) return fail(DBFR_ERR_ARG, "null model");
   m->profile = on;
@@ -773,7 +787,7 @@ extern "C" int dbfr_profile_enable(dbfr_model* m, int32_t on) {
 }
 
 extern "C" int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops,
-                                 int32_t reset) {
+                                 double* ref_form_bytes, int32_t reset) {
   if (!m) return fail(DBFR_ERR_ARG, "null model");
   HIPCHECK(hipDeviceSynchronize());
   for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
@@ -781,12 +795,13 @@ extern "C" int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_l
     if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) { m->conv_ms_acc += ms; m->conv_launches_acc++; }
   }
   m->ev_used = 0;
-  double fl = 0;
-  HIPCHECK(hipMemcpy(&fl, m->flops_dev, sizeof fl, hipMemcpyDeviceToHost));
+  double fl[2] = {0, 0};
+  HIPCHECK(hipMemcpy(fl, m->flops_dev, sizeof fl, hipMemcpyDeviceToHost));
   if (conv_ms) *conv_ms = m->conv_ms_acc;
   if (conv_launches) *conv_launches = m->conv_launches_acc;
-  if (conv_flops) *conv_flops = fl;
-  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, sizeof(double))); }
+  if (conv_flops) *conv_flops = fl[0];
+  if (ref_form_bytes) *ref_form_bytes = fl[1];
+  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, 2 * sizeof(double))); }
   return DBFR_OK;
 }
 

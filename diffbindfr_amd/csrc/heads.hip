@@ -373,6 +373,80 @@ void launch_sidechain(const dbfr_batch& b, const float* score, const float* z, f
   if (b.NR > 0) hipLaunchKernelGGL(k_atom14, dim3((b.NR + 63) / 64), dim3(64), 0, st, b, a14_group, atom14_out, traj14);
 }
 
+// ------------------------------------------------------------------------------------------------ pose initialisation
+// LigInit (struct_init.py:24-53): uniform torsion kicks applied in order (no Kabsch), then rotate about the centroid and
+// translate -- the centroid is not added back.  One workgroup per ligand, the conformer lives in LDS.
+__global__ __launch_bounds__(128) void k_init_ligand(dbfr_batch b, dbfr_init_tape z) {
+  __shared__ float fx[MAX_NL], fy[MAX_NL], fz[MAX_NL];
+  __shared__ float sh_R[9], sh_v[3], sh_c[3];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[g], nl = b.lig_ptr[g + 1] - l0;
+  const int k0 = b.tor_ptr[g], nt = b.tor_ptr[g + 1] - k0;
+  for (int i = tid; i < nl; i += blockDim.x) {
+    fx[i] = b.lig_pos[3 * (l0 + i)]; fy[i] = b.lig_pos[3 * (l0 + i) + 1]; fz[i] = b.lig_pos[3 * (l0 + i) + 2];
+  }
+  __syncthreads();
+  for (int k = 0; k < nt; ++k) {
+    const float upd = z.tor_u[k0 + k];
+    if (upd == 0.f) continue;
+    const int e = b.tor_bond[k0 + k];
+    const int u = b.bond_src[e] - l0, v = b.bond_dst[e] - l0;
+    if (tid == 0) {
+      float ax[3] = {fx[u] - fx[v], fy[u] - fy[v], fz[u] - fz[v]};
+      float nrm = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      float rv[3] = {ax[0] * upd / nrm, ax[1] * upd / nrm, ax[2] * upd / nrm};
+      axis_angle_to_rot(rv, sh_R);
+      sh_v[0] = fx[v]; sh_v[1] = fy[v]; sh_v[2] = fz[v];
+    }
+    __syncthreads();
+    const uint8_t* mask = b.rot_mask + b.rot_mask_off[k0 + k];
+    for (int i = tid; i < nl; i += blockDim.x)
+      if (mask[i]) {
+        float x = fx[i] - sh_v[0], y = fy[i] - sh_v[1], zc = fz[i] - sh_v[2];
+        fx[i] = (x * sh_R[0] + y * sh_R[1] + zc * sh_R[2]) + sh_v[0];
+        fy[i] = (x * sh_R[3] + y * sh_R[4] + zc * sh_R[5]) + sh_v[1];
+        fz[i] = (x * sh_R[6] + y * sh_R[7] + zc * sh_R[8]) + sh_v[2];
+      }
+    __syncthreads();
+  }
+  if (tid < 3) {
+    const float* p = tid == 0 ? fx : tid == 1 ? fy : fz;
+    float s = 0.f;
+    for (int i = 0; i < nl; ++i) s += p[i];
+    sh_c[tid] = s / (float)nl;
+  }
+  if (tid < 9) sh_R[tid] = z.rot[9 * (size_t)g + tid];
+  __syncthreads();
+  for (int i = tid; i < nl; i += blockDim.x) {   // (x - c) R^T + tr
+    float x = fx[i] - sh_c[0], y = fy[i] - sh_c[1], zc = fz[i] - sh_c[2];
+    float* o = b.lig_pos + 3 * (size_t)(l0 + i);
+    o[0] = (x * sh_R[0] + y * sh_R[1] + zc * sh_R[2]) + z.tr[3 * g];
+    o[1] = (x * sh_R[3] + y * sh_R[4] + zc * sh_R[5]) + z.tr[3 * g + 1];
+    o[2] = (x * sh_R[6] + y * sh_R[7] + zc * sh_R[8]) + z.tr[3 * g + 2];
+  }
+}
+
+// SCProtInit (struct_init.py:117-124): chi <- draw * mask, psi untouched
+__global__ void k_init_chi_zero(dbfr_batch b) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= b.NR) return;
+  float* t = b.torsion_angle + (size_t)r * 5;
+  t[1] = t[2] = t[3] = t[4] = 0.f;
+}
+__global__ void k_init_chi_set(dbfr_batch b, const float* sc_u) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= b.NSC) return;
+  int rc = b.sc_res_chi[k];
+  b.torsion_angle[(size_t)(rc >> 2) * 5 + 1 + (rc & 3)] = sc_u[rc];
+}
+
+void launch_init_poses(const dbfr_batch& b, const dbfr_init_tape& z, const int* a14_group, float* atom14_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_init_ligand, dim3(b.G), dim3(128), 0, st, b, z);
+  hipLaunchKernelGGL(k_init_chi_zero, dim3((b.NR + 255) / 256), dim3(256), 0, st, b);
+  if (b.NSC > 0) hipLaunchKernelGGL(k_init_chi_set, dim3((b.NSC + 255) / 256), dim3(256), 0, st, b, z.sc_u);
+  hipLaunchKernelGGL(k_atom14, dim3((b.NR + 63) / 64), dim3(64), 0, st, b, a14_group, atom14_out, (float*)nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------ small utilities
 __global__ void k_fill(float* p, float v, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,7 +457,10 @@ void launch_fill(float* p, float v, int n, hipStream_t st) {
 }
 __global__ void k_set_int(int* p, int v) { *p = v; }
 void launch_set_int(int* p, int v, hipStream_t st) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, p, v); }
-__global__ void k_acc_flops(const int* n_edges, double per_edge, double* counter) { *counter += per_edge * (double)*n_edges; }
-void launch_acc_flops(const int* n_edges, double per_edge, double* counter, hipStream_t st) {
-  hipLaunchKernelGGL(k_acc_flops, dim3(1), dim3(1), 0, st, n_edges, per_edge, counter);
+__global__ void k_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter) {
+  counter[0] += flops_per_edge * (double)*n_edges;
+  counter[1] += bytes_per_edge * (double)*n_edges;
+}
+void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st) {
+  hipLaunchKernelGGL(k_acc_flops, dim3(1), dim3(1), 0, st, n_edges, flops_per_edge, bytes_per_edge, counter);
 }

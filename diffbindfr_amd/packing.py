@@ -110,14 +110,28 @@ class PackedBatch:
         tei = to(g("torsion_edge_index"), torch.int64).reshape(NR * 4, 2)
         T["sc_bond"] = tei[sc_idx].to(i32).contiguous() if NSC else torch.zeros(1, 2, dtype=i32, device=dev)
         T["sc_ptr"] = _ptr_from_batch(res_batch[sc_idx // 4], G).to(i32)
+        self._finish(T, scm, m14, lig_ptr, atm_ptr, T["res_ptr"])
+
+    @classmethod
+    def from_tensors(cls, T, sc_mask, atom14_mask):
+        """A PackedBatch over already packed device tensors (diffbindfr_amd.assemble builds them directly
+        from per-complex records, without the per-pose dicts and the collate)."""
+        self = cls.__new__(cls)
+        self.G = int(T["lig_ptr"].numel()) - 1
+        self._finish(T, sc_mask, atom14_mask, T["lig_ptr"].long(), T["atm_ptr"].long(), T["res_ptr"])
+        return self
+
+    def _finish(self, T, scm, m14, lig_ptr, atm_ptr, res_ptr):
         self.t = T
         self.sc_mask = scm
         self.atom14_mask = m14
         self.lig_ptr_host = lig_ptr.cpu()
-        self.res_ptr_host = T["res_ptr"].cpu().long()
-        dims = dict(G=G, NL=NL, NA=NA, NR=NR, EB=EB, NTOR=NTOR, NSC=NSC,
-                    max_nl=int((lig_ptr[1:] - lig_ptr[:-1]).max().item()),
-                    max_na=int((atm_ptr[1:] - atm_ptr[:-1]).max().item()),
+        self.res_ptr_host = res_ptr.cpu().long()
+        apc = atm_ptr.cpu()
+        dims = dict(G=self.G, NL=int(T["lig_pos"].shape[0]), NA=int(T["rec_pos"].shape[0]), NR=int(T["sequence"].shape[0]),
+                    EB=int(T["bond_src"].shape[0]), NTOR=int(self.tor_count(T)), NSC=int(scm.sum().item()),
+                    max_nl=int((self.lig_ptr_host[1:] - self.lig_ptr_host[:-1]).max().item()),
+                    max_na=int((apc[1:] - apc[:-1]).max().item()),
                     max_nr=int((self.res_ptr_host[1:] - self.res_ptr_host[:-1]).max().item()))
         self.dims = dims
         self.c = L.Batch()
@@ -125,6 +139,10 @@ class PackedBatch:
             setattr(self.c, k, v)
         for k in L._BATCH_PTRS:
             setattr(self.c, k, C.c_void_p(T[k].data_ptr()))
+
+    @staticmethod
+    def tor_count(T):
+        return int(T["tor_ptr"][-1].item())
 
     # convenience views on the evolving state
     @property

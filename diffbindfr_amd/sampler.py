@@ -104,6 +104,40 @@ class DiffBindFRHIP(nn.Module):
         return pb.lig_pos.unsqueeze(0), a14.unsqueeze(0)
 
     @torch.no_grad()
+    def sample_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0):
+        """Records in, poses out: the reference's `_prepare_test_sample` x num_poses + collate + `sample`
+        (inference_dataset.py:578-612, struct_init.py, scFlex.py:124-250) with everything per-pose on the device.
+        ``records``: list of ``assemble.ComplexRecord`` (or reference-format per-complex dicts); ``poses``: int or
+        per-complex list.  Both random tapes (initialisation, SDE noise) come from one torch device generator.
+        Returns list[G] of (lig [T,N_l,3], atom14 [T,N_r,14,3]) CPU tensors, complex-major."""
+        from . import assemble
+        dev = torch.device(device)
+        recs = [r if isinstance(r, assemble.ComplexRecord) else assemble.ComplexRecord(r) for r in records]
+        pb = assemble.assemble(recs, poses, dev)
+        gen = torch.Generator(device=dev)
+        if seed is not None:
+            gen.manual_seed(int(seed))
+        assemble.init_poses(self.diffusion_model, pb, assemble.draw_init_tape(pb, tr_sigma_max, gen))
+        steps, _ = self.schedule()
+        T, d = len(steps), pb.dims
+        z = {"tr": torch.randn(T, pb.G, 3, device=dev, generator=gen), "rot": torch.randn(T, pb.G, 3, device=dev, generator=gen),
+             "tor": torch.randn(T, max(d["NTOR"], 1), device=dev, generator=gen),
+             "sc": torch.randn(T, max(d["NSC"], 1), device=dev, generator=gen)}
+        for s, r in enumerate(steps):
+            if r.noise_free:
+                for v in z.values():
+                    v[s].zero_()
+        lig, a14 = self.sample_packed(pb, z, visualize=visualize)
+        return self._split(pb, lig.cpu(), a14.cpu())
+
+    def _split(self, pb, lig, a14):
+        lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
+        out = [(lig[:, lp[g]:lp[g + 1]].clone(), a14[:, rp[g]:rp[g + 1]].clone()) for g in range(pb.G)]
+        if cfg_get(self.diffusion_model_cfg if hasattr(self, "diffusion_model_cfg") else None, "no_sc_torsion", False):
+            return [o[0] for o in out]
+        return out
+
+    @torch.no_grad()
     def sample(self, data, visualize=False):
         """scFlex.py:124-250.  Returns list[G] of (lig [T,N_l,3], atom14 [T,N_r,14,3]) CPU tensors."""
         dev = TensorProductModelHIP._device_of(data)
@@ -112,11 +146,4 @@ class DiffBindFRHIP(nn.Module):
         z = draw_noise_tape(recs, pb.G, pb.dims["NTOR"], pb.dims["NSC"])
         z = {k: v.to(dev).contiguous() for k, v in z.items()}
         lig, a14 = self.sample_packed(pb, z, visualize=visualize)
-        lig, a14 = lig.cpu(), a14.cpu()
-        lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
-        out = []
-        for g in range(pb.G):
-            out.append((lig[:, lp[g]:lp[g + 1]].clone(), a14[:, rp[g]:rp[g + 1]].clone()))
-        if cfg_get(self.diffusion_model_cfg if hasattr(self, "diffusion_model_cfg") else None, "no_sc_torsion", False):
-            return [o[0] for o in out]
-        return out
+        return self._split(pb, lig.cpu(), a14.cpu())

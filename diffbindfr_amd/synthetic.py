@@ -120,7 +120,7 @@ def make_pocket(rng, n_atoms_target):
     return dict(sequence=seq, backbone_transl=transl.astype(np.float32), backbone_rots=rots.astype(np.float32),
                 default_frame=default_frame.astype(np.float32), rigid_group_positions=rigid_pos.astype(np.float32),
                 atom14_mask=mask14, sc_torsion_edge_mask=chi_mask, torsion_edge_index=tors.astype(np.int64),
-                pocket_node_feature=feat14[mask14], n_atoms=int(mask14.sum()))
+                pocket_node_feature=feat14[mask14], pocket_node_feature14=feat14, n_atoms=int(mask14.sum()))
 
 
 def _components_without(adj, n, u, v):
@@ -231,6 +231,33 @@ def init_pose(rng, pocket, lig, tr_sigma=10.0):
                           pocket["backbone_rots"].astype(np.float64), pocket["default_frame"].astype(np.float64),
                           pocket["rigid_group_positions"].astype(np.float64), tor, T["atom14_to_group"])
     return pos.astype(np.float32), tor.astype(np.float32), a14[pocket["atom14_mask"]].astype(np.float32)
+
+
+def make_record(pocket, lig, rng=None, drop_sidechains=0):
+    """One per-complex record with the reference's collected keys (diffbindfr_ts.py:49-55, before the
+    real-time transforms): torch tensors, pocket features still in atom14 layout, the ligand's
+    reference conformer, psi from the "input structure" (random here).  ``drop_sidechains`` removes
+    the side-chain atoms of that many residues so that SCFixer (struct_init.py:61-106) has work."""
+    rng = rng or np.random.default_rng(0)
+    N = pocket["sequence"].shape[0]
+    ta = np.zeros((N, 5), np.float32)
+    ta[:, 0] = rng.uniform(-np.pi, np.pi, size=N)
+    ta[:, 1:] = rng.uniform(-np.pi, np.pi, size=(N, 4)) * pocket["sc_torsion_edge_mask"]
+    m14 = pocket["atom14_mask"].copy()
+    scm = pocket["sc_torsion_edge_mask"].copy()
+    if drop_sidechains:
+        cand = np.nonzero(scm.any(1))[0]
+        for r in rng.choice(cand, size=min(drop_sidechains, len(cand)), replace=False):
+            m14[r, 5:] = False                     # keep N, CA, C, O, CB
+            scm[r] = False
+    t = torch.from_numpy
+    return dict(lig_pos=t(lig["lig_pos_ref"]).float(), lig_edge_index=t(lig["lig_edge_index"]), lig_node=t(lig["lig_node"]),
+                lig_edge_feat=t(lig["lig_edge_feat"]), tor_edge_mask=t(lig["tor_edge_mask"]).long(),
+                rot_node_mask=t(lig["rot_node_mask"]), atom14_mask=t(m14), sequence=t(pocket["sequence"]),
+                backbone_transl=t(pocket["backbone_transl"]), backbone_rots=t(pocket["backbone_rots"]),
+                default_frame=t(pocket["default_frame"]).clone(), rigid_group_positions=t(pocket["rigid_group_positions"]).clone(),
+                torsion_angle=t(ta), torsion_edge_index=t(pocket["torsion_edge_index"]),
+                sc_torsion_edge_mask=t(scm), pocket_node_feature=t(pocket["pocket_node_feature14"] * m14[..., None]))
 
 
 def collate(items):

@@ -180,6 +180,25 @@ int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int3
                 const dbfr_noise* noise, float* atom14_out, float* traj_lig, float* traj_atom14,
                 void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream);
 
+/* ---- pose initialisation, on the device.
+ * Replaces the per-pose real-time transforms LigInit + SCProtInit +
+ * Atom14ToAllAtomsRepr (druglib/datasets/Docking/struct_init.py:16-53,114-138;
+ * formatting.py:41-51) for every graph of an assembled batch at once:
+ *   lig_pos       <- torsion kicks in bond order, (x - centroid) R^T + tr
+ *   torsion_angle <- chi_k = sc_u * sc_torsion_edge_mask (psi kept)
+ *   rec_pos       <- side chains rebuilt from the templates, compacted
+ * The random draws come from the caller as a device tape in the reference's
+ * draw order per pose.  b->lig_pos must hold the ligands' input conformers.     */
+typedef struct {
+  const float* tor_u;  /* [NTOR]  U(-pi,pi) torsion kicks                       */
+  const float* rot;    /* [G,3,3] uniformly random rotation matrices, row-major  */
+  const float* tr;     /* [G,3]   N(0, tr_sigma_max) translations                */
+  const float* sc_u;   /* [NR,4]  U(-pi,pi) chi draws (unmasked)                 */
+} dbfr_init_tape;
+
+int dbfr_init_poses(const dbfr_model* m, const dbfr_batch* b, const dbfr_init_tape* tape, float* atom14_out,
+                    void* hip_stream);
+
 /* Synchronises the stream and returns the device-side status word of the last
  * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
  * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last
@@ -198,10 +217,12 @@ int dbfr_wigner3j(int32_t l1, int32_t l2, int32_t l3, double* out);
 int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* weight_numel);
 /* Profiling hooks: time (ms) spent in the dominant fused conv kernel and the
  * number of launches + edges since the last reset, measured with hip events on
- * the launch stream when profiling is enabled.                                    */
+ * the launch stream when profiling is enabled.  conv_flops = algorithmic FLOP
+ * (2K(K+W) per edge); ref_form_bytes = HBM bytes the reference's two-kernel form
+ * of the same launches would move (4(W+D_in+9)+16 per edge).        */
 int dbfr_profile_enable(dbfr_model* m, int32_t on);
 int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops,
-                      int32_t reset);
+                      double* ref_form_bytes, int32_t reset);
 
 /* Test hook: names (';'-separated) / byte offsets / sizes of the library's internal
  * buffers inside the workspace for this batch shape.  Returns the entry count.       */

@@ -20,12 +20,16 @@ algorithm, each function citing the reference ``file:line`` it follows
 * ``geometry``      -- ligand rigid+torsion update, Kabsch, side-chain rebuild.
 * ``schedule``      -- t/sigma/g schedule, so3 / torus score-norm tables.
 * ``sampler``       -- ``DiffBindFR.sample`` (scFlex.py:124-250).
+* ``pose_init``     -- SURVEY 8(f) row f1: LigInit / SCFixer / SCProtInit /
+                       Atom14ToAllAtomsRepr (struct_init.py, formatting.py) and
+                       the PLData collate (druglib/data/collate.py).
 
 Pinning status (see DESIGN.md "Oracle"):
 
 * Every function whose reference source imports in the build container
   (geometry, schedule, embeddings, LayerNorm, bipartite graph, the whole
-  ``tpscore.py`` / ``scFlex.py`` glue) is checked against the reference's own
+  ``tpscore.py`` / ``scFlex.py`` glue, the real-time pose transforms of
+  ``struct_init.py`` and the reference's own ``druglib.data`` collate) is checked against the reference's own
   source by ``tests/golden/make_golden.py`` (run in the build container only)
   and frozen as fixtures under ``tests/golden/``.
 * The e3nn / torch_cluster / torch_scatter arithmetic lives in un-vendored,

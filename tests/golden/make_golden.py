@@ -288,10 +288,104 @@ def golden_model_and_sampler():
     np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
 
 
+def golden_pose_init():
+    """f1: LigInit / SCFixer / SCProtInit / Atom14ToAllAtomsRepr of the reference's struct_init.py run on seeded
+    global generators; the oracle gets the same draws as an explicit tape."""
+    print("[pose init]")
+    from scipy.spatial.transform import Rotation
+    from oracle import pose_init as opi
+    dsb = types.ModuleType("druglib.datasets.builder")
+    dsb.PIPELINES = ns.builder.INTERACTION.__class__("pipeline")
+    sys.modules["druglib.datasets.builder"] = dsb
+    sys.modules["druglib.utils.geometry_utils"].radian2sincos_torch = ns.geom.radian2sincos_torch
+    sys.modules["druglib.utils"].get_logger = lambda name: __import__("logging").getLogger(name)
+    # the reference's real data package (Data / DataContainer / Batch / collate); torch_sparse & PyG stay stubs
+    class SparseTensor:
+        pass
+    sys.modules["torch_sparse"].SparseTensor = SparseTensor
+    sys.modules["torch_sparse"].cat = lambda *a, **k: None
+    for nm in ["torch_geometric.utils.num_nodes", "torch_geometric.utils.hetero", "torch_geometric.data",
+               "torch_geometric.data.storage", "torch_geometric.data.data"]:
+        sys.modules[nm] = ref_shims._Anything(nm)
+    sys.modules["druglib.utils"].color = types.SimpleNamespace()
+    for k in [k for k in sys.modules if k == "druglib.data" or k.startswith("druglib.data.")]:
+        del sys.modules[k]
+    D = __import__("importlib").import_module("druglib.data")
+    si = ref_shims._load("druglib.datasets.Docking.struct_init", "datasets/Docking/struct_init.py")
+    fm = ref_shims._load("druglib.datasets.Docking.formatting", "datasets/Docking/formatting.py")
+    rng = np.random.default_rng(4711)
+    cases = [("plain", synthetic.make_record(synthetic.make_pocket(rng, 60), synthetic.make_ligand(rng, 14), rng)),
+             ("fixer", synthetic.make_record(synthetic.make_pocket(rng, 80), synthetic.make_ligand(rng, 22), rng, drop_sidechains=3)),
+             ("rigid", synthetic.make_record(synthetic.make_pocket(rng, 40), synthetic.make_ligand(rng, 5), rng))]
+    cases[2][1]["tor_edge_mask"].zero_()
+    cases[2][1]["rot_node_mask"] = cases[2][1]["rot_node_mask"][:0]
+    out = {}
+    for name, rec in cases:
+        for seed in (3, 4):
+            d = copy.deepcopy({k: v for k, v in rec.items() if k != "rot_node_mask"})
+            d["metastore"] = dict(rot_node_mask=rec["rot_node_mask"].clone())
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            d = si.LigInit(tr_sigma_max=10)(d)
+            d = si.SCFixer()(d)
+            d = si.SCProtInit()(d)
+            d = fm.Atom14ToAllAtomsRepr()(d)
+            # the same draws, in the reference's order, as an explicit tape
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            n_tor, n_res = int(rec["tor_edge_mask"].sum()), rec["sequence"].shape[0]
+            tape = {}
+            if n_tor:
+                tape["tor"] = np.random.uniform(low=-np.pi, high=np.pi, size=n_tor)
+            tape["rot"] = Rotation.random().as_matrix()
+            tape["tr"] = torch.normal(mean=0, std=10., size=(1, 3))
+            tape["sc"] = np.random.uniform(low=-np.pi, high=np.pi, size=(n_res, 4))
+            fixed = opi.sc_fixer(copy.deepcopy(rec), T)
+            mine = opi.init_pose(fixed, tape, {k: torch.from_numpy(np.asarray(v)) if k == "atom14_to_group" else v for k, v in T.items()})
+            for k in ("lig_pos", "torsion_angle", "rec_atm_pos", "pocket_node_feature", "sc_torsion_edge_mask", "atom14_mask",
+                      "default_frame", "rigid_group_positions"):
+                close(mine[k].float(), d[k].float(), 0.0, f"{name}/s{seed}/{k}")
+            pre = f"{name}_s{seed}_"
+            out.update({pre + "tape_" + k: npy(v) for k, v in tape.items()})
+            out.update({pre + "out_" + k: npy(d[k]) for k in ("lig_pos", "torsion_angle", "rec_atm_pos", "pocket_node_feature",
+                                                                "sc_torsion_edge_mask", "atom14_mask", "default_frame",
+                                                                "rigid_group_positions")})
+        out.update({f"{name}_rec_{k}": npy(v) for k, v in rec.items()})
+    # ---- collate: 2 complexes x 2 poses through the reference's Batch.from_data_list (follow_batch as diffbindfr_ts.py:92-96)
+    Tt = {k: torch.from_numpy(np.asarray(v)) if k == "atom14_to_group" else v for k, v in T.items()}
+    poses = []
+    for name, rec in cases[:2]:
+        fixed = opi.sc_fixer(copy.deepcopy(rec), T)
+        for p in range(2):
+            n_tor = int(rec["tor_edge_mask"].sum())
+            tape = dict(tor=rng.uniform(-np.pi, np.pi, n_tor), rot=Rotation.random(random_state=7 + p).as_matrix(),
+                        tr=torch.from_numpy(rng.normal(0, 10, (1, 3))).float(), sc=rng.uniform(-np.pi, np.pi, (rec["sequence"].shape[0], 4)))
+            poses.append(opi.init_pose(fixed, tape, Tt))
+            out.update({f"collate_tape{len(poses) - 1}_{k}": npy(v) for k, v in tape.items()})
+    fields = ("lig_node", "lig_pos", "lig_edge_index", "lig_edge_feat", "tor_edge_mask", "pocket_node_feature", "rec_atm_pos",
+              "sc_torsion_edge_mask", "torsion_edge_index", "backbone_transl", "sequence", "atom14_mask", "backbone_rots",
+              "default_frame", "rigid_group_positions", "torsion_angle")
+    items = []
+    for p in poses:
+        d = {k: D.DataContainer(p[k], stack=False, is_graph=True) for k in fields}
+        d["metastore"] = dict(rot_node_mask=p["rot_node_mask"])
+        items.append(fm.ToPLData()(d))
+    ref = D.Batch.from_data_list(items, follow_batch=["lig_node", "rec_atm_pos"], exclude_keys=None).to_dict(decode=True, drop_meta=False)
+    mine = opi.collate(poses)
+    for k, v in ref.items():
+        if torch.is_tensor(v) and k not in ("batch", "ptr"):
+            assert v.dtype == mine[k].dtype and v.shape == mine[k].shape, k
+            close(mine[k].double(), v.double(), 0.0, f"collate/{k}")
+            out["collate_" + k] = npy(v)
+    assert all(bool((a == b).all()) for a, b in zip(ref["metastore"]["rot_node_mask"], mine["rot_node_mask"]))
+    np.savez_compressed(os.path.join(HERE, "pose_init.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_geometry()
     golden_embeddings()
     golden_schedule()
     golden_model_and_sampler()
+    golden_pose_init()
     print("golden fixtures written to", HERE)
