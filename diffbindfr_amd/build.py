@@ -17,7 +17,7 @@ SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "graph.hip", "heads.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # graph/heads: every fp op rounded separately (edge-in/out decisions and the SDE update mirror the oracle's
 # operation order); conv: contraction allowed (fewer VALU slots next to the MFMAs; results are tolerance-checked)
-FILE_FLAGS = {"conv.hip": ["-ffp-contract=fast"]}
+FILE_FLAGS = {"conv.hip": ["-ffp-contract=fast"] + ([f"-DCONV_NB={os.environ['DBFR_BUILD_NB']}"] if "DBFR_BUILD_NB" in os.environ else [])}
 DEFAULT_FP = ["-ffp-contract=off"]
 
 

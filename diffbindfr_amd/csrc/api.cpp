@@ -251,32 +251,48 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
     if (!improved) break;
   }
   std::vector<Row> rows;
-  std::vector<uint32_t> quads;
-  int wave_tile0[5] = {0, 0, 0, 0, 0};
+  std::vector<RunDesc> runs;
+  int wave_tile0[5] = {0, 0, 0, 0, 0}, wave_run0[5] = {0, 0, 0, 0, 0};
   for (int v = 0; v < 4; ++v) {
     std::sort(wave_groups[v].begin(), wave_groups[v].end());
     wave_tile0[v] = (int)rows.size() / 16;
+    wave_run0[v] = (int)runs.size();
     for (int gi : wave_groups[v]) {
       const Group& G = groups[gi];
       const Pair& lead = pairs[G.pair_idx[0]];
-      int tile_in_group = 0;
-      for (size_t pi = 0; pi < lead.paths.size(); ++pi)
-        for (int u0 = 0; u0 < lead.paths[pi]->mul1; u0 += 4, ++tile_in_group) {
-          uint32_t flags = (tile_in_group == 0 ? 1u : 0u) | (tile_in_group == G.tiles - 1 ? 2u : 0u);
+      for (size_t pi = 0; pi < lead.paths.size(); ++pi) {
+        const PathDesc* lp = lead.paths[pi];
+        RunDesc rd;
+        const uint32_t flags = (pi == 0 ? 1u : 0u) | (pi + 1 == lead.paths.size() ? 2u : 0u);
+        const uint32_t tile0 = (uint32_t)rows.size() / 16, nt = (uint32_t)lp->mul1 / 4, x_step = 4u * (2 * lp->l1 + 1);
+        if (tile0 >= (1u << 20) || nt >= (1u << 12)) return fail(DBFR_ERR_ARG, "conv too large for the run descriptor");
+        rd.tile0_n = tile0 | (nt << 20);
+        rd.meta = (uint32_t)lp->type | (flags << 4) | ((uint32_t)lp->sh_off << 8) | (x_step << 12);
+        rd.x_off4 = rd.o_off4 = 0;
+        for (int g = 0; g < 4; ++g) {
+          const int pidx = G.pair_idx[g];
+          const PathDesc* p = pidx >= 0 ? pairs[pidx].paths[pi] : lp;
+          if (p->type != lp->type || p->sh_off != lp->sh_off || p->mul1 != lp->mul1)
+            return fail(DBFR_ERR_ARG, "channel group with non-uniform paths in " + name);
+          const int d_o = 2 * p->lo + 1;
+          const uint32_t xo = p->in_off;
+          const uint32_t oo = pidx >= 0 ? p->out_off + pairs[pidx].w * d_o : (uint32_t)sp.D_out;  // dummy -> trash column
+          if (xo > 255 || oo > 255) return fail(DBFR_ERR_ARG, "irreps too wide for the run descriptor");
+          rd.x_off4 |= xo << (8 * g);
+          rd.o_off4 |= oo << (8 * g);
+        }
+        runs.push_back(rd);
+        for (int u0 = 0; u0 < lp->mul1; u0 += 4)
           for (int g = 0; g < 4; ++g) {
             const int pidx = G.pair_idx[g];
-            const PathDesc* p = pidx >= 0 ? pairs[pidx].paths[pi] : lead.paths[pi];
-            const int d1 = 2 * p->l1 + 1, d_o = 2 * p->lo + 1;
-            uint32_t xo = p->in_off + u0 * d1;
-            uint32_t oo = pidx >= 0 ? p->out_off + pairs[pidx].w * d_o : (uint32_t)sp.D_out;  // dummy -> trash column
-            if (xo > 255 || oo > 255) return fail(DBFR_ERR_ARG, "irreps too wide for the quad descriptor");
-            quads.push_back(xo | (oo << 8) | ((uint32_t)p->type << 16) | ((uint32_t)p->sh_off << 20) | (flags << 24));
+            const PathDesc* p = pidx >= 0 ? pairs[pidx].paths[pi] : lp;
             for (int r = 0; r < 4; ++r)
               rows.push_back(pidx >= 0 ? Row{p->w_off + (u0 + r) * p->mulo + pairs[pidx].w, p->fold} : Row{-1, 0.f});
           }
-        }
+      }
     }
   }
+  wave_run0[4] = (int)runs.size();
   wave_tile0[4] = (int)rows.size() / 16;
   const int n_tiles = (int)rows.size() / 16;
   std::vector<float> w2p((size_t)n_tiles * KT * 64 * 4), b2p((size_t)n_tiles * 16);
@@ -291,12 +307,12 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
       }
   }
   o->K = K; o->D_in = sp.D_in; o->D_out = sp.D_out; o->n_tiles = n_tiles; o->W = sp.W;
-  for (int v = 0; v < 5; ++v) o->wave_tile0[v] = wave_tile0[v];
+  for (int v = 0; v < 5; ++v) { o->wave_tile0[v] = wave_tile0[v]; o->wave_run0[v] = wave_run0[v]; }
   o->W1p = upload(m, w1p, &rc);
   o->b1 = upload(m, std::vector<float>(B1, B1 + K), &rc);
   o->W2p = upload(m, w2p, &rc);
   o->b2p = upload(m, b2p, &rc);
-  o->quads = upload(m, quads, &rc);
+  o->runs = upload(m, runs, &rc);
   LNDesc& ln = o->ln;
   memset(&ln, 0, sizeof ln);
   ln.nblk = (int)sp.out.size();

@@ -48,6 +48,16 @@ struct LNDesc {            // equivariant LayerNorm over the out irreps (tpscore
   const float* bias;         // [num 0e]
 };
 
+// A "run" = consecutive W2 row tiles of one wave that share the tensor-product path (same closed-form type, same
+// harmonics) and walk the input multiplicity u in steps of 4: the kernel dispatches on the path type once per run and
+// loads the edge harmonics once per run.  Uniform per run => fetched with scalar loads.
+struct RunDesc {
+  uint32_t tile0_n;   // first tile | n_tiles << 20
+  uint32_t meta;      // type | flags << 4 (bit0: first run of its channel group, bit1: last) | sh_off << 8 | x_step << 12
+  uint32_t x_off4;    // byte g: x_off (floats) of lane group g at the run's first tile
+  uint32_t o_off4;    // byte g: message column owned by lane group g
+};
+
 struct ConvW {             // one TensorProductConvLayer, device resident
   int K, D_in, D_out, n_tiles, W;
   int wave_tile0[5];  // tiles [wave_tile0[v], wave_tile0[v+1]) belong to wave v of the workgroup
@@ -55,7 +65,8 @@ struct ConvW {             // one TensorProductConvLayer, device resident
   const float* b1;    // [K]
   const float* W2p;   // [n_tiles][K/16][64][4] lin.3 weight rows permuted (path, w, u), path norm folded
   const float* b2p;   // [n_tiles*16]
-  const uint32_t* quads;  // [n_tiles*4]  x_off | out_off<<8 | type<<16 | sh_off<<20
+  const RunDesc* runs;    // runs of all four waves, wave-major
+  int wave_run0[5];       // runs [wave_run0[v], wave_run0[v+1]) belong to wave v
   LNDesc ln;
 };
 
@@ -96,6 +107,8 @@ struct ConvArgs {
   const float* x; int ldx;      // tensor-product input rows, gathered by gth
   ConvW w;
   float* msg;                   // [E][D_out]
+  int skew_blocks;              // workgroups of the first residency round (see conv.hip: phase skew), 0 = off
+  unsigned long long* trace;    // developer timeline (DBFR_CONV_TRACE): [block][wave][1 + 3*TRACE_TILES] or null
 };
 
 #define HIPCHECK(expr)                                                                         \

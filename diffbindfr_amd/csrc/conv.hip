@@ -25,7 +25,10 @@
 //            closed-form CG of the path, keeps the running message element in registers and stores it to the
 //            LDS message tile exactly once -- no atomics, fixed summation order (bit-reproducible)
 //   phase E  coalesced store of the [TE, D_out] message tile
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -33,52 +36,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#define TRACE_BLOCKS 1024
+#define TRACE_TILES 48
 #ifndef SKEW
 #define SKEW 59   // s_sleep units of 64 cycles: ~half of a (shared-pipe MFMA phase + epilogue) period
 #endif
 
-// closed-form Clebsch-Gordan contraction of one 4-row quad (must mirror so3_host.cpp: closed_form)
-__device__ __forceinline__ void quad_contract(int type, const f32x4 v, const float* __restrict__ xr,
-                                              const float* __restrict__ sp, float& p0, float& p1, float& p2) {
-  p0 = 0.f; p1 = 0.f; p2 = 0.f;
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(xr);   // x_off and the row stride are multiples of 4 floats
-  const f32x4 xa = x4[0];
-  if (type == PT_SS || type == PT_SV) {
-    const float z = v[0] * xa[0] + v[1] * xa[1] + v[2] * xa[2] + v[3] * xa[3];
-    if (type == PT_SS) {
-      p0 = z * sp[0];
-    } else {
-      p0 = z * sp[0]; p1 = z * sp[1]; p2 = z * sp[2];
-    }
-  } else {
-    const f32x4 xb = x4[1], xc = x4[2];   // [u0..u0+3][3] = 12 consecutive floats
-    const float z0 = v[0] * xa[0] + v[1] * xa[3] + v[2] * xb[2] + v[3] * xc[1];
-    const float z1 = v[0] * xa[1] + v[1] * xb[0] + v[2] * xb[3] + v[3] * xc[2];
-    const float z2 = v[0] * xa[2] + v[1] * xb[1] + v[2] * xc[0] + v[3] * xc[3];
-    if (type == PT_VS) {
-      const float s0 = sp[0];
-      p0 = z0 * s0; p1 = z1 * s0; p2 = z2 * s0;
-    } else if (type == PT_VVS) {
-      p0 = z0 * sp[0] + z1 * sp[1] + z2 * sp[2];
-    } else if (type == PT_VVV) {
-      const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
-      p0 = z1 * s2 - z2 * s1; p1 = z2 * s0 - z0 * s2; p2 = z0 * s1 - z1 * s0;
-    } else {  // PT_VTV
-      const float r3 = 1.7320508075688772f;
-      const float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-      const float m00 = -s2 - r3 * s4, m01 = r3 * s1, m02 = r3 * s0, m11 = 2.f * s2, m12 = r3 * s3,
-                  m22 = -s2 + r3 * s4;
-      p0 = m00 * z0 + m01 * z1 + m02 * z2;
-      p1 = m01 * z0 + m11 * z1 + m12 * z2;
-      p2 = m02 * z0 + m12 * z1 + m22 * z2;
-    }
-  }
-}
-
 // K: radial-MLP width (144 / 96); NB: 16-edge blocks per workgroup (TE = 16 NB edges share every A fragment
 // fetched from L2 -- the L2->CU fabric, not HBM, is what the weight stream loads); ABL: developer ablations.
 template <int K, int NB, int ABL, int NH>
-__global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
+__global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
   constexpr int TE = 16 * NB;
   constexpr int KT = K / 16;  // 16-wide tiles along the MLP input/hidden dim
   constexpr int KS = K / 4;   // MFMA k-steps
@@ -233,74 +200,162 @@ __global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
   if (NH == 2 && half) {        // start half 1 ~half an MFMA phase behind its SIMD partner (see the kernel header)
     __builtin_amdgcn_s_sleep(SKEW);
   }
-  // ---------------- phase D: W2 row tiles of this wave (channel-owner order, see api.cpp pack_conv)
-  const f32x4* W2 = reinterpret_cast<const f32x4*>(a.w.W2p);
-  const int t_begin = a.w.wave_tile0[wave], t_end = a.w.wave_tile0[wave + 1];
-  // A fragments of the current tile live in A[]; each register is re-loaded with the NEXT tile's fragment
-  // right after its last MFMA, so a whole tile of matrix work hides the L2 latency with one register set.
-  // The quad descriptor + bias are prefetched one tile ahead the same way (vector loads retire in order:
-  // every wait then refers to a load issued a whole tile of matrix work earlier).
-  f32x4 A[KT];
-  uint32_t qd_n = 0;
-  f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
-  if (t_begin < t_end) {
-    const f32x4* Ap0 = W2 + (size_t)t_begin * KT * 64 + lane;
+  // Phase skew (NH == 1).  The two workgroups resident on a CU start together, take the same time and so stay in
+  // lock step for the whole launch: the two waves that share a SIMD's matrix pipe hit their epilogues at the same
+  // moment, every tile, and the pipe idles.  The workgroup whose waves sit in the odd hardware wave slot is delayed
+  // ONCE, in the first residency round, by half a (two-wave MFMA phase + epilogue) period; its successors inherit the
+  // offset because each starts when its predecessor ends.  (blockIdx parity cannot be used: co-resident first-round
+  // workgroups always have equal parity -- measured, tools/exp/hwid.hip.)
+  if (NH == 1 && (int)blockIdx.x < a.skew_blocks) {
+    const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1;   // HW_ID.WAVE_ID bit 0
+    if (slot) __builtin_amdgcn_s_sleep(SKEW);
+  }
+  // ---------------- phase D: the W2 row tiles of this wave, run by run (channel-owner order, see api.cpp pack_conv).
+  // Measured on MI355X (tools/exp/mfma_shadow.hip): a dense v_mfma_f32_16x16x4_f32 stream leaves room for only ~2.5
+  // vector instructions of the OTHER wave on the SIMD per MFMA and for none of its own, so everything that is not an
+  // MFMA is kept off the vector pipe: A fragments and biases come through buffer loads with scalar offsets (no address
+  // VALU), the bias is the accumulator's initial value, the path type is dispatched once per run (tiles of a run
+  // differ only in the u-quad), the harmonics are read once per run, and the contraction itself is 5..21 FMAs per
+  // 16-edge block.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int r_begin = a.w.wave_run0[wv], r_end = a.w.wave_run0[wv + 1];
+  const int t_last = a.w.wave_tile0[wv + 1] - 1;
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w.W2p, 0, a.w.n_tiles * KT * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w.b2p, 0, a.w.n_tiles * 64, 0x00020000);
+  const int vW = lane * 16, vB = g * 16;
+  // A fragments of the current tile live in A[]; each register is re-loaded with the NEXT tile's fragment right after
+  // its last MFMA, so a whole tile of matrix work hides the L2 latency with one register set.  Same for the bias.
+  f32x4 A[KT], bias_n = {0.f, 0.f, 0.f, 0.f};
+  if (r_begin < r_end) {
+    const int t0 = a.w.wave_tile0[wv];
 #pragma unroll
-    for (int s4 = 0; s4 < KT; ++s4) A[s4] = Ap0[s4 * 64];
-    qd_n = a.w.quads[t_begin * 4 + g];
-    bias_n = reinterpret_cast<const f32x4*>(a.w.b2p)[t_begin * 4 + g];
+    for (int s4 = 0; s4 < KT; ++s4)
+      A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, (t0 * KT + s4) * 1024, 0));
+    bias_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB, t0 * 64, 0));
   }
   float oacc[NB][3];   // running message element(s) of this lane's channel, per edge block
 #pragma unroll
   for (int b = 0; b < NB; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
-  for (int t = t_begin; t < ((ABL & 8) ? t_begin : t_end); ++t) {
-    const bool has_next = t + 1 < t_end;
-    const int tn = has_next ? t + 1 : t;
-    const f32x4* Apn = W2 + (size_t)tn * KT * 64 + lane;
-    const uint32_t qd = qd_n;
-    const f32x4 bias = bias_n;
-    qd_n = a.w.quads[tn * 4 + g];
-    bias_n = reinterpret_cast<const f32x4*>(a.w.b2p)[tn * 4 + g];
-    f32x4 acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s4 = 0; s4 < KT; ++s4) {
-      const f32x4 av = A[s4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bv[b][4 * s4 + q], acc[b], 0, 0, 0);
-      if (!(ABL & 2) && !((ABL & 4) && (t & 1))) A[s4] = Apn[s4 * 64];
-    }
-    if (ABL & 1) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(acc[b]));
-      continue;
-    }
-    const int x_off = qd & 0xff, o_off = (qd >> 8) & 0xff, sh_off = (qd >> 20) & 0xf;
-    const int type = __builtin_amdgcn_readfirstlane((qd >> 16) & 0xf);   // uniform per tile
-    const int flags = __builtin_amdgcn_readfirstlane(qd >> 24);          // bit0 first / bit1 last tile of the group
+  unsigned long long* trc = nullptr;
+  int trc_n = 0;
+  if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS) {
+    trc = a.trace + ((size_t)blockIdx.x * 4 + wave) * (2 + 3 * TRACE_TILES);
+    if (lane == 0) { trc[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); trc[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20); }
+  }
+  const float* xs_lane = xs + n * XS_LD;      // + 16 b XS_LD per edge block (immediate offsets)
+  const float* sh_lane = shs + n * 10;
+  for (int r = ((ABL & 8) ? r_end : r_begin); r < r_end; ++r) {
+    const RunDesc rd = a.w.runs[r];
+    const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
+    const int type = rd.meta & 15, flags = (rd.meta >> 4) & 3, sh_off = (rd.meta >> 8) & 15, x_step = rd.meta >> 12;
+    const int xo = (rd.x_off4 >> (8 * g)) & 0xff, oo = (rd.o_off4 >> (8 * g)) & 0xff;
     if (flags & 1) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
     }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int e = 16 * b + n;
-      float p0, p1, p2;
-      quad_contract(type, acc[b] + bias, xs + e * XS_LD + x_off, shs + e * 10 + sh_off, p0, p1, p2);
-      oacc[b][0] += p0; oacc[b][1] += p1; oacc[b][2] += p2;
-    }
-    if (flags & 2) {   // last tile of the group: this lane owns out[(e), o_off .. o_off+k)
-      const bool vec = !(type == PT_SS || type == PT_VVS);   // output irrep l=1 (3 components) or l=0
+    auto run = [&](auto type_c) {
+      constexpr int TYPE = decltype(type_c)::value;
+      constexpr bool VIN = !(TYPE == PT_SS || TYPE == PT_SV);      // input irrep l=1: 12 consecutive floats per quad
+      constexpr bool VOUT = !(TYPE == PT_SS || TYPE == PT_VVS);    // output irrep l=1
+      constexpr int NSV = (TYPE == PT_SS || TYPE == PT_VS) ? 1 : (TYPE == PT_VTV ? 6 : 3);
+      float S[NB][NSV];      // what the contraction needs of the edge's harmonics, constant over the run
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        float* op = un + (16 * b + n) * O_LD + o_off;
-        op[0] = oacc[b][0];
-        if (vec) { op[1] = oacc[b][1]; op[2] = oacc[b][2]; }
+        const float* sp = sh_lane + 160 * b + sh_off;
+        if (TYPE == PT_VTV) {
+          const float r3 = 1.7320508075688772f;
+          const float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+          S[b][0] = -s2 - r3 * s4; S[b][1] = r3 * s1; S[b][2] = r3 * s0; S[b][3] = 2.f * s2; S[b][4] = r3 * s3;
+          S[b][NSV - 1] = -s2 + r3 * s4;
+        } else {
+#pragma unroll
+          for (int k = 0; k < NSV; ++k) S[b][k] = sp[k];
+        }
       }
+      const float* xp = xs_lane + xo;
+      for (int i = 0; i < nt; ++i, xp += x_step) {
+        const int t = tile0 + i;
+        const int tn = t < t_last ? t + 1 : t;
+        if ((ABL & 16) && trc && trc_n < TRACE_TILES && lane == 0) trc[2 + 3 * trc_n] = __builtin_readcyclecounter();
+        f32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = bias_n;
+        bias_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB, tn * 64, 0));
+#pragma unroll
+        for (int s4 = 0; s4 < KT; ++s4) {
+          const f32x4 av = A[s4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+              acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bv[b][4 * s4 + q], acc[b], 0, 0, 0);
+          A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, (tn * KT + s4) * 1024, 0));
+        }
+        if ((ABL & 16) && trc && trc_n < TRACE_TILES) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(acc[b]));
+          if (lane == 0) trc[3 + 3 * trc_n] = __builtin_readcyclecounter();
+        }
+        if (ABL & 1) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(acc[b]));
+          continue;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const f32x4 v = acc[b];
+          const f32x4* x4 = reinterpret_cast<const f32x4*>(xp + 16 * b * XS_LD);
+          const f32x4 xa = x4[0];
+          if (!VIN) {
+            const float z = v[0] * xa[0] + v[1] * xa[1] + v[2] * xa[2] + v[3] * xa[3];
+            oacc[b][0] += z * S[b][0];
+            if (TYPE == PT_SV) { oacc[b][1] += z * S[b][1]; oacc[b][2] += z * S[b][2]; }
+          } else {
+            const f32x4 xb = x4[1], xc = x4[2];   // [u0..u0+3][3] = 12 consecutive floats
+            const float z0 = v[0] * xa[0] + v[1] * xa[3] + v[2] * xb[2] + v[3] * xc[1];
+            const float z1 = v[0] * xa[1] + v[1] * xb[0] + v[2] * xb[3] + v[3] * xc[2];
+            const float z2 = v[0] * xa[2] + v[1] * xb[1] + v[2] * xc[0] + v[3] * xc[3];
+            if (TYPE == PT_VS) {
+              oacc[b][0] += z0 * S[b][0]; oacc[b][1] += z1 * S[b][0]; oacc[b][2] += z2 * S[b][0];
+            } else if (TYPE == PT_VVS) {
+              oacc[b][0] += z0 * S[b][0] + z1 * S[b][1] + z2 * S[b][2];
+            } else if (TYPE == PT_VVV) {
+              oacc[b][0] += z1 * S[b][2] - z2 * S[b][1];
+              oacc[b][1] += z2 * S[b][0] - z0 * S[b][2];
+              oacc[b][2] += z0 * S[b][1] - z1 * S[b][0];
+            } else {   // PT_VTV: symmetric traceless matrix of the l=2 harmonics (m00 m01 m02 m11 m12 m22)
+              oacc[b][0] += S[b][0] * z0 + S[b][1] * z1 + S[b][2] * z2;
+              oacc[b][1] += S[b][1] * z0 + S[b][3] * z1 + S[b][4] * z2;
+              oacc[b][2] += S[b][2] * z0 + S[b][4] * z1 + S[b][NSV - 1] * z2;
+            }
+            // one edge block at a time: the 12 x registers of the next block are not requested before this block's
+            // FMAs are done (register budget 256 at 2 waves/SIMD; the other wave's MFMAs cover the LDS latency)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if ((ABL & 16) && trc && trc_n < TRACE_TILES) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(oacc[b][0]));
+          if (lane == 0) trc[4 + 3 * trc_n] = __builtin_readcyclecounter();
+          ++trc_n;
+        }
+      }
+      if (flags & 2) {   // last run of the channel group: this lane owns out[e][oo .. oo + (VOUT ? 3 : 1))
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float* op = un + (16 * b + n) * O_LD + oo;
+          op[0] = oacc[b][0];
+          if (VOUT) { op[1] = oacc[b][1]; op[2] = oacc[b][2]; }
+        }
+      }
+    };
+    switch (type) {
+      case PT_SS: run(std::integral_constant<int, PT_SS>{}); break;
+      case PT_SV: run(std::integral_constant<int, PT_SV>{}); break;
+      case PT_VS: run(std::integral_constant<int, PT_VS>{}); break;
+      case PT_VVS: run(std::integral_constant<int, PT_VVS>{}); break;
+      case PT_VVV: run(std::integral_constant<int, PT_VVV>{}); break;
+      default: run(std::integral_constant<int, PT_VTV>{}); break;
     }
   }
   __syncthreads();
@@ -315,7 +370,9 @@ __global__ __launch_bounds__(256 * NH, 2) void k_conv(ConvArgs a) {
   }
 }
 
+#ifndef CONV_NB
 #define CONV_NB 3
+#endif
 #define CONV_NH 1   // 2 = two skewed halves per 512-thread workgroup (hides the epilogue but exposes the prologue: slower)
 
 
@@ -323,13 +380,41 @@ void launch_conv(const ConvArgs& a, hipStream_t st) {
   static int nh = -1, abl = -1;   // developer knobs: DBFR_CONV_NH (1 | 2 halves per workgroup), DBFR_CONV_ABL (ablations)
   if (nh < 0) { const char* e = getenv("DBFR_CONV_NH"); nh = e ? atoi(e) : CONV_NH; }
   if (abl < 0) { const char* e = getenv("DBFR_CONV_ABL"); abl = e ? atoi(e) : 0; }
+  static int skew = -1;
+  if (skew < 0) { const char* e = getenv("DBFR_CONV_SKEW"); skew = e ? atoi(e) : 1; }
   const int te = 16 * CONV_NB;
   const int tiles = (a.max_edges + te - 1) / te;
   if (tiles <= 0) return;
-#define LAUNCH(KK, AB, NHH) hipLaunchKernelGGL((k_conv<KK, CONV_NB, AB, NHH>), dim3((tiles + NHH - 1) / NHH), dim3(256 * NHH), 0, st, a)
-  if (a.w.K != 144) { if (nh == 2) LAUNCH(96, 0, 2); else LAUNCH(96, 0, 1); return; }
-  if (nh == 2) { switch (abl) { case 1: LAUNCH(144, 1, 2); break; case 8: LAUNCH(144, 8, 2); break; default: LAUNCH(144, 0, 2); } }
-  else { switch (abl) { case 1: LAUNCH(144, 1, 1); break; case 8: LAUNCH(144, 8, 1); break; default: LAUNCH(144, 0, 1); } }
+  ConvArgs b = a;
+  b.skew_blocks = skew ? 512 : 0;     // 256 CUs x 2 resident workgroups
+  b.trace = nullptr;
+  static const char* trace_path = getenv("DBFR_CONV_TRACE");   // developer: dump a per-tile timeline of one big launch
+  if (trace_path && a.w.K == 144 && a.w.W == 7776 && tiles >= 4096) {
+    const size_t nw = (size_t)TRACE_BLOCKS * 4 * (2 + 3 * TRACE_TILES);
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, nw * 8) == hipSuccess) {
+      (void)hipMemsetAsync(d, 0, nw * 8, st);
+      b.trace = d;
+      hipLaunchKernelGGL((k_conv<144, CONV_NB, 16, 1>), dim3(tiles), dim3(256), 0, st, b);
+      (void)hipStreamSynchronize(st);
+      std::vector<unsigned long long> h(nw);
+      (void)hipMemcpy(h.data(), d, nw * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(d);
+      if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, nw, f); fclose(f); }
+      trace_path = nullptr;
+      return;
+    }
+  }
+#define LAUNCH(KK, AB, NHH) hipLaunchKernelGGL((k_conv<KK, CONV_NB, AB, NHH>), dim3((tiles + NHH - 1) / NHH), dim3(256 * NHH), 0, st, b)
+#if CONV_NB <= 3
+  if (nh == 2) {
+    if (a.w.K != 144) { LAUNCH(96, 0, 2); return; }
+    switch (abl) { case 1: LAUNCH(144, 1, 2); break; case 8: LAUNCH(144, 8, 2); break; default: LAUNCH(144, 0, 2); }
+    return;
+  }
+#endif
+  if (a.w.K != 144) { LAUNCH(96, 0, 1); return; }
+  switch (abl) { case 1: LAUNCH(144, 1, 1); break; case 8: LAUNCH(144, 8, 1); break; default: LAUNCH(144, 0, 1); }
 #undef LAUNCH
 }
 
