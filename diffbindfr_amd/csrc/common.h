@@ -107,7 +107,6 @@ struct ConvArgs {
   const float* x; int ldx;      // tensor-product input rows, gathered by gth
   ConvW w;
   float* msg;                   // [E][D_out]
-  int skew_blocks;              // workgroups of the first residency round (see conv.hip: phase skew), 0 = off
   unsigned long long* trace;    // developer timeline (DBFR_CONV_TRACE): [block][wave][1 + 3*TRACE_TILES] or null
 };
 

@@ -38,45 +38,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TRACE_BLOCKS 1024
 #define TRACE_TILES 48
-#ifndef SKEW
-#define SKEW 59   // s_sleep units of 64 cycles: ~half of a (shared-pipe MFMA phase + epilogue) period
-#endif
+#define TRACE_REC (2 + 3 * TRACE_TILES + 6)
+#define TSTAMP(k) do { if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * TRACE_REC + 2 + 3 * TRACE_TILES + (k)] = __builtin_readcyclecounter(); } while (0)
 
 // K: radial-MLP width (144 / 96); NB: 16-edge blocks per workgroup (TE = 16 NB edges share every A fragment
 // fetched from L2 -- the L2->CU fabric, not HBM, is what the weight stream loads); ABL: developer ablations.
-template <int K, int NB, int ABL, int NH>
-__global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
+template <int K, int NB, int ABL>
+__global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
   constexpr int TE = 16 * NB;
   constexpr int KT = K / 16;  // 16-wide tiles along the MLP input/hidden dim
   constexpr int KS = K / 4;   // MFMA k-steps
   constexpr int A_LD = K + 1;
   constexpr int H_LD = TE + 1;
   constexpr int UN = (TE * (MAXD + 8) > K * H_LD) ? TE * (MAXD + 8) : K * H_LD;
-  // Two independent 4-wave halves per workgroup (512 threads): half h works on edge tile 2*blockIdx+h.  A 512-thread
-  // workgroup puts waves w and w+4 on the same SIMD, i.e. the two waves that share a matrix pipe are the SAME wave
-  // slot of the two halves and walk the SAME W2 tile range.  Half 1 is started half an MFMA phase late, so that
-  //  (1) its epilogues fall into the other wave's MFMA phase instead of colliding with its epilogues every tile
-  //      (two co-resident 4-wave workgroups start and finish together and stay in phase for their whole life), and
-  //  (2) its W2 fragment loads find the lines its partner fetched a moment earlier still in the CU's L1.
-  __shared__ __attribute__((aligned(16))) float xs_all[NH * TE * XS_LD];
-  __shared__ __attribute__((aligned(16))) float un_all[NH * UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][D_out+5]
-  __shared__ float shs_all[NH * TE * 10];
-  __shared__ int s_idx[NH * 3 * TE];
+  __shared__ __attribute__((aligned(16))) float xs[TE * XS_LD];
+  __shared__ __attribute__((aligned(16))) float un[UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][O_LD]
+  __shared__ float shs[TE * 10];
+  __shared__ int s_idx[3 * TE];
+  __shared__ __attribute__((aligned(16))) float ms[TE * 8];   // per edge: the symmetric traceless l=2 matrix (m00 m01 m02 m11 m12 m22) of PT_VTV
 
   const int E = min(*a.n_edges, a.max_edges);
-  if (blockIdx.x * NH * TE >= E) return;
-  const int half = threadIdx.x >> 8;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  const bool active = (blockIdx.x * NH + half) * TE < E;     // an inactive half shadows half 0 and stores nothing
-  const int tile0 = (blockIdx.x * NH + (active ? half : 0)) * TE;
+  if (blockIdx.x * TE >= E) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile0 = blockIdx.x * TE;
   const int ne = min(TE, E - tile0);
-  float* xs = xs_all + half * TE * XS_LD;
-  float* un = un_all + half * UN;
-  float* shs = shs_all + half * TE * 10;
-  int* s_gth = s_idx + half * 3 * TE;
+  int* s_gth = s_idx;
   int* s_i1 = s_gth + TE;
   int* s_i2 = s_i1 + TE;
   const int n = lane & 15, g = lane >> 4;
+  TSTAMP(0);
   const int D_in = a.w.D_in, D_out = a.w.D_out;
   const int O_LD = ((D_out + 3) & ~3) + 4;   // 16-B aligned rows (phase E moves float4s) + trash columns for padded channels
 
@@ -142,6 +132,14 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
     }
   }
   __syncthreads();
+  TSTAMP(1);
+  if (tid < TE) {   // closed form of the 1 x 2 -> 1 coupling (must mirror so3_host.cpp: closed_form)
+    const float r3 = 1.7320508075688772f;
+    const float* sp = shs + tid * 10 + 4;
+    const float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+    float* m = ms + tid * 8;
+    m[0] = -s2 - r3 * s4; m[1] = r3 * s1; m[2] = r3 * s0; m[3] = 2.f * s2; m[4] = r3 * s3; m[5] = -s2 + r3 * s4;
+  }
   // ---------------- phase B: hidden layer on the matrix cores.  A job = one 16-row tile of W1 against all NB edge
   // blocks (each W1 fragment feeds NB MFMAs, NB independent accumulator chains); the next job's fragments are
   // requested before the current job's MFMAs.
@@ -197,19 +195,7 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) Bv[b][s] = un[(4 * s + g) * H_LD + 16 * b + n];
   __syncthreads();   // hs is dead: the region becomes the message tile (every element is stored exactly once)
-  if (NH == 2 && half) {        // start half 1 ~half an MFMA phase behind its SIMD partner (see the kernel header)
-    __builtin_amdgcn_s_sleep(SKEW);
-  }
-  // Phase skew (NH == 1).  The two workgroups resident on a CU start together, take the same time and so stay in
-  // lock step for the whole launch: the two waves that share a SIMD's matrix pipe hit their epilogues at the same
-  // moment, every tile, and the pipe idles.  The workgroup whose waves sit in the odd hardware wave slot is delayed
-  // ONCE, in the first residency round, by half a (two-wave MFMA phase + epilogue) period; its successors inherit the
-  // offset because each starts when its predecessor ends.  (blockIdx parity cannot be used: co-resident first-round
-  // workgroups always have equal parity -- measured, tools/exp/hwid.hip.)
-  if (NH == 1 && (int)blockIdx.x < a.skew_blocks) {
-    const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1;   // HW_ID.WAVE_ID bit 0
-    if (slot) __builtin_amdgcn_s_sleep(SKEW);
-  }
+  TSTAMP(2);
   // ---------------- phase D: the W2 row tiles of this wave, run by run (channel-owner order, see api.cpp pack_conv).
   // Measured on MI355X (tools/exp/mfma_shadow.hip): a dense v_mfma_f32_16x16x4_f32 stream leaves room for only ~2.5
   // vector instructions of the OTHER wave on the SIMD per MFMA and for none of its own, so everything that is not an
@@ -239,7 +225,7 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
   unsigned long long* trc = nullptr;
   int trc_n = 0;
   if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS) {
-    trc = a.trace + ((size_t)blockIdx.x * 4 + wave) * (2 + 3 * TRACE_TILES);
+    trc = a.trace + ((size_t)blockIdx.x * 4 + wave) * TRACE_REC;
     if (lane == 0) { trc[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); trc[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20); }
   }
   const float* xs_lane = xs + n * XS_LD;      // + 16 b XS_LD per edge block (immediate offsets)
@@ -257,17 +243,12 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
       constexpr int TYPE = decltype(type_c)::value;
       constexpr bool VIN = !(TYPE == PT_SS || TYPE == PT_SV);      // input irrep l=1: 12 consecutive floats per quad
       constexpr bool VOUT = !(TYPE == PT_SS || TYPE == PT_VVS);    // output irrep l=1
-      constexpr int NSV = (TYPE == PT_SS || TYPE == PT_VS) ? 1 : (TYPE == PT_VTV ? 6 : 3);
-      float S[NB][NSV];      // what the contraction needs of the edge's harmonics, constant over the run
+      constexpr int NSV = (TYPE == PT_SS || TYPE == PT_VS) ? 1 : (TYPE == PT_VTV ? 0 : 3);
+      float S[NB][NSV ? NSV : 1];      // what the contraction needs of the edge's harmonics, constant over the run
+      if (TYPE != PT_VTV) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float* sp = sh_lane + 160 * b + sh_off;
-        if (TYPE == PT_VTV) {
-          const float r3 = 1.7320508075688772f;
-          const float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-          S[b][0] = -s2 - r3 * s4; S[b][1] = r3 * s1; S[b][2] = r3 * s0; S[b][3] = 2.f * s2; S[b][4] = r3 * s3;
-          S[b][NSV - 1] = -s2 + r3 * s4;
-        } else {
+        for (int b = 0; b < NB; ++b) {
+          const float* sp = sh_lane + 160 * b + sh_off;
 #pragma unroll
           for (int k = 0; k < NSV; ++k) S[b][k] = sp[k];
         }
@@ -289,7 +270,10 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
 #pragma unroll
             for (int b = 0; b < NB; ++b)
               acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bv[b][4 * s4 + q], acc[b], 0, 0, 0);
-          A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, (tn * KT + s4) * 1024, 0));
+          // pin the re-load BEHIND the last MFMA that reads this register: hoisted to the top of the tile (what the
+          // scheduler does on its own) it needs a second 36-register set and the kernel spills
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(ABL & 2)) A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, (tn * KT + s4) * 1024, 0));
         }
         if ((ABL & 16) && trc && trc_n < TRACE_TILES) {
 #pragma unroll
@@ -323,10 +307,12 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
               oacc[b][0] += z1 * S[b][2] - z2 * S[b][1];
               oacc[b][1] += z2 * S[b][0] - z0 * S[b][2];
               oacc[b][2] += z0 * S[b][1] - z1 * S[b][0];
-            } else {   // PT_VTV: symmetric traceless matrix of the l=2 harmonics (m00 m01 m02 m11 m12 m22)
-              oacc[b][0] += S[b][0] * z0 + S[b][1] * z1 + S[b][2] * z2;
-              oacc[b][1] += S[b][1] * z0 + S[b][3] * z1 + S[b][4] * z2;
-              oacc[b][2] += S[b][2] * z0 + S[b][4] * z1 + S[b][NSV - 1] * z2;
+            } else {   // PT_VTV: symmetric traceless matrix of the l=2 harmonics, read per tile (register budget)
+              const f32x4 ma = *reinterpret_cast<const f32x4*>(ms + (16 * b + n) * 8);
+              const float2 mb = *reinterpret_cast<const float2*>(ms + (16 * b + n) * 8 + 4);
+              oacc[b][0] += ma[0] * z0 + ma[1] * z1 + ma[2] * z2;
+              oacc[b][1] += ma[1] * z0 + ma[3] * z1 + mb.x * z2;
+              oacc[b][2] += ma[2] * z0 + mb.x * z1 + mb.y * z2;
             }
             // one edge block at a time: the 12 x registers of the next block are not requested before this block's
             // FMAs are done (register budget 256 at 2 waves/SIMD; the other wave's MFMAs cover the LDS latency)
@@ -358,9 +344,11 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
       default: run(std::integral_constant<int, PT_VTV>{}); break;
     }
   }
+  TSTAMP(3);
   __syncthreads();
+  TSTAMP(4);
   // ---------------- phase E
-  if (active) {
+  {
     const int d4 = D_out >> 2;             // D_out is a multiple of 4 for every conv (84, 120, 168, 12, 96)
     for (int i = tid; i < ne * d4; i += 256) {
       const int e = i / d4, c4 = i - e * d4;
@@ -368,34 +356,29 @@ __global__ __launch_bounds__(256 * NH, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a)
           *reinterpret_cast<const f32x4*>(un + e * O_LD + 4 * c4);
     }
   }
+  TSTAMP(5);
 }
 
 #ifndef CONV_NB
 #define CONV_NB 3
 #endif
-#define CONV_NH 1   // 2 = two skewed halves per 512-thread workgroup (hides the epilogue but exposes the prologue: slower)
-
 
 void launch_conv(const ConvArgs& a, hipStream_t st) {
-  static int nh = -1, abl = -1;   // developer knobs: DBFR_CONV_NH (1 | 2 halves per workgroup), DBFR_CONV_ABL (ablations)
-  if (nh < 0) { const char* e = getenv("DBFR_CONV_NH"); nh = e ? atoi(e) : CONV_NH; }
+  static int abl = -1;   // developer knob DBFR_CONV_ABL: 1 no contraction, 2 no W2 re-load, 8 prologue only (timing only, wrong results)
   if (abl < 0) { const char* e = getenv("DBFR_CONV_ABL"); abl = e ? atoi(e) : 0; }
-  static int skew = -1;
-  if (skew < 0) { const char* e = getenv("DBFR_CONV_SKEW"); skew = e ? atoi(e) : 1; }
   const int te = 16 * CONV_NB;
   const int tiles = (a.max_edges + te - 1) / te;
   if (tiles <= 0) return;
   ConvArgs b = a;
-  b.skew_blocks = skew ? 512 : 0;     // 256 CUs x 2 resident workgroups
   b.trace = nullptr;
   static const char* trace_path = getenv("DBFR_CONV_TRACE");   // developer: dump a per-tile timeline of one big launch
   if (trace_path && a.w.K == 144 && a.w.W == 7776 && tiles >= 4096) {
-    const size_t nw = (size_t)TRACE_BLOCKS * 4 * (2 + 3 * TRACE_TILES);
+    const size_t nw = (size_t)TRACE_BLOCKS * 4 * TRACE_REC;
     unsigned long long* d = nullptr;
     if (hipMalloc(&d, nw * 8) == hipSuccess) {
       (void)hipMemsetAsync(d, 0, nw * 8, st);
       b.trace = d;
-      hipLaunchKernelGGL((k_conv<144, CONV_NB, 16, 1>), dim3(tiles), dim3(256), 0, st, b);
+      hipLaunchKernelGGL((k_conv<144, CONV_NB, 16>), dim3(tiles), dim3(256), 0, st, b);
       (void)hipStreamSynchronize(st);
       std::vector<unsigned long long> h(nw);
       (void)hipMemcpy(h.data(), d, nw * 8, hipMemcpyDeviceToHost);
@@ -405,16 +388,9 @@ void launch_conv(const ConvArgs& a, hipStream_t st) {
       return;
     }
   }
-#define LAUNCH(KK, AB, NHH) hipLaunchKernelGGL((k_conv<KK, CONV_NB, AB, NHH>), dim3((tiles + NHH - 1) / NHH), dim3(256 * NHH), 0, st, b)
-#if CONV_NB <= 3
-  if (nh == 2) {
-    if (a.w.K != 144) { LAUNCH(96, 0, 2); return; }
-    switch (abl) { case 1: LAUNCH(144, 1, 2); break; case 8: LAUNCH(144, 8, 2); break; default: LAUNCH(144, 0, 2); }
-    return;
-  }
-#endif
-  if (a.w.K != 144) { LAUNCH(96, 0, 1); return; }
-  switch (abl) { case 1: LAUNCH(144, 1, 1); break; case 8: LAUNCH(144, 8, 1); break; default: LAUNCH(144, 0, 1); }
+#define LAUNCH(KK, AB) hipLaunchKernelGGL((k_conv<KK, CONV_NB, AB>), dim3(tiles), dim3(256), 0, st, b)
+  if (a.w.K != 144) { LAUNCH(96, 0); return; }
+  switch (abl) { case 1: LAUNCH(144, 1); break; case 2: LAUNCH(144, 2); break; case 8: LAUNCH(144, 8); break; default: LAUNCH(144, 0); }
 #undef LAUNCH
 }
 

@@ -2,7 +2,9 @@
 import sys
 import numpy as np
 TB, TT = 1024, 48
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(TB, 4, 2 + 3 * TT)
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(TB, 4, 2 + 3 * TT + 6)
+ph = a[:, :, 2 + 3 * TT:].astype(np.int64)
+a = a[:, :, :2 + 3 * TT]
 hw, xcc = a[:, :, 0].astype(np.int64), a[:, :, 1].astype(np.int64) & 15
 t = a[:, :, 2:].astype(np.int64).reshape(TB, 4, TT, 3)       # start, mfma done, epilogue done
 ok = t[:, :, :, 2].min(axis=2) > 0
@@ -51,3 +53,12 @@ base = min(t[b, w, 0, 0], t[b2, w2, 0, 0])
 print("example pair timelines (start, mfma_done, epi_done) relative cycles:")
 for i in range(8, 14):
     print("  A", (t[b, w, i] - base).tolist(), "  B", (t[b2, w2, i] - base).tolist())
+
+# ---- phases per wave: entry, gather done, B operand ready (start of D), D done, after the D barrier, end
+okp = ph.min(axis=2) > 0
+d = np.diff(ph, axis=2)[okp]
+names = ["A gather", "B hidden layer + C", "D tiles", "wait at barrier", "E store"]
+tot = (ph[..., 5] - ph[..., 0])[okp]
+print("workgroup life (cycles): median %d" % np.median(tot))
+for i, nm in enumerate(names):
+    print("  %-20s median %7d  mean %7d  (%.1f%% of life)" % (nm, np.median(d[:, i]), d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))
