@@ -32,7 +32,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "dbfr.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "residue_tables.inc"), os.path.join(HERE, "..", "include", "dbfr.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

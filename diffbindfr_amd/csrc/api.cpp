@@ -57,17 +57,14 @@ void launch_sidechain(const dbfr_batch& b, const float* score, const float* z, f
 void launch_fill(float* p, float v, int n, hipStream_t st);
 void launch_set_int(int* p, int v, hipStream_t st);
 void launch_init_poses(const dbfr_batch& b, const dbfr_init_tape& z, const int* a14_group, float* atom14_out, hipStream_t st);
+void launch_extract_templates(int n_res, const int* aatype, const float* pos14, float* transl, float* rots, float* frames,
+                              float* rigid, float* angle, hipStream_t st);
 void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st);
 
-// restype_atom14_to_rigid_group (AF2 constant table; reference protein_constants.py:1177, data only)
-static const int kAtom14ToGroup[21 * 14] = {
-    0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 6, 7, 7, 7, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 0, 0, 0, 0, 0, 0,
-    0, 0, 0, 3, 0, 4, 5, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 6, 6, 0, 0, 0, 0, 0,
-    0, 0, 0, 3, 0, 4, 5, 6, 6, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 0, 0, 0, 0,
-    0, 0, 0, 3, 0, 4, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 6, 7, 0, 0, 0, 0, 0,
-    0, 0, 0, 3, 0, 4, 5, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 5, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 0, 0, 0, 0, 0, 0, 0,
-    0, 0, 0, 3, 0, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 5, 5, 5, 5,
-    0, 0, 0, 3, 0, 4, 5, 5, 5, 5, 5, 5, 0, 0, 0, 0, 0, 3, 0, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// AF2 residue constant tables (data only; generated from the reference's protein_constants.py by tools/make_residue_tables.py)
+#define RT_TABLE static const
+#include "residue_tables.inc"
+#undef RT_TABLE
 
 static thread_local std::string g_err;
 void dbfr_set_error(const std::string& s) { g_err = s; }
@@ -793,6 +790,18 @@ extern "C" int dbfr_init_poses(const dbfr_model* m, const dbfr_batch* b, const d
   if (!tape || !tape->rot || !tape->tr || !tape->sc_u || (b->NTOR > 0 && !tape->tor_u))
     return fail(DBFR_ERR_ARG, "null init tape");
   launch_init_poses(*b, *tape, m->a14_group, atom14_out, (hipStream_t)hip_stream);
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_extract_templates(int32_t n_res, const int32_t* aatype, const float* atom14_pos, float* backbone_transl,
+                                      float* backbone_rots, float* default_frame, float* rigid_group_positions,
+                                      float* torsion_angle, void* hip_stream) {
+  if (n_res < 0 || !aatype || !atom14_pos || !backbone_transl || !backbone_rots || !default_frame || !rigid_group_positions ||
+      !torsion_angle)
+    return fail(DBFR_ERR_ARG, "null argument");
+  launch_extract_templates(n_res, aatype, atom14_pos, backbone_transl, backbone_rots, default_frame, rigid_group_positions,
+                           torsion_angle, (hipStream_t)hip_stream);
   HIPCHECK(hipGetLastError());
   return DBFR_OK;
 }

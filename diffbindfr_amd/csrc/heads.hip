@@ -447,6 +447,117 @@ void launch_init_poses(const dbfr_batch& b, const dbfr_init_tape& z, const int* 
   hipLaunchKernelGGL(k_atom14, dim3((b.NR + 63) / 64), dim3(64), 0, st, b, a14_group, atom14_out, (float*)nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------ pocket templates
+// extract_chi_and_template (prot_math.py:116-241): the inverse of k_atom14.  One thread per residue: backbone frame from
+// N, CA, C; psi and chi1..4 from the atom14 coordinates; per-residue default frames (the pose of every rigid group in
+// its parent group) and the atoms' coordinates inside their groups.
+#define RT_TABLE __device__ const
+#include "residue_tables.inc"
+#undef RT_TABLE
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3 scale3(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+
+struct Frame3 { V3 ex, ey, ez, t; };
+// make_rigid_transformation_4x4 (geometry_utils/utils.py:93-122)
+__device__ __forceinline__ Frame3 rigid_frame(V3 ex, V3 ey, V3 t) {
+  Frame3 f;
+  f.ex = scale3(ex, 1.f / (sqrtf(dot3(ex, ex)) + 1e-6f));
+  V3 e = ey - scale3(f.ex, dot3(ey, f.ex));
+  f.ey = scale3(e, 1.f / sqrtf(dot3(e, e)));
+  f.ez = cross3(f.ex, f.ey);
+  f.t = t;
+  return f;
+}
+__device__ __forceinline__ V3 to_local(const Frame3& f, V3 p) {   // apply_inv_euclidean: R^T (p - t)
+  V3 d = p - f.t;
+  return v3(dot3(f.ex, d), dot3(f.ey, d), dot3(f.ez, d));
+}
+__device__ __forceinline__ void store_frame(float* m, const Frame3& f) {   // 4x4 row-major, columns (ex ey ez t)
+  m[0] = f.ex.x; m[1] = f.ey.x; m[2] = f.ez.x; m[3] = f.t.x;
+  m[4] = f.ex.y; m[5] = f.ey.y; m[6] = f.ez.y; m[7] = f.t.y;
+  m[8] = f.ex.z; m[9] = f.ey.z; m[10] = f.ez.z; m[11] = f.t.z;
+  m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
+}
+
+__global__ void k_extract_templates(int n_res, const int* __restrict__ aatype, const float* __restrict__ pos14,
+                                    float* __restrict__ transl, float* __restrict__ rots, float* __restrict__ frames,
+                                    float* __restrict__ rigid, float* __restrict__ angle) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_res) return;
+  const int aa = aatype[r];
+  V3 P[14];
+  for (int a = 0; a < 14; ++a) { const float* p = pos14 + ((size_t)r * 14 + a) * 3; P[a] = v3(p[0], p[1], p[2]); }
+  // residue_frame(origin = CA, x_axis = C, xy_plane = N)   (geometry_utils/utils.py:125-148)
+  Frame3 bbf;
+  {
+    V3 e0 = P[2] - P[1], e1 = P[0] - P[1];
+    e0 = scale3(e0, 1.f / sqrtf(dot3(e0, e0) + 1e-20f));
+    e1 = e1 - scale3(e0, dot3(e0, e1));
+    e1 = scale3(e1, 1.f / sqrtf(dot3(e1, e1) + 1e-20f));
+    bbf.ex = e0; bbf.ey = e1; bbf.ez = cross3(e0, e1); bbf.t = P[1];
+  }
+  transl[3 * r] = P[1].x; transl[3 * r + 1] = P[1].y; transl[3 * r + 2] = P[1].z;
+  {
+    float* R = rots + (size_t)r * 9;       // columns e0 e1 e2
+    R[0] = bbf.ex.x; R[1] = bbf.ey.x; R[2] = bbf.ez.x;
+    R[3] = bbf.ex.y; R[4] = bbf.ey.y; R[5] = bbf.ez.y;
+    R[6] = bbf.ex.z; R[7] = bbf.ey.z; R[8] = bbf.ez.z;
+  }
+  V3 cur[14], tm[14];
+  for (int a = 0; a < 14; ++a) { cur[a] = to_local(bbf, P[a]); tm[a] = v3(0.f, 0.f, 0.f); }
+  tm[0] = v3(cur[0].x, cur[0].y, 0.f);      // N: x, y
+  tm[2] = v3(cur[2].x, 0.f, 0.f);           // C: x
+  tm[4] = cur[4];                           // CB
+  float* F = frames + (size_t)r * 128;
+  for (int i = 0; i < 128; ++i) F[i] = 0.f;
+  F[0] = F[5] = F[10] = F[15] = 1.f;                    // backbone group
+  F[16] = F[21] = F[26] = F[31] = 1.f;                  // pre-omega group (empty)
+  store_frame(F + 32, rigid_frame(tm[0] - tm[1], v3(1.f, 0.f, 0.f), tm[0]));          // phi group (empty)
+  const Frame3 psi_f = rigid_frame(tm[2] - tm[1], tm[1] - tm[0], tm[2]);
+  store_frame(F + 48, psi_f);
+  float* A = angle + (size_t)r * 5;
+  {
+    const V3 o = to_local(psi_f, cur[3]);               // O in the psi frame -> (x, |yz|, 0), psi = atan2(z, y)
+    tm[3] = v3(o.x, sqrtf(o.y * o.y + o.z * o.z), 0.f);
+    A[0] = atan2f(o.z, o.y);
+  }
+  for (int k = 0; k < 4; ++k) {
+    A[k + 1] = 0.f;
+    if (!kChiMask[aa][k]) continue;
+    const int i0 = kChiAtoms14[aa][k][0], i1 = kChiAtoms14[aa][k][1], i2 = kChiAtoms14[aa][k][2], i3 = kChiAtoms14[aa][k][3];
+    const Frame3 f = k == 0 ? rigid_frame(cur[i2] - cur[i1], cur[i0] - cur[i1], cur[i2])
+                            : rigid_frame(cur[i2], v3(-1.f, 0.f, 0.f), cur[i2]);
+    store_frame(F + 16 * (4 + k), f);
+    const V3 last = to_local(f, cur[i3]);
+    const float chi = atan2f(last.z, last.y);
+    A[k + 1] = chi;
+    const float sn = sinf(-chi), cs = cosf(-chi);       // rot_vec_around_x_axis(x, -chi)
+    for (int a = 0; a < 14; ++a) {
+      const V3 l = to_local(f, cur[a]);
+      cur[a] = v3(l.x, cs * l.y - sn * l.z, sn * l.y + cs * l.z);
+      if (kAtom14ToGroup[aa * 14 + a] == k + 4) { tm[a].x += cur[a].x; tm[a].y += cur[a].y; tm[a].z += cur[a].z; }
+    }
+  }
+  // * restype_atom14_mask (ideal mask of the residue type): the slots the type does not use stay zero
+  for (int a = 0; a < 14; ++a) {
+    const bool used = kAtom14Mask[aa][a] != 0;
+    float* o = rigid + ((size_t)r * 14 + a) * 3;
+    o[0] = used ? tm[a].x : 0.f; o[1] = used ? tm[a].y : 0.f; o[2] = used ? tm[a].z : 0.f;
+  }
+}
+
+void launch_extract_templates(int n_res, const int* aatype, const float* pos14, float* transl, float* rots, float* frames,
+                              float* rigid, float* angle, hipStream_t st) {
+  if (n_res > 0)
+    hipLaunchKernelGGL(k_extract_templates, dim3((n_res + 63) / 64), dim3(64), 0, st, n_res, aatype, pos14, transl, rots,
+                       frames, rigid, angle);
+}
+
 // ------------------------------------------------------------------------------------------------ small utilities
 __global__ void k_fill(float* p, float v, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

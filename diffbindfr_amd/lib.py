@@ -63,7 +63,7 @@ class InitTape(C.Structure):
 
 # every symbol include/dbfr.h declares (tests check that the library exports all of them)
 SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
-           "dbfr_init_poses", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
+           "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
            "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_reduce_ln"]
 
 _lib = None
@@ -92,6 +92,7 @@ def load():
     lib.dbfr_sample.argtypes = [vp, C.POINTER(Batch), C.POINTER(Step), i32, C.POINTER(Noise), vp, vp, vp, vp,
                                 C.c_size_t, C.POINTER(Limits), vp]
     lib.dbfr_init_poses.argtypes = [vp, C.POINTER(Batch), C.POINTER(InitTape), vp, vp]
+    lib.dbfr_extract_templates.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dbfr_status_sync.argtypes = [vp, vp, C.POINTER(C.c_int64)]
     lib.dbfr_wigner3j.argtypes = [i32, i32, i32, C.POINTER(C.c_double)]
     lib.dbfr_conv_paths.argtypes = [i32, C.POINTER(i32), i32, C.POINTER(i32)]

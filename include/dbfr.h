@@ -199,6 +199,18 @@ typedef struct {
 int dbfr_init_poses(const dbfr_model* m, const dbfr_batch* b, const dbfr_init_tape* tape, float* atom14_out,
                     void* hip_stream);
 
+/* ---- pocket templates, on the device.
+ * Replaces extract_chi_and_template (druglib/utils/obj/prot_math.py:116-241,
+ * called once per pocket from SCPocketFinderDefault, pocket_pipeline.py:174-189):
+ * from residue types and atom14 coordinates (unused slots zero) to the backbone
+ * frames, psi/chi1..4 (radians), the per-residue default frames [n,8,4,4] and the
+ * atoms' positions inside their rigid groups [n,14,3] -- the inverse of the
+ * side-chain rebuild inside dbfr_sample.  All pointers are device pointers; the
+ * residue tables are compiled in.  aatype in [0, 20].                            */
+int dbfr_extract_templates(int32_t n_res, const int32_t* aatype, const float* atom14_pos, float* backbone_transl,
+                           float* backbone_rots, float* default_frame, float* rigid_group_positions,
+                           float* torsion_angle, void* hip_stream);
+
 /* Synchronises the stream and returns the device-side status word of the last
  * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
  * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last

@@ -381,6 +381,67 @@ def golden_pose_init():
     np.savez_compressed(os.path.join(HERE, "pose_init.npz"), **out)
 
 
+def golden_pocket():
+    """f2: once-per-pocket preparation -- extract_chi_and_template, make_torsion_mask, build_torsion_edges,
+    PocketFeaturizer, Decentration of the reference on a synthetic all-residue-type pocket (float64 coordinates,
+    as Protein.atom_positions holds them)."""
+    print("[pocket]")
+    from oracle import pocket as opk
+    if "druglib.datasets.builder" not in sys.modules or not hasattr(sys.modules["druglib.datasets.builder"], "PIPELINES"):
+        dsb = types.ModuleType("druglib.datasets.builder")
+        dsb.PIPELINES = ns.builder.INTERACTION.__class__("pipeline")
+        sys.modules["druglib.datasets.builder"] = dsb
+    obj = sys.modules["druglib.utils.obj"]
+    obj.Ligand3D = object
+    obj.make_torsion_mask = ns.prot_math.make_torsion_mask
+    du = ref_shims._load("druglib.datasets.Docking.utils", "datasets/Docking/utils.py")
+    pp = ref_shims._load("druglib.datasets.Docking.pocket_pipeline", "datasets/Docking/pocket_pipeline.py")
+    rng = np.random.default_rng(808)
+    # every residue type at least twice, random order
+    seq = np.concatenate([np.arange(20), np.arange(20), rng.integers(0, 20, 24)])
+    rng.shuffle(seq)
+    N = len(seq)
+    transl = rng.normal(0, 8.0, (N, 3))
+    rots = np.stack([synthetic._rand_rot(rng) for _ in range(N)])
+    m14 = T["atom14_mask"][seq].astype(bool)
+    rigid = T["atom14_lit_pos"][seq].astype(np.float64) + rng.normal(0, 0.04, (N, 14, 3)) * m14[..., None]
+    tor = rng.uniform(-np.pi, np.pi, (N, 5))
+    pos = synthetic.build_atom14_np(seq, transl, rots, T["default_frame"][seq].astype(np.float64), rigid, tor, T["atom14_to_group"])
+    ideal = T["atom14_mask"][seq][..., None].astype(np.float32)
+    pos = pos * ideal                                            # float64, zeros in unused slots (to_pos14)
+    ref = ns.prot_math.extract_chi_and_template(seq, pos.copy(), ideal, return_radian=True)
+    mine = opk.extract_chi_and_template(seq, pos.copy(), ideal, T)
+    out = dict(aatype=seq, atom14_position=pos, ideal_mask=ideal[..., 0])
+    for k in ("backbone_transl", "backbone_rots", "default_frame", "rigid_group_positions", "torsion_angle"):
+        close(mine[k], ref[k], 0.0, "pocket/" + k)
+        out["ref_" + k] = npy(ref[k])
+    # the reference's own inverse: templates -> atom14 must give the input back
+    back = ns.prot_math.build_pdb_from_template(ED(sequence=torch.from_numpy(seq), backbone_transl=torch.from_numpy(ref["backbone_transl"]).float(),
+                                                    backbone_rots=torch.from_numpy(ref["backbone_rots"]).float(),
+                                                    default_frame=torch.from_numpy(ref["default_frame"]),
+                                                    rigid_group_positions=torch.from_numpy(ref["rigid_group_positions"]),
+                                                    torsion_angle=ns.geom.radian2sincos_torch(torch.from_numpy(ref["torsion_angle"]))),
+                                                 torch.device("cpu"))[0]
+    close(back * torch.from_numpy(ideal), torch.from_numpy(pos).float(), 2e-4, "pocket/round trip through build_pdb_from_template")
+    # masks / edges / features with some side chains missing
+    actual = torch.from_numpy(m14.copy())
+    for r in rng.choice(np.nonzero(m14[:, 6:].any(1))[0], 6, replace=False):
+        actual[r, 6:] = False
+    actual[3, 5] = False
+    seq_t = torch.from_numpy(seq)
+    close(opk.make_torsion_mask(seq_t, actual, T).float(), ns.prot_math.make_torsion_mask(seq_t, actual).float(), 0.0, "pocket/make_torsion_mask")
+    te_ref, cm_ref = du.build_torsion_edges(seq_t, actual)
+    te, cm = opk.build_torsion_edges(seq_t, actual, T)
+    close(te, te_ref[..., 1, :], 0.0, "pocket/torsion_edge_index")
+    close(cm.float(), cm_ref.float(), 0.0, "pocket/sc_torsion_edge_mask")
+    fake = types.SimpleNamespace(num_res=lambda: N, atom_mask=np.zeros((N, 37)), residue_prop={})
+    d = pp.PocketFeaturizer()(dict(atom14_mask=actual, sequence=seq_t, pocket=fake))
+    close(opk.pocket_features(seq_t, actual, T), d["pocket_node_feature"], 0.0, "pocket/pocket_node_feature")
+    out.update(actual_mask=npy(actual), ref_torsion_edge_index=npy(te_ref[..., 1, :]), ref_sc_torsion_edge_mask=npy(cm_ref),
+               ref_pocket_node_feature=npy(d["pocket_node_feature"]))
+    np.savez_compressed(os.path.join(HERE, "pocket.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_geometry()
@@ -388,4 +449,5 @@ if __name__ == "__main__":
     golden_schedule()
     golden_model_and_sampler()
     golden_pose_init()
+    golden_pocket()
     print("golden fixtures written to", HERE)
