@@ -408,20 +408,21 @@ __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ msg
   const bool live = node_raw < N;
   const int node = live ? node_raw : N - 1;
   const int rs = row_start[node], rc = row_cnt[node];
-  float acc[3] = {0.f, 0.f, 0.f};
-  for (int e = 0; e < rc; ++e) {
-    const float* r = msg + (size_t)(rs + e) * D;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      int c = lane + 64 * j;
-      if (c < D) acc[j] += r[c];
+  // rows are 16-B aligned (D is a multiple of 4): one float4 per lane covers a row, four rows are requested before the
+  // first add so that one L2 round trip serves four edges; the adds keep the edge order (reproducible, order = CSR order)
+  const int d4 = D >> 2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (lane < d4) {
+    const f32x4* r = reinterpret_cast<const f32x4*>(msg + (size_t)rs * D) + lane;
+    int e = 0;
+    for (; e + 4 <= rc; e += 4) {
+      const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
+      acc += v0; acc += v1; acc += v2; acc += v3;
     }
-  }
-  const float cntf = (float)max(rc, 1);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    int c = lane + 64 * j;
-    if (c < D) buf[wave][c] = acc[j] / cntf;
+    for (; e < rc; ++e) acc += r[(size_t)e * d4];
+    const float cntf = (float)max(rc, 1);
+    float* bw = buf[wave] + 4 * lane;
+    bw[0] = acc[0] / cntf; bw[1] = acc[1] / cntf; bw[2] = acc[2] / cntf; bw[3] = acc[3] / cntf;
   }
   __syncthreads();
   int iw = 0, ib = 0;

@@ -445,25 +445,46 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
     }
     xin[r][c] = v;
   }
-  __syncthreads();
-  if (threadIdx.x < 192) {
-    const int c = threadIdx.x % NS, eg = threadIdx.x / NS;
-    const float b = a.w.b0 ? a.w.b0[c] : 0.f;
-    for (int r = eg; r < MLP_ROWS; r += 4) {
-      float acc = b;
-      for (int i = 0; i < in; ++i) acc += w0[i * NS + c] * xin[r][i];
-      hid[r][c] = fmaxf(acc, 0.f);
-    }
+  // zero padding of the reduction dim to a multiple of 4 (MFMA k-step)
+  const int kin = (in + 3) & ~3;
+  if (kin > in) {
+    for (int i = threadIdx.x; i < MLP_ROWS * (kin - in); i += 256) xin[i / (kin - in)][in + i % (kin - in)] = 0.f;
+    for (int i = threadIdx.x; i < (kin - in) * NS; i += 256) w0[in * NS + i] = 0.f;
   }
   __syncthreads();
-  if (threadIdx.x < 192) {
-    const int c = threadIdx.x % NS, eg = threadIdx.x / NS;
-    const float b = a.w.b1 ? a.w.b1[c] : 0.f;
-    for (int r = eg; r < nr; r += 4) {
-      float acc = b;
-      for (int i = 0; i < NS; ++i) acc += w1[i * NS + c] * hid[r][i];
-      a.out[(size_t)(r0 + r) * NS + c] = acc;
-    }
+  // both layers on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): wave w owns rows 16w..16w+15,
+  // D[channel, row] orientation => lane (g, n) holds 4 consecutive output channels of row 16w + n
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+  const int row = 16 * wave + n;
+  f32x4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = a.w.b0 ? a.w.b0[16 * t + 4 * g + r] : 0.f;
+  for (int k = 0; k < kin; k += 4) {
+    const float bv = xin[row][k + g];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[(k + g) * NS + 16 * t + n], bv, acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hid[row][16 * t + 4 * g + r] = fmaxf(acc[t][r], 0.f);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = a.w.b1 ? a.w.b1[16 * t + 4 * g + r] : 0.f;
+#pragma unroll
+  for (int k = 0; k < NS; k += 4) {
+    const float bv = hid[row][k + g];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[(k + g) * NS + 16 * t + n], bv, acc[t], 0, 0, 0);
+  }
+  if (row < nr) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(a.out + (size_t)(r0 + row) * NS + 16 * t + 4 * g) = acc[t];
   }
 }
 
