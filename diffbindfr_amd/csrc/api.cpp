@@ -155,13 +155,15 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
   const float* ab = need(tm, name + ".batch_norm.affine_bias", n0e, &rc);
   if (rc) return rc;
   const int KT = K / 16;
-  // lin.0 in MFMA A-fragment order: [m][s4][lane][q] = W1[16m + (lane&15)][4(4 s4+q) + (lane>>4)]
+  // lin.0 in MFMA A-fragment order: [m][s4][lane][q] = W1[16m + (lane&15)][16 s4 + 4 (lane>>4) + q].  The reduction index is
+  // permuted inside every 16-group (MFMA k-step q of lane group g takes k = 16 s4 + 4 g + q) so that the four B operands a lane
+  // needs for one A fragment are 4 consecutive floats of its edge's activation row: one ds_read_b128 instead of four ds_read_b32
   std::vector<float> w1p((size_t)KT * KT * 64 * 4);
   for (int mt = 0; mt < KT; ++mt)
     for (int s4 = 0; s4 < KT; ++s4)
       for (int lane = 0; lane < 64; ++lane)
         for (int q = 0; q < 4; ++q)
-          w1p[(((size_t)mt * KT + s4) * 64 + lane) * 4 + q] = W1[(size_t)(16 * mt + (lane & 15)) * K + 4 * (4 * s4 + q) + (lane >> 4)];
+          w1p[(((size_t)mt * KT + s4) * 64 + lane) * 4 + q] = W1[(size_t)(16 * mt + (lane & 15)) * K + 16 * s4 + 4 * (lane >> 4) + q];
   // lin.3 rows re-ordered for OWNER accumulation (no atomics, reproducible):
   //   an output channel (io, w) is a "pair"; its contributions come from every path into io, all u_in.
   //   4 pairs with the same (type, mul1) path sequence form a group processed in lock step: tile =
@@ -300,7 +302,7 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
         const Row& r = rows[16 * t + (lane & 15)];
         for (int q = 0; q < 4; ++q)
           w2p[(((size_t)t * KT + s4) * 64 + lane) * 4 + q] =
-              r.orig >= 0 ? r.scale * W2[(size_t)r.orig * K + 4 * (4 * s4 + q) + (lane >> 4)] : 0.f;
+              r.orig >= 0 ? r.scale * W2[(size_t)r.orig * K + 16 * s4 + 4 * (lane >> 4) + q] : 0.f;
       }
   }
   o->K = K; o->D_in = sp.D_in; o->D_out = sp.D_out; o->n_tiles = n_tiles; o->W = sp.W;

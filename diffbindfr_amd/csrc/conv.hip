@@ -48,11 +48,10 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
   constexpr int TE = 16 * NB;
   constexpr int KT = K / 16;  // 16-wide tiles along the MLP input/hidden dim
   constexpr int KS = K / 4;   // MFMA k-steps
-  constexpr int A_LD = K + 1;
-  constexpr int H_LD = TE + 1;
-  constexpr int UN = (TE * (MAXD + 8) > K * H_LD) ? TE * (MAXD + 8) : K * H_LD;
+  constexpr int A_LD = K + 4;   // edge-major activation rows [edge][k], 16-B aligned: inputs a1, then the hidden layer h
+  constexpr int UN = (TE * (MAXD + 8) > TE * A_LD) ? TE * (MAXD + 8) : TE * A_LD;
   __shared__ __attribute__((aligned(16))) float xs[TE * XS_LD];
-  __shared__ __attribute__((aligned(16))) float un[UN];       // a1 [TE][A_LD]  ->  hs [K][H_LD]  ->  out [TE][O_LD]
+  __shared__ __attribute__((aligned(16))) float un[UN];       // a1 [TE][A_LD]  ->  h [TE][A_LD]  ->  out [TE][O_LD]
   __shared__ float shs[TE * 10];
   __shared__ int s_idx[3 * TE];
   __shared__ __attribute__((aligned(16))) float ms[TE * 8];   // per edge: the symmetric traceless l=2 matrix (m00 m01 m02 m11 m12 m22) of PT_VTV
@@ -118,8 +117,7 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
       const int i = tid + 256 * j;
       if (i < NA4) {
         const int e = i / (NPART * P4), r = i - e * (NPART * P4);
-        float* dst = un + e * A_LD + 4 * r;
-        dst[0] = va[j][0]; dst[1] = va[j][1]; dst[2] = va[j][2]; dst[3] = va[j][3];
+        *reinterpret_cast<f32x4*>(un + e * A_LD + 4 * r) = va[j];
       }
     }
 #pragma unroll
@@ -159,15 +157,18 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
       for (int b = 0; b < NB; ++b) hacc[jj][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (m < KT) {
         const int mn = (m + 4 < KT) ? m + 4 : m;
-        const float* Bp = un + n * A_LD + g;
+        const float* Bp = un + n * A_LD + 4 * g;     // k-step q of lane group g reads k = 16 s4 + 4 g + q (see api.cpp pack_conv)
 #pragma unroll
         for (int s4 = 0; s4 < KT; ++s4) {
           const f32x4 av = A1[s4];
+          f32x4 bq[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) bq[b] = *reinterpret_cast<const f32x4*>(Bp + 16 * b * A_LD + 16 * s4);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int b = 0; b < NB; ++b)
-              hacc[jj][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bp[16 * b * A_LD + 4 * (4 * s4 + q)], hacc[jj][b], 0, 0, 0);
+              hacc[jj][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bq[b][q], hacc[jj][b], 0, 0, 0);
           A1[s4] = W1[((size_t)mn * KT + s4) * 64];
         }
       }
@@ -178,22 +179,27 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
   for (int jj = 0; jj < JPW; ++jj) {
     const int m = wave + 4 * jj;
     if (m < KT) {
+      const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.w.b1 + 16 * m + 4 * g);
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+      for (int b = 0; b < NB; ++b) {
+        f32x4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * m + 4 * g + r;
-          un[row * H_LD + 16 * b + n] = fmaxf(hacc[jj][b][r] + a.w.b1[row], 0.f);
-        }
+        for (int r = 0; r < 4; ++r) h[r] = fmaxf(hacc[jj][b][r] + b1v[r], 0.f);
+        *reinterpret_cast<f32x4*>(un + (16 * b + n) * A_LD + 16 * m + 4 * g) = h;     // h[edge][hidden unit]
+      }
     }
   }
   __syncthreads();
   // ---------------- phase C: B operand (h^T) into registers
   float Bv[NB][KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+  for (int s4 = 0; s4 < KT; ++s4)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) Bv[b][s] = un[(4 * s + g) * H_LD + 16 * b + n];
+    for (int b = 0; b < NB; ++b) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(un + (16 * b + n) * A_LD + 16 * s4 + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Bv[b][4 * s4 + q] = v[q];
+    }
   __syncthreads();   // hs is dead: the region becomes the message tile (every element is stored exactly once)
   TSTAMP(2);
   // ---------------- phase D: the W2 row tiles of this wave, run by run (channel-owner order, see api.cpp pack_conv).
