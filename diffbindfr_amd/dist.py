@@ -21,7 +21,8 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # DBFR_DIST_BACKEND=gloo: developer override to walk the multi-rank path on a box with fewer GPUs than ranks
+        backend = backend or os.environ.get("DBFR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -52,9 +53,12 @@ def gather_records(local, world=None):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = world or dist.get_world_size()
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:      # gloo has no device collectives: stage through the host
+        local = local.cpu()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    return out.to(dev)
 
 
 def gather_ragged(local, n_valid):
@@ -62,7 +66,7 @@ def gather_ragged(local, n_valid):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local[:n_valid]
     world = dist.get_world_size()
-    n = torch.tensor([n_valid], dtype=torch.int64, device=local.device)
+    n = torch.tensor([n_valid], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else local.device)
     ns = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(ns, n)
     nmax = int(max(int(x) for x in ns))
@@ -75,7 +79,7 @@ def gather_ragged(local, n_valid):
 def max_over_ranks(x, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(x)
-    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(x)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)
 
