@@ -22,6 +22,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const float* W, float* out, u
   f32x4 tot = {0, 0, 0, 0};
   __syncthreads();
   if (SYNC >= 2 && wave >= 4) for (int k = 0; k < SYNC; ++k) __builtin_amdgcn_s_sleep(16);   // lag the second wave of every SIMD by SYNC x 1024 cycles
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long c0 = __builtin_readcyclecounter();
   for (int i = 0; i < tiles; ++i) {
     const int tn = SAME_TILE ? t0 : (t0 + i + DEPTH) % n_tiles_w;
@@ -43,22 +44,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const float* W, float* out, u
     for (int b = 0; b < 3; ++b) tot += acc[b];
   }
   unsigned long long c1 = __builtin_readcyclecounter();
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   out[blockIdx.x * 64 * WAVES + threadIdx.x] = tot[0] + tot[1] + tot[2] + tot[3];
-  if (lane == 0) cyc[blockIdx.x * 8 + wave] = c1 - c0;
+  if (lane == 0) { cyc[blockIdx.x * 8 + wave] = c1 - c0; cyc[4096 + blockIdx.x * 8 + wave] = r1 - r0; }
 }
 
 int main() {
   const int n_tiles_w = 486, tiles = 400;
   float* W; hipMalloc(&W, (size_t)n_tiles_w * 9 * 1024); hipMemset(W, 0, (size_t)n_tiles_w * 9 * 1024);
-  float* out; unsigned long long* cyc; hipMalloc(&out, 256 * 2 * 512 * 4); hipMalloc(&cyc, 512 * 8 * 8);
+  float* out; unsigned long long* cyc; hipMalloc(&out, 256 * 2 * 512 * 4); hipMalloc(&cyc, 2 * 4096 * 8);
 #define RUN(WAVES, LOADS, SAME, GRID, what) RUNX(WAVES, LOADS, SAME, 1, 0, GRID, n_tiles_w, what)
 #define RUNX(WAVES, LOADS, SAME, DEPTH, SYNC, GRID, n_tiles_w, what) RUNY(WAVES, LOADS, SAME, DEPTH, SYNC, 0, 4, GRID, n_tiles_w, what)
 #define RUNY(WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH, GRID, n_tiles_w, what) do { \
     hipLaunchKernelGGL((k<WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH>), dim3(GRID), dim3(64 * WAVES), 0, 0, W, out, cyc, 20, n_tiles_w); hipDeviceSynchronize(); \
     hipLaunchKernelGGL((k<WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH>), dim3(GRID), dim3(64 * WAVES), 0, 0, W, out, cyc, tiles, n_tiles_w); hipDeviceSynchronize(); \
-    std::vector<unsigned long long> h(GRID * 8); hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost); \
-    double s = 0; for (int b = 0; b < GRID; ++b) for (int w = 0; w < WAVES; ++w) s += h[b * 8 + w]; \
-    printf("%-70s %.0f cycles / tile / wave\n", what, s / (GRID * WAVES) / tiles); } while (0)
+    std::vector<unsigned long long> h(2 * 4096); hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost); \
+    double s = 0, rr = 0; for (int b = 0; b < GRID; ++b) for (int w = 0; w < WAVES; ++w) { s += h[b * 8 + w]; rr += h[4096 + b * 8 + w]; } \
+    printf("%-70s %.0f memtime ticks, %.1f ns / tile / wave\n", what, s / (GRID * WAVES) / tiles, rr / (GRID * WAVES) / tiles * 10.0); } while (0)
   RUN(4, 0, 0, 256, "1 wave/SIMD, no loads (ideal 3456)");
   RUN(4, 1, 1, 256, "1 wave/SIMD, loads of one fixed tile (L1 hits)");
   RUN(4, 1, 0, 256, "1 wave/SIMD, streaming W2 from L2");
