@@ -38,7 +38,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TRACE_BLOCKS 1024
 #define TRACE_TILES 48
-#define TRACE_REC (2 + 3 * TRACE_TILES + 6)
+#define TRACE_REC (2 + 3 * TRACE_TILES + 8)
+#define RSTAMP(k) do { if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * TRACE_REC + 2 + 3 * TRACE_TILES + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TSTAMP(k) do { if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * TRACE_REC + 2 + 3 * TRACE_TILES + (k)] = __builtin_readcyclecounter(); } while (0)
 
 // K: radial-MLP width (144 / 96); NB: 16-edge blocks per workgroup (TE = 16 NB edges share every A fragment
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
     }
   __syncthreads();   // hs is dead: the region becomes the message tile (every element is stored exactly once)
   TSTAMP(2);
+  RSTAMP(6);
   // ---------------- phase D: the W2 row tiles of this wave, run by run (channel-owner order, see api.cpp pack_conv).
   // Measured on MI355X (tools/exp/mfma_shadow.hip): a dense v_mfma_f32_16x16x4_f32 stream leaves room for only ~2.5
   // vector instructions of the OTHER wave on the SIMD per MFMA and for none of its own, so everything that is not an
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
     }
   }
   TSTAMP(3);
+  RSTAMP(7);
   __syncthreads();
   TSTAMP(4);
   // ---------------- phase E

@@ -59,6 +59,7 @@ int main() {
     double s = 0, rr = 0; for (int b = 0; b < 256; ++b) for (int w = 0; w < WAVES; ++w) { s += h[b * 8 + w]; rr += h[4096 + b * 8 + w]; } \
     printf("%-58s %.0f memtime ticks / tile / wave, %.1f ns (100 MHz realtime) => %.3f MFMA-cycles per ns if the pipe were full\n", what, s / (256 * WAVES) / tiles, \
            rr / (256 * WAVES) / tiles * 10.0, (WAVES == 8 ? 6912.0 : 3456.0) / (rr / (256 * WAVES) / tiles * 10.0)); } while (0)
+  RUN(4, 0, "1 wave/SIMD, A from LDS, no loads (ideal 3456)");
   RUN(8, 0, "2 waves/SIMD, A from LDS, no loads (ideal 6912)");
   RUN(8, 2, "2 waves/SIMD, LDS-DMA of one fixed tile");
   RUN(8, 1, "2 waves/SIMD, LDS-DMA stream of W2 from L2");

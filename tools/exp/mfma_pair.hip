@@ -8,7 +8,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int WAVES, int LOADS, int SAME_TILE, int DEPTH = 1, int SYNC = 0, int AUX = 0, int WIDTH = 4>
+template <int WAVES, int LOADS, int SAME_TILE, int DEPTH = 1, int SYNC = 0, int AUX = 0, int WIDTH = 4, int PAUSE = 0>
 __global__ __launch_bounds__(64 * WAVES, 1) void k(const float* W, float* out, unsigned long long* cyc, int tiles, int n_tiles_w) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, n_tiles_w * 9 * 1024, 0x00020000);
@@ -35,6 +35,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const float* W, float* out, u
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bv[b][4 * s4 + q], acc[b], 0, 0, 0);
+      if (PAUSE == 1) __builtin_amdgcn_s_sleep(1);
+      if (PAUSE == 2) __builtin_amdgcn_s_sleep(2);
+      if (PAUSE == 3) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
       if (LOADS && DEPTH == 1 && WIDTH == 4) A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (tn * 9 + s4) * 1024, AUX));
       if (LOADS && DEPTH == 1 && WIDTH == 1) {
         for (int c = 0; c < 4; ++c) A[s4][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, lane * 4, (tn * 9 + s4) * 1024 + c * 256, AUX));
@@ -55,12 +58,18 @@ int main() {
   float* out; unsigned long long* cyc; hipMalloc(&out, 256 * 2 * 512 * 4); hipMalloc(&cyc, 2 * 4096 * 8);
 #define RUN(WAVES, LOADS, SAME, GRID, what) RUNX(WAVES, LOADS, SAME, 1, 0, GRID, n_tiles_w, what)
 #define RUNX(WAVES, LOADS, SAME, DEPTH, SYNC, GRID, n_tiles_w, what) RUNY(WAVES, LOADS, SAME, DEPTH, SYNC, 0, 4, GRID, n_tiles_w, what)
-#define RUNY(WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH, GRID, n_tiles_w, what) do { \
-    hipLaunchKernelGGL((k<WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH>), dim3(GRID), dim3(64 * WAVES), 0, 0, W, out, cyc, 20, n_tiles_w); hipDeviceSynchronize(); \
-    hipLaunchKernelGGL((k<WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH>), dim3(GRID), dim3(64 * WAVES), 0, 0, W, out, cyc, tiles, n_tiles_w); hipDeviceSynchronize(); \
+#define RUNY(WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH, GRID, n_tiles_w, what) RUNZ(WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH, 0, GRID, n_tiles_w, what)
+#define RUNZ(WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH, PAUSE, GRID, n_tiles_w, what) do { \
+    hipLaunchKernelGGL((k<WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH, PAUSE>), dim3(GRID), dim3(64 * WAVES), 0, 0, W, out, cyc, 20, n_tiles_w); hipDeviceSynchronize(); \
+    hipLaunchKernelGGL((k<WAVES, LOADS, SAME, DEPTH, SYNC, AUX, WIDTH, PAUSE>), dim3(GRID), dim3(64 * WAVES), 0, 0, W, out, cyc, tiles, n_tiles_w); hipDeviceSynchronize(); \
     std::vector<unsigned long long> h(2 * 4096); hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost); \
     double s = 0, rr = 0; for (int b = 0; b < GRID; ++b) for (int w = 0; w < WAVES; ++w) { s += h[b * 8 + w]; rr += h[4096 + b * 8 + w]; } \
     printf("%-70s %.0f memtime ticks, %.1f ns / tile / wave\n", what, s / (GRID * WAVES) / tiles, rr / (GRID * WAVES) / tiles * 10.0); } while (0)
+  RUNZ(8, 0, 0, 1, 0, 0, 4, 1, 256, 486, "2 waves/SIMD, no loads, s_sleep 1 after every 12 MFMAs");
+  RUNZ(8, 0, 0, 1, 0, 0, 4, 2, 256, 486, "2 waves/SIMD, no loads, s_sleep 2 after every 12 MFMAs");
+  RUNZ(8, 0, 0, 1, 0, 0, 4, 3, 256, 486, "2 waves/SIMD, no loads, 64 nop cycles after every 12 MFMAs");
+  RUNZ(8, 1, 0, 1, 0, 0, 4, 1, 256, 486, "2 waves/SIMD, streaming, s_sleep 1 after every 12 MFMAs");
+  RUNZ(8, 1, 0, 1, 0, 0, 4, 2, 256, 486, "2 waves/SIMD, streaming, s_sleep 2 after every 12 MFMAs");
   RUN(4, 0, 0, 256, "1 wave/SIMD, no loads (ideal 3456)");
   RUN(4, 1, 1, 256, "1 wave/SIMD, loads of one fixed tile (L1 hits)");
   RUN(4, 1, 0, 256, "1 wave/SIMD, streaming W2 from L2");
