@@ -70,6 +70,7 @@ int main() {
   RUNZ(8, 0, 0, 1, 0, 0, 4, 3, 256, 486, "2 waves/SIMD, no loads, 64 nop cycles after every 12 MFMAs");
   RUNZ(8, 1, 0, 1, 0, 0, 4, 1, 256, 486, "2 waves/SIMD, streaming, s_sleep 1 after every 12 MFMAs");
   RUNZ(8, 1, 0, 1, 0, 0, 4, 2, 256, 486, "2 waves/SIMD, streaming, s_sleep 2 after every 12 MFMAs");
+  RUNX(4, 1, 0, 2, 0, 256, 486, "1 wave/SIMD, streaming, prefetch 2 tiles ahead");
   RUN(4, 0, 0, 256, "1 wave/SIMD, no loads (ideal 3456)");
   RUN(4, 1, 1, 256, "1 wave/SIMD, loads of one fixed tile (L1 hits)");
   RUN(4, 1, 0, 256, "1 wave/SIMD, streaming W2 from L2");
