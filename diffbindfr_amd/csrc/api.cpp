@@ -449,7 +449,7 @@ struct Ws {
   float *c_t, *c_tr_sigma, *c_rot_norm, *c_tor_n2, *c_sc_n2;
   float *s_tr, *s_rot, *s_tor, *s_sc;
   float *lig_x[2], *atom_x[2];
-  EdgeSet set[N_SETS]; int n_edges_store_dummy;
+  EdgeSet set[N_SETS];
   // centre set
   int *c_tgt, *c_gth, *c_row_start, *c_row_cnt, *c_n; float *c_dist, *c_sh, *c_emb;
   float* msg[4]; int multi; float* gp; float *tor_attr, *sc_attr, *tor_feat, *sc_feat;
