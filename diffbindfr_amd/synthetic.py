@@ -20,6 +20,8 @@ import os
 from types import SimpleNamespace
 
 import numpy as np
+
+from . import ligand
 import torch
 
 _TABLES = None
@@ -123,22 +125,6 @@ def make_pocket(rng, n_atoms_target):
                 pocket_node_feature=feat14[mask14], pocket_node_feature14=feat14, n_atoms=int(mask14.sum()))
 
 
-def _components_without(adj, n, u, v):
-    """Component containing v after removing edge u-v (iterative DFS)."""
-    seen = np.zeros(n, bool)
-    stack = [v]
-    seen[v] = True
-    while stack:
-        a = stack.pop()
-        for b in adj[a]:
-            if (a == v and b == u) or (a == u and b == v):
-                continue
-            if not seen[b]:
-                seen[b] = True
-                stack.append(b)
-    return seen
-
-
 def make_ligand(rng, n):
     pos = np.zeros((n, 3))
     deg = np.zeros(n, int)
@@ -178,17 +164,8 @@ def make_ligand(rng, n):
     directed = sorted([(a, b) for a, b in und] + [(b, a) for a, b in und], key=lambda e: e[0] * n + e[1])
     ei = np.asarray(directed, np.int64).T
     E = ei.shape[1]
-    tor_mask = np.zeros(E, bool)
-    rot_masks = []
-    for k, (u, v) in enumerate(directed):
-        comp_v = _components_without(adj, n, u, v)
-        if comp_v[u]:
-            continue                      # not a bridge
-        nv = int(comp_v.sum())
-        small_is_v = nv < n - nv or (nv == n - nv and v < u)
-        if small_is_v and nv > 1:
-            tor_mask[k] = True
-            rot_masks.append(comp_v.copy())
+    tor_mask, rot_all = ligand.torsion_masks(n, ei)
+    rot_masks = list(rot_all)
     # real ligands are ~half ring atoms: keep ~0.25 n of the bridge bonds rotatable, the rest rigid
     keep_n = max(1, int(round(0.25 * n)))
     if len(rot_masks) > keep_n:

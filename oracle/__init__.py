@@ -23,6 +23,7 @@ algorithm, each function citing the reference ``file:line`` it follows
 * ``pose_init``     -- SURVEY 8(f) row f1: LigInit / SCFixer / SCProtInit /
                        Atom14ToAllAtomsRepr (struct_init.py, formatting.py) and
                        the PLData collate (druglib/data/collate.py).
+* ``ligand``        -- find_torsion (datasets/Docking/utils.py:47-92).
 * ``pocket``        -- SURVEY 8(f) row f2: extract_chi_and_template, make_torsion_mask,
                        build_torsion_edges, PocketFeaturizer (prot_math.py,
                        datasets/Docking/utils.py, pocket_pipeline.py).

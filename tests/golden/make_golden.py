@@ -442,6 +442,108 @@ def golden_pocket():
     np.savez_compressed(os.path.join(HERE, "pocket.npz"), **out)
 
 
+def _parse_sdf_heavy(path):
+    """V2000 mol block -> heavy-atom coordinates, elements, bonds (hydrogens dropped, order kept as RDKit's
+    RemoveHs does)."""
+    L = open(path).read().split("\n")
+    na, nb = int(L[3][0:3]), int(L[3][3:6])
+    xyz = [[float(L[4 + i][0:10]), float(L[4 + i][10:20]), float(L[4 + i][20:30])] for i in range(na)]
+    el = [L[4 + i][31:34].strip() for i in range(na)]
+    bonds = [(int(L[4 + na + i][0:3]) - 1, int(L[4 + na + i][3:6]) - 1) for i in range(nb)]
+    keep = [i for i, e in enumerate(el) if e != "H"]
+    ren = {a: k for k, a in enumerate(keep)}
+    return np.array([xyz[i] for i in keep]), [(ren[a], ren[b]) for a, b in bonds if a in ren and b in ren]
+
+
+def _parse_pdb_residues(path):
+    """ATOM records -> [(key, resname, {atom name: xyz})] in file order; heavy atoms, first alternate location."""
+    res, order = {}, []
+    for l in open(path):
+        if not l.startswith("ATOM") or l[16] not in " A":
+            continue
+        name, el = l[12:16].strip(), (l[76:78].strip() if len(l) > 77 else "")
+        if el == "H" or (not el and name[0] == "H"):
+            continue
+        key = (l[21], int(l[22:26]), l[26])
+        if key not in res:
+            res[key] = (l[17:20], {})
+            order.append(key)
+        res[key][1].setdefault(name, [float(l[30:38]), float(l[38:46]), float(l[46:54])])
+    return [(k,) + res[k] for k in order]
+
+
+def golden_real_complex():
+    """BASELINE config 1's structure: examples/forward/3dbs_protein.pdb + its crystal ligand, pocket = residues with any
+    heavy atom within 12 A of any ligand heavy atom (diffbindfr_ts.py:33-41).  Real side-chain geometry through the
+    reference's extract_chi_and_template / masks / edges, the real bond graph through its find_torsion."""
+    print("[real complex 3DBS]")
+    from oracle import pocket as opk, ligand as olig, cluster
+    from diffbindfr_amd import ligand as plig
+    obj = sys.modules["druglib.utils.obj"]
+    obj.Ligand3D = object
+    obj.make_torsion_mask = ns.prot_math.make_torsion_mask
+    du = ref_shims._load("druglib.datasets.Docking.utils", "datasets/Docking/utils.py")
+    ex = os.path.join(ref_shims.REF, "examples", "forward")
+    lig, bonds = _parse_sdf_heavy(os.path.join(ex, "3dbs_protein_crystal.sdf"))
+    pc = ns.pc
+    seq, pos, msk = [], [], []
+    for key, rn, atoms in _parse_pdb_residues(os.path.join(ex, "3dbs_protein.pdb")):
+        if rn not in pc.restype_3to1:
+            continue
+        P = np.array(list(atoms.values()))
+        if np.linalg.norm(P[:, None] - lig[None], axis=-1).min() >= 12.0:
+            continue
+        names = pc.restype_name_to_atom14_names[rn]
+        seq.append(pc.restype_order[pc.restype_3to1[rn]])
+        pos.append([atoms.get(nm, [0.0, 0.0, 0.0]) if nm else [0.0, 0.0, 0.0] for nm in names])
+        msk.append([bool(nm) and nm in atoms for nm in names])
+    seq, pos, msk = np.asarray(seq), np.asarray(pos, np.float64), np.asarray(msk)
+    n_l = lig.shape[0]
+    assert (len(seq), int(msk.sum()), int(msk[:, 1].sum() + msk[:, 4].sum()), n_l) == (105, 866, 205, 35), "SURVEY.md section 8 counts"
+    ideal = T["atom14_mask"][seq][..., None].astype(np.float32)
+    ref = ns.prot_math.extract_chi_and_template(seq, pos.copy(), ideal, return_radian=True)
+    mine = opk.extract_chi_and_template(seq, pos.copy(), ideal, T)
+    out = dict(aatype=seq, atom14_position=pos, atom14_mask=msk, lig_pos=lig)
+    for k in ("backbone_transl", "backbone_rots", "default_frame", "rigid_group_positions", "torsion_angle"):
+        close(mine[k], ref[k], 0.0, "3dbs/" + k)
+        out["ref_" + k] = npy(ref[k])
+    seq_t, msk_t = torch.from_numpy(seq), torch.from_numpy(msk)
+    te_ref, cm_ref = du.build_torsion_edges(seq_t, msk_t)
+    te, cm = opk.build_torsion_edges(seq_t, msk_t, T)
+    close(te, te_ref[..., 1, :], 0.0, "3dbs/torsion_edge_index")
+    close(cm.float(), cm_ref.float(), 0.0, "3dbs/sc_torsion_edge_mask")
+    out.update(ref_torsion_edge_index=npy(te_ref[..., 1, :]), ref_sc_torsion_edge_mask=npy(cm_ref))
+    # ligand graph: directed bonds sorted by src * N + dst (ligand.py:568-570), torsions by the reference's find_torsion
+    directed = sorted([(a, b) for a, b in bonds] + [(b, a) for a, b in bonds], key=lambda e: e[0] * n_l + e[1])
+    ei = np.asarray(directed, np.int64).T
+    fake = types.SimpleNamespace(bond_prop=dict(bond_label=np.zeros(ei.shape[1], int)), edge_index=ei, numatoms=n_l,
+                                 atomtype=np.zeros(n_l, int))
+    tor_ref, rot_ref = du.find_torsion(fake)
+    for what, fn in (("oracle", olig.find_torsion), ("product", plig.torsion_masks)):
+        tor, rot = fn(n_l, ei)
+        close(tor.astype(float), tor_ref.astype(float), 0.0, f"3dbs/find_torsion tor_edge_mask ({what})")
+        close(rot.astype(float), rot_ref.astype(float), 0.0, f"3dbs/find_torsion rot_node_mask ({what})")
+    rng = np.random.default_rng(5)
+    for i in range(6):                                  # synthetic molecules incl. equal-halves ties
+        lg = synthetic.make_ligand(rng, int(rng.integers(4, 40)))
+        e2 = lg["lig_edge_index"]
+        fk = types.SimpleNamespace(bond_prop=dict(bond_label=np.zeros(e2.shape[1], int)), edge_index=e2, numatoms=lg["n_lig"],
+                                   atomtype=np.zeros(lg["n_lig"], int))
+        tr, rr = du.find_torsion(fk)
+        for fn in (olig.find_torsion, plig.torsion_masks):
+            t2, r2 = fn(lg["n_lig"], e2)
+            assert np.array_equal(t2, tr) and np.array_equal(r2, rr), ("find_torsion", i, fn.__module__)
+    print("  pinned find_torsion on 6 synthetic molecules (oracle and product)")
+    out.update(lig_edge_index=ei, ref_tor_edge_mask=tor_ref, ref_rot_node_mask=rot_ref)
+    # edge counts at the crystal pose (SURVEY.md section 8 quotes 9 002 pocket edges and 458 ligand radius edges)
+    rec = torch.from_numpy(pos[msk]).float()
+    e_aa = cluster.radius_graph(rec, 4.0, torch.zeros(rec.shape[0], dtype=torch.long), max_num_neighbors=1000).shape[1]
+    e_ll = cluster.radius_graph(torch.from_numpy(lig).float(), 5.0, torch.zeros(n_l, dtype=torch.long), max_num_neighbors=32).shape[1]
+    print(f"  edges at the crystal pose: pocket {e_aa}, ligand radius {e_ll}, ligand bonds {ei.shape[1]}")
+    out.update(e_aa=np.asarray(e_aa), e_ll=np.asarray(e_ll))
+    np.savez_compressed(os.path.join(HERE, "real_3dbs.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_geometry()
@@ -450,4 +552,5 @@ if __name__ == "__main__":
     golden_model_and_sampler()
     golden_pose_init()
     golden_pocket()
+    golden_real_complex()
     print("golden fixtures written to", HERE)
