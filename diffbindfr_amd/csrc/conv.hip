@@ -381,7 +381,8 @@ void launch_conv(const ConvArgs& a, hipStream_t st) {
   ConvArgs b = a;
   b.trace = nullptr;
   static const char* trace_path = getenv("DBFR_CONV_TRACE");   // developer: dump a per-tile timeline of one big launch
-  if (trace_path && a.w.K == 144 && a.w.W == 7776 && tiles >= 4096) {
+  static int trace_skip = getenv("DBFR_CONV_TRACE_SKIP") ? atoi(getenv("DBFR_CONV_TRACE_SKIP")) : 0;   // matching launches to pass over first
+  if (trace_path && a.w.K == 144 && a.w.W == 7776 && tiles >= 4096 && trace_skip-- <= 0) {
     const size_t nw = (size_t)TRACE_BLOCKS * 4 * TRACE_REC;
     unsigned long long* d = nullptr;
     if (hipMalloc(&d, nw * 8) == hipSuccess) {
