@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from . import synthetic
+from .tables import residue_tables
 from .packing import PackedBatch
 
 
@@ -38,7 +38,7 @@ class ComplexRecord:
     """Static host-side form of one complex: everything that does not change between poses."""
 
     def __init__(self, rec, tables=None):
-        tables = tables or synthetic.residue_tables()
+        tables = tables or residue_tables()
         g = lambda k: rec[k] if isinstance(rec, dict) else getattr(rec, k)
         meta = g("metastore") if (isinstance(rec, dict) and "metastore" in rec) or hasattr(rec, "metastore") else None
         rot = meta["rot_node_mask"] if meta is not None and "rot_node_mask" in meta else g("rot_node_mask")

@@ -17,11 +17,11 @@ import numpy as np
 import torch
 
 from . import lib as L
-from . import synthetic
+from .tables import residue_tables
 
 
 def _tables(dev):
-    T = synthetic.residue_tables()
+    T = residue_tables()
     t = lambda k, dt: torch.as_tensor(np.asarray(T[k])).to(device=dev, dtype=dt)
     return dict(chi_atoms14=t("chi_atoms14", torch.long), chi_mask=t("chi_mask", torch.float32),
                 torsion_edges=t("torsion_edges", torch.long), atom14_mask=t("atom14_mask", torch.bool),

@@ -22,18 +22,8 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import ligand
+from .tables import residue_tables  # noqa: F401  (re-exported: tests and tools use synthetic.residue_tables)
 import torch
-
-_TABLES = None
-
-
-def residue_tables():
-    global _TABLES
-    if _TABLES is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "residue_tables.npz")
-        _TABLES = {k: v for k, v in np.load(path).items()}
-    return _TABLES
-
 
 # BASELINE.json configs -> generator sizes
 CONFIGS = {
