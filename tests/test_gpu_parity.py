@@ -368,3 +368,20 @@ def test_oversized_inputs_are_rejected(setup, dev):
     sc = osched.step_scalars(osched.default_sample_cfg(), 0)
     with pytest.raises(L.DbfrError, match="256"):
         model(namespace_to(osampler.set_time(d, sc, 1), dev))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
+def test_random_ragged_batches_vs_oracle(setup, dev, case):
+    """Seeded fuzz: 1-4 graphs of random pocket / ligand sizes (2-40 ligand atoms, rigid ligands included), random
+    initial spread and denoise step (tools/fuzz_scores.py runs the long version)."""
+    rng = np.random.default_rng(1000 + case)
+    items = []
+    for _ in range(int(rng.integers(1, 5))):
+        na, nl = int(rng.integers(12, 160)), int(rng.integers(2, 40))
+        pk, lg = synthetic.make_pocket(rng, na), synthetic.make_ligand(rng, nl)
+        if rng.random() < 0.2:
+            lg["tor_edge_mask"][:] = False
+            lg["rot_node_mask"] = lg["rot_node_mask"][:0]
+        items.append((pk, lg) + synthetic.init_pose(rng, pk, lg, tr_sigma=float(rng.choice([0.5, 3.0, 10.0]))))
+    errs = _oracle_vs_hip_scores(setup, dev, synthetic.collate(items), step=int(rng.integers(0, 20)))
+    assert max(errs) < SCORE_RTOL, errs
