@@ -1,8 +1,14 @@
 """Developer script (GPU box): seeded fuzz of the HIP score network against the CPU oracle on random ragged batches.
     python tools/fuzz_scores.py [n_cases]
 Test infrastructure (imports oracle/)."""
-import sys, copy, numpy as np, torch
-sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import diffbindfr_amd as dba
 from diffbindfr_amd import synthetic
 from oracle import sampler as osampler, schedule as osched, score_model as sm
