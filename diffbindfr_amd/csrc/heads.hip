@@ -106,24 +106,35 @@ void launch_bond_attr(const float* x, int ldx, const int* b0, const int* b1, con
 }
 
 // torsion heads: tanh-MLP(96 -> 48 -> 1, no bias) * sqrt(score_norm2)
-__global__ void k_tor_final(const float* feat, Mlp2 w, const float* norm2, int scale, int n, float* out) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const float* f = feat + (size_t)k * w.in;
-  float o = 0.f;
-  for (int h = 0; h < w.hid; ++h) {
-    float a = 0.f;
-    for (int i = 0; i < w.in; ++i) a += w.w0t[i * w.hid + h] * f[i];
-    o += w.w1t[h] * tanhf(a);
+// tanh-MLP head of a torsion (tpscore.py:548-571): 2ns -> ns -> 1, no biases.  One hidden unit per thread (coalesced
+// weight rows), the torsion's feature row shared through LDS, hidden units summed in a fixed order (reproducible).
+#define TOR_PER_BLOCK 4
+__global__ __launch_bounds__(TOR_PER_BLOCK * NS) void k_tor_final(const float* feat, Mlp2 w, const float* norm2, int scale, int n,
+                                                                float* out) {
+  __shared__ float f[TOR_PER_BLOCK][2 * NS];
+  __shared__ float part[TOR_PER_BLOCK][NS];
+  const int sub = threadIdx.x / NS, h = threadIdx.x - sub * NS;
+  const int k = blockIdx.x * TOR_PER_BLOCK + sub;
+  const bool live = k < n;
+  for (int i = h; i < w.in; i += NS) f[sub][i] = live ? feat[(size_t)k * w.in + i] : 0.f;
+  __syncthreads();
+  float a = 0.f;
+  for (int i = 0; i < w.in; ++i) a += w.w0t[i * w.hid + h] * f[sub][i];
+  part[sub][h] = w.w1t[h] * tanhf(a);
+  __syncthreads();
+  if (h == 0 && live) {
+    float o = 0.f;
+    for (int q = 0; q < NS; ++q) o += part[sub][q];
+    if (scale) o *= sqrtf(norm2[k]);
+    out[k] = o;
   }
-  if (scale) o *= sqrtf(norm2[k]);
-  out[k] = o;
 }
 
 void launch_tor_final(const float* feat, const Mlp2& w, const float* norm2, int scale, int n, float* out,
                       hipStream_t st) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_tor_final, dim3((n + 63) / 64), dim3(64), 0, st, feat, w, norm2, scale, n, out);
+  hipLaunchKernelGGL(k_tor_final, dim3((n + TOR_PER_BLOCK - 1) / TOR_PER_BLOCK), dim3(TOR_PER_BLOCK * NS), 0, st, feat, w, norm2,
+                     scale, n, out);
 }
 
 // ------------------------------------------------------------------------------------------------ SDE step
