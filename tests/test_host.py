@@ -166,3 +166,35 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert int(out[s]) == C.sizeof(cls), s
         for f in fields[s]:
             assert int(out[f"{s}.{f}"]) == getattr(cls, f).offset, (s, f)
+
+
+def test_device_residue_tables_match_host_tables():
+    """csrc/residue_tables.inc (compiled into the kernels) and data/residue_tables.npz (host look-ups) come from the same
+    generator run: every integer table must agree."""
+    import re
+    inc = open(os.path.join(ROOT, "diffbindfr_amd", "csrc", "residue_tables.inc")).read()
+    T = synthetic.residue_tables()
+
+    def table(name):
+        m = re.search(r"RT_TABLE int " + name + r"((?:\[\d+\])+) = \{([^}]*)\};", inc)
+        assert m, name
+        shape = [int(x) for x in re.findall(r"\[(\d+)\]", m.group(1))]
+        return np.array([int(x) for x in m.group(2).split(",")]).reshape(shape)
+
+    assert np.array_equal(table("kAtom14ToGroup").reshape(21, 14), T["atom14_to_group"])
+    assert np.array_equal(table("kChiAtoms14"), T["chi_atoms14"])
+    assert np.array_equal(table("kChiMask"), T["chi_mask"].astype(int))
+    assert np.array_equal(table("kAtom14Mask"), T["atom14_mask"].astype(int))
+
+
+def test_f1_f2_entry_points_have_no_cpu_path():
+    from diffbindfr_amd import assemble, pocket
+    z = np.load(os.path.join(ROOT, "tests", "golden", "pocket.npz"))
+    with pytest.raises(L.DbfrError):
+        pocket.extract_templates(torch.from_numpy(z["aatype"]), torch.from_numpy(z["atom14_position"]).float())
+    rng = np.random.default_rng(0)
+    rec = synthetic.make_record(synthetic.make_pocket(rng, 40), synthetic.make_ligand(rng, 6), rng)
+    pb = assemble.assemble([assemble.ComplexRecord(rec)], 2, "cpu")          # packing itself is host/torch only
+    with pytest.raises(L.DbfrError):
+        assemble.init_poses(None, pb, dict(tor=torch.zeros(1), rot=torch.eye(3).repeat(2, 1, 1), tr=torch.zeros(2, 3),
+                                           sc=torch.zeros(pb.dims["NR"], 4)))
