@@ -18,9 +18,38 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const float* W, float* out, u
   f32x4 A[9], A2[9];
   const int t0 = SYNC ? ((wave & 3) * (n_tiles_w / 4)) : (blockIdx.x * 7 + wave * 131) % n_tiles_w;
   for (int s4 = 0; s4 < 9; ++s4) A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (t0 * 9 + s4) * 1024, 0));
-  if (DEPTH == 2) for (int s4 = 0; s4 < 9; ++s4) A2[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (((t0 + 1) % n_tiles_w) * 9 + s4) * 1024, 0));
+  if (DEPTH >= 2) for (int s4 = 0; s4 < 9; ++s4) A2[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (((t0 + 1) % n_tiles_w) * 9 + s4) * 1024, 0));
   f32x4 tot = {0, 0, 0, 0};
   __syncthreads();
+  if (DEPTH == 3) {   // two register sets used alternately, each re-loaded in place with the tile TWO ahead (no copies)
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long c0 = __builtin_readcyclecounter();
+    for (int i = 0; i < tiles; i += 2) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int tn = (t0 + i + half + 2) % n_tiles_w;
+        f32x4 acc[3];
+        for (int b = 0; b < 3; ++b) acc[b] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 9; ++s4) {
+          const f32x4 av = half ? A2[s4] : A[s4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bv[b][4 * s4 + q], acc[b], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (half) A2[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (tn * 9 + s4) * 1024, 0));
+          else A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (tn * 9 + s4) * 1024, 0));
+        }
+        for (int b = 0; b < 3; ++b) tot += acc[b];
+      }
+    }
+    unsigned long long c1 = __builtin_readcyclecounter();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * 64 * WAVES + threadIdx.x] = tot[0] + tot[1] + tot[2] + tot[3];
+    if (lane == 0) { cyc[blockIdx.x * 8 + wave] = c1 - c0; cyc[4096 + blockIdx.x * 8 + wave] = r1 - r0; }
+    return;
+  }
   if (SYNC >= 2 && wave >= 4) for (int k = 0; k < SYNC; ++k) __builtin_amdgcn_s_sleep(16);   // lag the second wave of every SIMD by SYNC x 1024 cycles
   unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long c0 = __builtin_readcyclecounter();
@@ -70,7 +99,9 @@ int main() {
   RUNZ(8, 0, 0, 1, 0, 0, 4, 3, 256, 486, "2 waves/SIMD, no loads, 64 nop cycles after every 12 MFMAs");
   RUNZ(8, 1, 0, 1, 0, 0, 4, 1, 256, 486, "2 waves/SIMD, streaming, s_sleep 1 after every 12 MFMAs");
   RUNZ(8, 1, 0, 1, 0, 0, 4, 2, 256, 486, "2 waves/SIMD, streaming, s_sleep 2 after every 12 MFMAs");
-  RUNX(4, 1, 0, 2, 0, 256, 486, "1 wave/SIMD, streaming, prefetch 2 tiles ahead");
+  RUNX(4, 1, 0, 3, 0, 256, 486, "1 wave/SIMD, streaming, two register sets (2 tiles in flight, no copies)");
+  RUNX(8, 1, 0, 3, 0, 256, 486, "2 waves/SIMD, streaming, two register sets (2 tiles in flight, no copies)");
+  RUNX(4, 1, 0, 2, 0, 256, 486, "1 wave/SIMD, streaming, prefetch 2 tiles ahead (with register copies)");
   RUN(4, 0, 0, 256, "1 wave/SIMD, no loads (ideal 3456)");
   RUN(4, 1, 1, 256, "1 wave/SIMD, loads of one fixed tile (L1 hits)");
   RUN(4, 1, 0, 256, "1 wave/SIMD, streaming W2 from L2");
