@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const float* W, float* out, u
   for (int b = 0; b < 3; ++b)
     for (int s = 0; s < 36; ++s) Bv[b][s] = 0.001f * (lane + b + s);
   f32x4 A[9], A2[9];
-  const int t0 = SYNC ? ((wave & 3) * (n_tiles_w / 4)) : (blockIdx.x * 7 + wave * 131) % n_tiles_w;
+  const int t0 = SYNC == 9 ? 0 : SYNC ? ((wave & 3) * (n_tiles_w / 4)) : (blockIdx.x * 7 + wave * 131) % n_tiles_w;
   for (int s4 = 0; s4 < 9; ++s4) A[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (t0 * 9 + s4) * 1024, 0));
   if (DEPTH >= 2) for (int s4 = 0; s4 < 9; ++s4) A2[s4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, lane * 16, (((t0 + 1) % n_tiles_w) * 9 + s4) * 1024, 0));
   f32x4 tot = {0, 0, 0, 0};
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(const float* W, float* out, u
   unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long c0 = __builtin_readcyclecounter();
   for (int i = 0; i < tiles; ++i) {
-    const int tn = SAME_TILE ? t0 : (t0 + i + DEPTH) % n_tiles_w;
+    const int tn = SAME_TILE == 1 ? t0 : SAME_TILE >= 2 ? (t0 + (i % SAME_TILE)) % n_tiles_w : (t0 + i + DEPTH) % n_tiles_w;
     f32x4 acc[3];
     for (int b = 0; b < 3; ++b) acc[b] = (f32x4){0, 0, 0, 0};
 #pragma unroll
@@ -99,6 +99,12 @@ int main() {
   RUNZ(8, 0, 0, 1, 0, 0, 4, 3, 256, 486, "2 waves/SIMD, no loads, 64 nop cycles after every 12 MFMAs");
   RUNZ(8, 1, 0, 1, 0, 0, 4, 1, 256, 486, "2 waves/SIMD, streaming, s_sleep 1 after every 12 MFMAs");
   RUNZ(8, 1, 0, 1, 0, 0, 4, 2, 256, 486, "2 waves/SIMD, streaming, s_sleep 2 after every 12 MFMAs");
+  RUNX(8, 1, 2, 1, 9, 256, 486, "2 waves/SIMD, ALL waves cycle over the same 2 tiles (18 KB per CU: L1-resident)");
+  RUNX(8, 1, 3, 1, 9, 256, 486, "2 waves/SIMD, ALL waves cycle over the same 3 tiles (27 KB per CU)");
+  RUNX(8, 1, 8, 1, 9, 256, 486, "2 waves/SIMD, ALL waves cycle over the same 8 tiles (72 KB per CU)");
+  RUN(8, 1, 4, 256, "2 waves/SIMD, cycling over 4 tiles per wave (288 KB per CU: L2, not L1)");
+  RUN(8, 1, 16, 256, "2 waves/SIMD, cycling over 16 tiles per wave (1.1 MB per CU)");
+  RUN(8, 1, 64, 256, "2 waves/SIMD, cycling over 64 tiles per wave (4.6 MB per CU)");
   RUNX(4, 1, 0, 3, 0, 256, 486, "1 wave/SIMD, streaming, two register sets (2 tiles in flight, no copies)");
   RUNX(8, 1, 0, 3, 0, 256, 486, "2 waves/SIMD, streaming, two register sets (2 tiles in flight, no copies)");
   RUNX(4, 1, 0, 2, 0, 256, 486, "1 wave/SIMD, streaming, prefetch 2 tiles ahead (with register copies)");
