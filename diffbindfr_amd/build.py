@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdbfr.so")
-SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "graph.hip", "heads.hip"]
+SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "graph.hip", "heads.hip", "export.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # conv: no SLP vectorisation -- it pairs the contraction FMAs of different edge blocks into v_pk_fma_f32 with a v_mov
 # shuffle per operand pair, which costs more vector-pipe slots next to the MFMAs than it saves and makes the kernel spill.
@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
         if verbose and r.stderr.strip():
             print(r.stderr)
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs)

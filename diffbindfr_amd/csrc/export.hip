@@ -1,0 +1,509 @@
+// Output side of the sampler: per-pose metrics on the device + PDB text on the host.
+// Replaces what complex_modeling (DiffBindFR/evaluation/export.py:106-312) does per pose in Python.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dbfr.h"
+#include "common.h"
+
+#define RT_TABLE __device__ const
+#include "residue_tables.inc"
+#undef RT_TABLE
+
+// ------------------------------------------------------------------------------------------------ device: metrics
+// A workgroup of 256 threads owns `ppb` consecutive (pose, frame) pairs -- as many as fit 256 residue rows (<= 25) -- so
+// that small pockets still fill the lanes; a pocket with more than 256 residues gets one pair per workgroup and is
+// walked in tiles of 256 rows.  The pocket rows of the workgroup's pairs are contiguous in the trajectory: they are
+// staged through LDS with coalesced float4 loads and consumed by one thread per residue.  Ligand poses sit in LDS for
+// the automorphism loop (waves over automorphisms, lanes over atoms).  All reductions run in a fixed order (bitwise
+// reproducible).  The kernel reads every trajectory byte exactly once: HBM-bound, algorithmic bytes =
+// 12 * (n_lig + 14 n_res) per (pose, frame); targets, masks and tables stay cache resident.
+#define PM_THREADS 256
+#define PM_MAX_PPB 25
+#define PM_LIG_LDS 6144          // floats: ppb * n_lig * 3 must fit
+#define PM_SMALL_LIG 128         // up to here: one lane per (pair, automorphism) instead of one wave
+#define PM_MAX_LIG (PM_LIG_LDS / 3)
+#define PM_NQ 10                 // per-residue partials: rmsd, has side chain, chi ok[4], chi exists[4]
+
+struct PmArgs {
+  dbfr_pose_metrics_in in;
+  dbfr_pose_metrics_out out;
+  int ppb;                       // (pose, frame) pairs per workgroup
+  long long n_pf;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+struct P3 { float x, y, z; };
+__device__ __forceinline__ P3 sub3(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float dotp(P3 a, P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// (sin, cos) of the dihedral a0-a1-a2-a3 the way AlphaFold's atom37_to_torsion_angles builds it: frame with origin a2,
+// x along a2-a1, a0 in the xy plane (eps 1e-8 under the roots), a3 expressed in it, (z, y) normalised.
+__device__ __forceinline__ void chi_sin_cos(P3 a0, P3 a1, P3 a2, P3 a3, float& s, float& c) {
+  P3 e0 = sub3(a2, a1), e1 = sub3(a0, a2);
+  float inv = 1.f / sqrtf(dotp(e0, e0) + 1e-8f);
+  e0 = {e0.x * inv, e0.y * inv, e0.z * inv};
+  float d = dotp(e0, e1);
+  e1 = {e1.x - e0.x * d, e1.y - e0.y * d, e1.z - e0.z * d};
+  inv = 1.f / sqrtf(dotp(e1, e1) + 1e-8f);
+  e1 = {e1.x * inv, e1.y * inv, e1.z * inv};
+  P3 e2 = {e0.y * e1.z - e0.z * e1.y, e0.z * e1.x - e0.x * e1.z, e0.x * e1.y - e0.y * e1.x};
+  P3 rel = sub3(a3, a2);
+  s = dotp(e2, rel);
+  c = dotp(e1, rel);
+  inv = 1.f / sqrtf(s * s + c * c + 1e-8f);
+  s *= inv;
+  c *= inv;
+}
+
+// metrics/angbin.py:11-29 with its argument order at :98-99 (fmod keeps the dividend's sign)
+__device__ __forceinline__ float ang_diff(float ang_pred, float ang_tgt) {
+  const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
+  // x = ang_tgt - ang_pred + pi lies in [-pi, 3 pi]: fmod(x, 2 pi) is x - 2 pi above 2 pi (exact, Sterbenz) and x otherwise
+  float x = ang_tgt - ang_pred + pi;
+  float d = (x >= two_pi ? x - two_pi : x) - pi;
+  return fminf(fmaxf(fabsf(d), 0.f), pi);
+}
+
+// Static description of one pocket row, built once per tile and shared by the workgroup's pairs (LDS):
+//   chi[k]   atom14 slots of the chi_k dihedral, 4 bits each (0 if the chi does not exist for this row)
+//   bits     [0..13] atom14 mask, [14..17] chi_k exists (type has it and its 4 atoms are present), [18..21] chi_k pi-periodic
+//   swap     atom14 slot of the other naming for slots 5..13, 4 bits each (36 bits)
+//   ang[k]   chi_k of the target structure
+struct RowInfo {
+  unsigned short chi[4];
+  unsigned bits;
+  unsigned long long swap;
+  float ang[4];
+};
+
+__global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[PM_THREADS * 42];      // pose rows; reused for the reduction partials
+  __shared__ float lig[PM_LIG_LDS];
+  __shared__ RowInfo info[PM_THREADS];
+  __shared__ float sums[PM_MAX_PPB][PM_NQ];
+  __shared__ float best_w[PM_MAX_PPB][PM_THREADS / 64];
+  __shared__ float cen[PM_MAX_PPB + 1][3];
+  __shared__ unsigned char hvy[PM_SMALL_LIG];
+  const dbfr_pose_metrics_in& in = a.in;
+  const long long pf0 = (long long)blockIdx.x * a.ppb;
+  const int npf = (int)min((long long)a.ppb, a.n_pf - pf0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float cx = in.center[0], cy = in.center[1], cz = in.center[2];
+
+  // ---- ligand: centroid distance and symmetry-corrected RMSD
+  if (a.out.centroid || a.out.lig_rmsd) {
+    const int nl3 = in.n_lig * 3;
+    const float* src = in.lig_traj + (size_t)pf0 * nl3;
+    for (int i = tid; i < npf * nl3; i += PM_THREADS) {
+      int c = i % 3;
+      lig[i] = src[i] + (c == 0 ? cx : (c == 1 ? cy : cz));
+    }
+    const bool small = in.n_lig <= PM_SMALL_LIG;
+    float* ligt = lig + npf * nl3;                       // small ligands: target + heavy-atom flags next to the poses
+    if (small) {
+      for (int i = tid; i < nl3; i += PM_THREADS) ligt[i] = in.lig_target[i];
+      for (int i = tid; i < in.n_lig; i += PM_THREADS) hvy[i] = !in.heavy_mask || in.heavy_mask[i];
+    }
+    __syncthreads();
+    if (small) {
+      // small ligands: one lane per (pair, coordinate) / per (pair, automorphism), serial over atoms -- no cross-lane traffic
+      if (a.out.centroid && tid < (npf + 1) * 3) {
+        const int q = tid / 3, c = tid - 3 * q;
+        const float* lp = lig + q * nl3;                                     // row npf: the target's centroid
+        float sacc = 0.f;
+        for (int i = 0; i < in.n_lig; ++i) sacc += lp[3 * i + c];
+        cen[q][c] = sacc / (float)in.n_lig;
+      }
+      if (a.out.lig_rmsd) {
+        for (int it = tid; it < npf * in.n_perm; it += PM_THREADS) {
+          const int q = it / in.n_perm, p = it - q * in.n_perm;
+          const float* lp = lig + q * nl3;
+          const int* perm = in.perms + (size_t)p * in.n_lig;
+          float acc = 0.f, cnt = 0.f;
+#pragma unroll 4
+          for (int i = 0; i < in.n_lig; ++i) {
+            const int j = perm[i];
+            const float w = (hvy[i] && hvy[j]) ? 1.f : 0.f;
+            const float dx = lp[3 * j] - ligt[3 * i], dy = lp[3 * j + 1] - ligt[3 * i + 1], dz = lp[3 * j + 2] - ligt[3 * i + 2];
+            if (w != 0.f) { acc += dx * dx + dy * dy + dz * dz; cnt += 1.f; }
+          }
+          tile[it] = sqrtf(acc / cnt);                   // npf * n_perm values; min taken below
+        }
+      }
+      __syncthreads();
+      if (tid < npf) {
+        if (a.out.centroid) {
+          float dx = cen[tid][0] - cen[npf][0], dy = cen[tid][1] - cen[npf][1], dz = cen[tid][2] - cen[npf][2];
+          a.out.centroid[pf0 + tid] = sqrtf(dx * dx + dy * dy + dz * dz);
+        }
+      }
+      if (a.out.lig_rmsd) {
+        // min over the automorphisms of each pair: chunks of up to PM_THREADS * 42 results were written above
+        if (tid < npf) {
+          float b = INFINITY;
+          for (int p = 0; p < in.n_perm; ++p) b = fminf(b, tile[tid * in.n_perm + p]);
+          a.out.lig_rmsd[pf0 + tid] = b;
+        }
+      }
+      __syncthreads();
+    } else {
+      // large ligands: waves over automorphisms, lanes over atoms
+      for (int q = 0; q < npf; ++q) {
+        const float* lp = lig + q * nl3;
+        if (a.out.centroid && wave == (q & 3)) {
+          float sx = 0, sy = 0, sz = 0, tx = 0, ty = 0, tz = 0;
+          for (int i = lane; i < in.n_lig; i += 64) {
+            sx += lp[3 * i]; sy += lp[3 * i + 1]; sz += lp[3 * i + 2];
+            tx += in.lig_target[3 * i]; ty += in.lig_target[3 * i + 1]; tz += in.lig_target[3 * i + 2];
+          }
+          sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+          tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+          if (lane == 0) {
+            float n = (float)in.n_lig;
+            float dx = sx / n - tx / n, dy = sy / n - ty / n, dz = sz / n - tz / n;
+            a.out.centroid[pf0 + q] = sqrtf(dx * dx + dy * dy + dz * dz);
+          }
+        }
+        if (a.out.lig_rmsd) {
+          float best = INFINITY;
+          for (int p = wave; p < in.n_perm; p += PM_THREADS / 64) {
+            const int* perm = in.perms + (size_t)p * in.n_lig;
+            float acc = 0.f, cnt = 0.f;
+            for (int i = lane; i < in.n_lig; i += 64) {
+              int j = perm[i];
+              if (!in.heavy_mask || (in.heavy_mask[i] && in.heavy_mask[j])) {
+                float dx = lp[3 * j] - in.lig_target[3 * i], dy = lp[3 * j + 1] - in.lig_target[3 * i + 1],
+                      dz = lp[3 * j + 2] - in.lig_target[3 * i + 2];
+                acc += dx * dx + dy * dy + dz * dz;
+                cnt += 1.f;
+              }
+            }
+            acc = wave_sum(acc);
+            cnt = wave_sum(cnt);
+            best = fminf(best, sqrtf(acc / cnt));      // lane 0 holds the sums
+          }
+          if (lane == 0) best_w[q][wave] = best;
+        }
+      }
+      if (a.out.lig_rmsd) {
+        __syncthreads();
+        if (tid < npf) {
+          float b = best_w[tid][0];
+          for (int w = 1; w < PM_THREADS / 64; ++w) b = fminf(b, best_w[tid][w]);
+          a.out.lig_rmsd[pf0 + tid] = b;
+        }
+      }
+    }
+  }
+  if (!(a.out.sc_rmsd || a.out.chi_rate || a.out.delta_chi)) return;
+
+  // ---- pocket: side-chain RMSD and chi differences, one thread per residue row
+  float acc[PM_NQ];
+  for (int k = 0; k < PM_NQ; ++k) acc[k] = 0.f;
+  const int seg = a.ppb > 1 ? in.n_res : PM_THREADS;
+  const float* psrc = in.prot_traj + (size_t)pf0 * in.n_res * 42;
+  for (int r0 = 0; r0 < (a.ppb > 1 ? 1 : in.n_res); r0 += PM_THREADS) {
+    const int trows = a.ppb > 1 ? in.n_res : min(PM_THREADS, in.n_res - r0);     // distinct target rows in this pass
+    const int rows = a.ppb > 1 ? npf * in.n_res : trows;                         // pose rows in this pass
+    __syncthreads();
+    {   // rows * 42 floats, contiguous; float2 keeps every row start aligned (42 is even)
+      const float2* s2 = reinterpret_cast<const float2*>(psrc + (size_t)r0 * 42);
+      float2* d2 = reinterpret_cast<float2*>(tile);
+      for (int i = tid; i < rows * 21; i += PM_THREADS) d2[i] = s2[i];
+    }
+    if (tid < trows) {
+      const int r = r0 + tid;
+      const int aa = in.aatype[r];
+      const float* tg = in.atom14_target + (size_t)r * 42;
+      const float* mk = in.atom14_target_mask + (size_t)r * 14;
+      RowInfo ri;
+      unsigned bits = 0;
+      for (int j = 0; j < 14; ++j) bits |= (mk[j] != 0.f ? 1u : 0u) << j;
+      unsigned long long sw = 0;
+      for (int j = 5; j < 14; ++j) sw |= (unsigned long long)kAtom14Swap[aa][j] << (4 * (j - 5));
+      for (int k = 0; k < 4; ++k) {
+        float ang = 0.f;
+        unsigned short packed = 0;
+        if (kChiMask[aa][k]) {
+          const int* ia = kChiAtoms14[aa][k];
+          P3 t4[4];
+          bool all = true;
+          for (int u = 0; u < 4; ++u) {
+            t4[u] = {tg[3 * ia[u]], tg[3 * ia[u] + 1], tg[3 * ia[u] + 2]};
+            packed |= (unsigned short)(ia[u] << (4 * u));
+            all = all && ((bits >> ia[u]) & 1u);
+          }
+          float ts, tc;
+          chi_sin_cos(t4[0], t4[1], t4[2], t4[3], ts, tc);
+          ang = atan2f(ts, tc);
+          if (all) bits |= 1u << (14 + k);
+          if (kChiPiPeriodic[aa][k]) bits |= 1u << (18 + k);
+        }
+        ri.chi[k] = packed;
+        ri.ang[k] = ang;
+      }
+      ri.bits = bits;
+      ri.swap = sw;
+      info[tid] = ri;
+    }
+    __syncthreads();
+    if (tid < rows) {
+      const int q = a.ppb > 1 ? tid / in.n_res : 0;
+      const int rl = a.ppb > 1 ? tid - q * in.n_res : tid;       // row inside the tile
+      const int r = r0 + rl;
+      const RowInfo ri = info[rl];
+      const float* pr = tile + tid * 42;
+      const float* tg = in.atom14_target + (size_t)r * 42;
+      // side chain: slots 5..13, both namings
+      float d2 = 0.f, d2a = 0.f, deno = 0.f;
+      for (int j = 5; j < 14; ++j) {
+        const int js = (int)((ri.swap >> (4 * (j - 5))) & 15u);
+        const float m = (float)((ri.bits >> j) & 1u), ma = (float)((ri.bits >> js) & 1u);
+        deno += m;
+        for (int c = 0; c < 3; ++c) {
+          float cc = c == 0 ? cx : (c == 1 ? cy : cz);
+          float p = (pr[3 * j + c] + cc) * m;
+          float t = (tg[3 * j + c] + cc) * m;
+          float ta = (tg[3 * js + c] + cc) * ma;
+          d2 += (t - p) * (t - p);
+          d2a += (ta - p) * (ta - p);
+        }
+      }
+      d2 = fminf(d2, d2a);
+      if ((ri.bits >> 5) & 0x1ffu) { acc[0] += sqrtf(d2 / (deno + 1e-6f)); acc[1] += 1.f; }
+      // chi angles
+      float dl[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 4; ++k) {
+        if (!((ri.bits >> (14 + k)) & 1u)) continue;
+        const unsigned pk = ri.chi[k];
+        P3 p4[4];
+        for (int u = 0; u < 4; ++u) {
+          const int s14 = (pk >> (4 * u)) & 15;
+          p4[u] = {pr[3 * s14] + cx, pr[3 * s14 + 1] + cy, pr[3 * s14 + 2] + cz};
+        }
+        float ps, pc;
+        chi_sin_cos(p4[0], p4[1], p4[2], p4[3], ps, pc);
+        const float pi = 3.14159265358979323846f;
+        const float ap = atan2f(ps, pc), at = ri.ang[k];
+        float d = ang_diff(ap, at);
+        if ((ri.bits >> (18 + k)) & 1u) d = fminf(d, ang_diff(ap, at > 0.f ? at - pi : at + pi));     // atan2(-sin, -cos)
+        dl[k] = d;
+        acc[6 + k] += 1.f;
+        if (d < in.chi_bound) acc[2 + k] += 1.f;
+      }
+      if (a.out.delta_chi) {
+        float4 v = {dl[0], dl[1], dl[2], dl[3]};
+        *reinterpret_cast<float4*>(a.out.delta_chi + ((size_t)(pf0 + q) * in.n_res + r) * 4) = v;
+      }
+    }
+  }
+  // ---- fixed-order reduction of the per-row partials over each pair's rows (partials overlay the pose tile)
+  __syncthreads();
+  float* part = tile;                                  // [PM_THREADS][PM_NQ + 1]
+  for (int k = 0; k < PM_NQ; ++k) part[tid * (PM_NQ + 1) + k] = acc[k];
+  __syncthreads();
+  if (tid < npf * PM_NQ) {
+    const int q = tid / PM_NQ, k = tid - q * PM_NQ;
+    float sacc = 0.f;
+    for (int i = 0; i < seg; ++i) sacc += part[(q * seg + i) * (PM_NQ + 1) + k];
+    sums[q][k] = sacc;
+  }
+  __syncthreads();
+  if (tid < npf) {
+    if (a.out.sc_rmsd) a.out.sc_rmsd[pf0 + tid] = sums[tid][0] / sums[tid][1];
+    if (a.out.chi_rate)
+      for (int k = 0; k < 4; ++k) a.out.chi_rate[(size_t)(pf0 + tid) * 4 + k] = sums[tid][2 + k] / sums[tid][6 + k];
+  }
+}
+
+extern "C" int dbfr_pose_metrics(const dbfr_pose_metrics_in* in, const dbfr_pose_metrics_out* out, void* hip_stream) {
+  if (!in || !out) { dbfr_set_error("null argument"); return DBFR_ERR_ARG; }
+  if (in->n_pose < 0 || in->n_frame < 0 || in->n_lig < 0 || in->n_res < 0) { dbfr_set_error("negative size"); return DBFR_ERR_ARG; }
+  const bool want_lig = out->centroid || out->lig_rmsd, want_prot = out->sc_rmsd || out->chi_rate || out->delta_chi;
+  if (want_lig && (!in->lig_traj || !in->lig_target || in->n_lig < 1)) { dbfr_set_error("ligand metrics need lig_traj / lig_target"); return DBFR_ERR_ARG; }
+  if (want_lig && in->n_lig > PM_MAX_LIG) { dbfr_set_error("ligand larger than 2048 atoms"); return DBFR_ERR_ARG; }
+  if (out->lig_rmsd && (in->n_perm < 1 || !in->perms)) { dbfr_set_error("lig_rmsd needs at least the identity automorphism"); return DBFR_ERR_ARG; }
+  if (want_prot && (!in->prot_traj || !in->atom14_target || !in->atom14_target_mask || !in->aatype || in->n_res < 1)) {
+    dbfr_set_error("pocket metrics need prot_traj / atom14_target / atom14_target_mask / aatype");
+    return DBFR_ERR_ARG;
+  }
+  if (want_prot && ((uintptr_t)in->prot_traj & 7)) { dbfr_set_error("prot_traj must be 8-byte aligned"); return DBFR_ERR_ARG; }
+  PmArgs a;
+  a.in = *in;
+  a.out = *out;
+  a.n_pf = (long long)in->n_pose * in->n_frame;
+  if (a.n_pf == 0 || !(want_lig || want_prot)) return DBFR_OK;
+  int ppb = PM_MAX_PPB;
+  if (want_prot) ppb = std::min(ppb, std::max(1, PM_THREADS / in->n_res));
+  if (want_lig) ppb = std::min(ppb, std::max(1, PM_LIG_LDS / (3 * in->n_lig) - 1));      // poses + the target in LDS
+  if (out->lig_rmsd && in->n_lig <= PM_SMALL_LIG) {
+    if (in->n_perm > PM_THREADS * 42) { dbfr_set_error("more than 10752 automorphisms"); return DBFR_ERR_ARG; }
+    ppb = std::min(ppb, std::max(1, PM_THREADS * 42 / in->n_perm));
+  }
+  a.ppb = ppb;
+  const long long blocks = (a.n_pf + ppb - 1) / ppb;
+  if (blocks > 0x7fffffffLL) { dbfr_set_error("too many (pose, frame) pairs for one launch"); return DBFR_ERR_ARG; }
+  hipLaunchKernelGGL(k_pose_metrics, dim3((unsigned)blocks), dim3(PM_THREADS), 0, (hipStream_t)hip_stream, a);
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host: PDB text
+#define RT_NAMES
+#define RT_TABLE static const
+namespace host_tables {
+#include "residue_tables.inc"
+}
+#undef RT_TABLE
+#undef RT_NAMES
+
+namespace {
+
+// druglib/utils/obj/protein.py:658-676: 1 -> A ... 26 -> Z, 27 -> AA, 28 -> BA, ...
+std::string chain_tag(int chain_index) {
+  long num = (long)chain_index;      // (chain_index + 1) - 1
+  std::string s;
+  while (num >= 0) {
+    s.push_back((char)('A' + num % 26));
+    num = num / 26 - 1;
+  }
+  return s;
+}
+
+struct Line {
+  char buf[160];
+  int n;
+};
+
+inline void pad80(std::string& out, const char* s, int n) {
+  out.append(s, (size_t)n);
+  if (n < 80) out.append((size_t)(80 - n), ' ');
+  out.push_back('\n');
+}
+
+// The text of one structure.  Coordinates are float32 values printed through double ("%8.3f" of the exactly converted
+// value, correctly rounded by glibc like Python's float formatting the reference relies on).
+void format_structure(const dbfr_pdb_topology& t, const std::vector<int>& row_of, const float* pos14, int model, int add_end,
+                      std::string& out) {
+  out.clear();
+  out.reserve((size_t)t.n_res * 9 * 81 + 256);
+  char line[192];
+  if (t.remark) pad80(out, t.remark, (int)strlen(t.remark));
+  long serial = 1;
+  const bool any_rows = pos14 != nullptr;
+  for (int i = 0; i < t.n_res; ++i) {
+    const int aa = t.aatype[i];
+    const std::string tag = chain_tag(t.chain_index[i]);
+    const char* rn = host_tables::kRestypeNames3[aa];
+    const int ri = t.residue_index[i];
+    const float* src14 = row_of[i] >= 0 ? pos14 + (size_t)row_of[i] * 42 : nullptr;
+    for (int a = 0; a < 37; ++a) {
+      if (t.atom37_mask[(size_t)i * 37 + a] < 0.5f) continue;
+      const char* atn = host_tables::kAtom37Names[a];
+      // Protein.pos_update with an atom14 array: atom37 slot a reads atom14 slot kAtom37ToAtom14[aa][a] (slot 0 for atoms
+      // outside the residue type's atom14 set, e.g. OXT).  Residues the pose does not cover went through
+      // Protein.to_pos14(True) first (export.py:262): masked by the type's atom14 set, so 'UNK' residues come out at 0.
+      float via14[3];
+      const float* p;
+      if (src14) p = src14 + 3 * host_tables::kAtom37ToAtom14[aa][a];
+      else if (!any_rows) p = t.atom37_pos + ((size_t)i * 37 + a) * 3;
+      else {
+        const int slot = host_tables::kAtom37ToAtom14[aa][a], a37 = host_tables::kAtom14ToAtom37[aa][slot];
+        const float m = (float)host_tables::kAtom14Mask[aa][slot] * t.atom37_mask[(size_t)i * 37 + a37];
+        for (int c = 0; c < 3; ++c) via14[c] = t.atom37_pos[((size_t)i * 37 + a37) * 3 + c] * m;
+        p = via14;
+      }
+      char name[8];
+      if (strlen(atn) == 4) snprintf(name, sizeof name, "%s", atn);
+      else snprintf(name, sizeof name, " %s", atn);
+      int n = snprintf(line, sizeof line, "ATOM  %5ld %-4s %3s %1s%4d    %8.3f%8.3f%8.3f%6.2f%6.2f          %2c  ", serial, name, rn,
+                       tag.c_str(), ri, (double)p[0], (double)p[1], (double)p[2], 1.0, t.b_factors[(size_t)i * 37 + a], atn[0]);
+      pad80(out, line, n);
+      ++serial;
+    }
+    if (i == t.n_res - 1 || t.chain_index[i] != t.chain_index[i + 1]) {
+      int n = snprintf(line, sizeof line, "TER   %5ld      %3s %1s%4d", serial, rn, tag.c_str(), ri);
+      pad80(out, line, n);
+      ++serial;
+    }
+  }
+  if (model >= 0) pad80(out, "ENDMDL", 6);
+  if (add_end) pad80(out, "END", 3);
+}
+
+int check_topology(const dbfr_pdb_topology* t, int n_rows, const int32_t* rows, const float* pos14, std::vector<int>& row_of) {
+  if (!t || t->n_res < 0 || (t->n_res > 0 && (!t->aatype || !t->atom37_pos || !t->atom37_mask || !t->residue_index || !t->chain_index ||
+                                              !t->b_factors))) {
+    dbfr_set_error("null topology field");
+    return DBFR_ERR_ARG;
+  }
+  for (int i = 0; i < t->n_res; ++i)
+    if (t->aatype[i] < 0 || t->aatype[i] > 20) { dbfr_set_error("Invalid residue type found, only allow natural AA."); return DBFR_ERR_ARG; }
+  row_of.assign((size_t)t->n_res, -1);
+  if (n_rows < 0 || (n_rows > 0 && !pos14)) { dbfr_set_error("pos14 missing"); return DBFR_ERR_ARG; }
+  if (n_rows > 0 && !rows && n_rows != t->n_res) { dbfr_set_error("rows == NULL needs n_rows == n_res"); return DBFR_ERR_ARG; }
+  for (int k = 0; k < n_rows; ++k) {
+    int r = rows ? rows[k] : k;
+    if (r < 0 || r >= t->n_res) { dbfr_set_error("row index out of range"); return DBFR_ERR_ARG; }
+    row_of[(size_t)r] = k;
+  }
+  return DBFR_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t dbfr_pdb_format(const dbfr_pdb_topology* topo, int32_t n_rows, const int32_t* rows, const float* pos14, int32_t model,
+                                   int32_t add_end, char* out, int64_t cap) {
+  std::vector<int> row_of;
+  int rc = check_topology(topo, n_rows, rows, pos14, row_of);
+  if (rc) return rc;
+  std::string s;
+  format_structure(*topo, row_of, pos14, model, add_end, s);
+  if ((int64_t)s.size() <= cap && out) memcpy(out, s.data(), s.size());
+  return (int64_t)s.size();
+}
+
+extern "C" int dbfr_pdb_write_files(const dbfr_pdb_topology* topo, int32_t n_rows, const int32_t* rows, const float* pos14, int32_t n_pose,
+                                    const char* const* paths, int32_t n_threads) {
+  std::vector<int> row_of;
+  int rc = check_topology(topo, n_rows, rows, pos14, row_of);
+  if (rc) return rc;
+  if (n_pose < 0 || (n_pose > 0 && !paths)) { dbfr_set_error("paths missing"); return DBFR_ERR_ARG; }
+  if (n_pose == 0) return DBFR_OK;
+  int hw = (int)std::thread::hardware_concurrency();
+  if (hw < 1) hw = 1;
+  int nt = n_threads > 0 ? n_threads : std::min(hw, (int)n_pose);
+  nt = std::max(1, std::min(nt, (int)n_pose));
+  std::atomic<int> next(0), failed(-1);
+  auto work = [&]() {
+    std::string s;
+    for (;;) {
+      int i = next.fetch_add(1);
+      if (i >= n_pose) break;
+      format_structure(*topo, row_of, pos14 + (size_t)i * n_rows * 42, -1, 1, s);
+      FILE* f = fopen(paths[i], "wb");
+      bool ok = f && fwrite(s.data(), 1, s.size(), f) == s.size();
+      if (f) ok = (fclose(f) == 0) && ok;
+      if (!ok) { int e = -1; failed.compare_exchange_strong(e, i); }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < nt; ++k) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+  if (failed.load() >= 0) { dbfr_set_error(std::string("cannot write ") + paths[failed.load()]); return DBFR_ERR_ARG; }
+  return DBFR_OK;
+}

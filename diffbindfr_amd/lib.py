@@ -61,10 +61,30 @@ class InitTape(C.Structure):
     _fields_ = [(n, vp) for n in ("tor_u", "rot", "tr", "sc_u")]
 
 
+class PoseMetricsIn(C.Structure):
+    _fields_ = [("n_pose", C.c_int32), ("n_frame", C.c_int32), ("n_lig", C.c_int32), ("n_res", C.c_int32),
+                ("lig_traj", C.c_void_p), ("prot_traj", C.c_void_p), ("lig_target", C.c_void_p),
+                ("atom14_target", C.c_void_p), ("atom14_target_mask", C.c_void_p), ("aatype", C.c_void_p),
+                ("n_perm", C.c_int32), ("perms", C.c_void_p), ("heavy_mask", C.c_void_p),
+                ("center", C.c_float * 3), ("chi_bound", C.c_float)]
+
+
+class PoseMetricsOut(C.Structure):
+    _fields_ = [("centroid", C.c_void_p), ("sc_rmsd", C.c_void_p), ("chi_rate", C.c_void_p), ("delta_chi", C.c_void_p),
+                ("lig_rmsd", C.c_void_p)]
+
+
+class PdbTopology(C.Structure):
+    _fields_ = [("n_res", C.c_int32), ("aatype", C.c_void_p), ("atom37_pos", C.c_void_p), ("atom37_mask", C.c_void_p),
+                ("residue_index", C.c_void_p), ("chain_index", C.c_void_p), ("b_factors", C.c_void_p),
+                ("remark", C.c_char_p)]
+
+
 # every symbol include/dbfr.h declares (tests check that the library exports all of them)
 SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
-           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_reduce_ln"]
+           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_reduce_ln",
+           "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files"]
 
 _lib = None
 
@@ -103,6 +123,10 @@ def load():
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i32]
     lib.dbfr_test_conv.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp]
     lib.dbfr_test_reduce_ln.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp]
+    lib.dbfr_pose_metrics.argtypes = [C.POINTER(PoseMetricsIn), C.POINTER(PoseMetricsOut), vp]
+    lib.dbfr_pdb_format.argtypes = [C.POINTER(PdbTopology), i32, vp, vp, i32, i32, vp, C.c_int64]
+    lib.dbfr_pdb_format.restype = C.c_int64
+    lib.dbfr_pdb_write_files.argtypes = [C.POINTER(PdbTopology), i32, vp, vp, i32, C.POINTER(C.c_char_p), i32]
     if lib.dbfr_abi_version() != 1:
         raise DbfrError("libdbfr ABI version mismatch")
     _lib = lib

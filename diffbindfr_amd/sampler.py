@@ -104,12 +104,14 @@ class DiffBindFRHIP(nn.Module):
         return pb.lig_pos.unsqueeze(0), a14.unsqueeze(0)
 
     @torch.no_grad()
-    def sample_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0):
+    def sample_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0,
+                         keep_on_device=False):
         """Records in, poses out: the reference's `_prepare_test_sample` x num_poses + collate + `sample`
         (inference_dataset.py:578-612, struct_init.py, scFlex.py:124-250) with everything per-pose on the device.
         ``records``: list of ``assemble.ComplexRecord`` (or reference-format per-complex dicts); ``poses``: int or
         per-complex list.  Both random tapes (initialisation, SDE noise) come from one torch device generator.
-        Returns list[G] of (lig [T,N_l,3], atom14 [T,N_r,14,3]) CPU tensors, complex-major."""
+        Returns list[G] of (lig [T,N_l,3], atom14 [T,N_r,14,3]) CPU tensors, complex-major; ``keep_on_device`` leaves them
+        in HBM (for ``export.pose_metrics``, which consumes them there)."""
         from . import assemble
         dev = torch.device(device)
         recs = [r if isinstance(r, assemble.ComplexRecord) else assemble.ComplexRecord(r) for r in records]
@@ -128,7 +130,7 @@ class DiffBindFRHIP(nn.Module):
                 for v in z.values():
                     v[s].zero_()
         lig, a14 = self.sample_packed(pb, z, visualize=visualize)
-        return self._split(pb, lig.cpu(), a14.cpu())
+        return self._split(pb, lig, a14) if keep_on_device else self._split(pb, lig.cpu(), a14.cpu())
 
     def _split(self, pb, lig, a14):
         lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()

@@ -211,6 +211,78 @@ int dbfr_extract_templates(int32_t n_res, const int32_t* aatype, const float* at
                            float* backbone_rots, float* default_frame, float* rigid_group_positions,
                            float* torsion_angle, void* hip_stream);
 
+/* ---- output side: what `complex_modeling`
+ * (DiffBindFR/evaluation/export.py:106-312) does with the trajectories dbfr_sample
+ * returns -- the per-pose metrics and the PDB text of every pose.                  */
+
+/* Per-(pose, frame) metrics over the trajectories of ONE complex, computed where the
+ * trajectories already are (device pointers, fp32):
+ *   centroid  |mean(lig + c) - mean(lig_target)|          metrics/centroid.py:6-14
+ *   sc_rmsd   side-chain RMSD, best of the two namings of the pi-symmetric groups,
+ *             mean over residues with a side chain        metrics/scrmsd.py:64-89
+ *   delta_chi |chi_pred - chi_target| per residue and chi (radians, wrapped as the
+ *             reference wraps it, best of the pi-periodic alternatives, 0 where the
+ *             chi does not exist)                         metrics/angbin.py:11-103
+ *   chi_rate  fraction of existing chi_k with delta below chi_bound (15 degrees in
+ *             the reference)                              evaluation/export.py:176-181
+ *   lig_rmsd  heavy-atom RMSD, minimum over the automorphisms `perms` of the ligand
+ *             graph                                       metrics/lrmsd.py:311-335
+ * center[3] (host) is the pocket centre the sampler's coordinates are relative to
+ * (add_center_pos, common/inference_dataset.py:57-63): it is added to both
+ * trajectories and to atom14_target for sc_rmsd; lig_target is absolute.           */
+typedef struct {
+  int32_t n_pose, n_frame, n_lig, n_res;
+  const float*   lig_traj;            /* [n_pose, n_frame, n_lig, 3]                   */
+  const float*   prot_traj;           /* [n_pose, n_frame, n_res, 14, 3]               */
+  const float*   lig_target;          /* [n_lig, 3]                                    */
+  const float*   atom14_target;       /* [n_res, 14, 3] pocket-centred like prot_traj  */
+  const float*   atom14_target_mask;  /* [n_res, 14] 0/1                               */
+  const int32_t* aatype;              /* [n_res] in [0, 20]                            */
+  int32_t        n_perm;              /* automorphisms (>= 1 when lig_rmsd is asked)   */
+  const int32_t* perms;               /* [n_perm, n_lig]: atom perms[p][a] of the pose is compared with target atom a */
+  const int32_t* heavy_mask;          /* [n_lig] 0/1 (atoms that count), or NULL = all */
+  float          center[3];
+  float          chi_bound;           /* radians                                       */
+} dbfr_pose_metrics_in;
+
+typedef struct {                      /* any pointer may be NULL = not wanted          */
+  float* centroid;                    /* [n_pose, n_frame]                             */
+  float* sc_rmsd;                     /* [n_pose, n_frame]                             */
+  float* chi_rate;                    /* [n_pose, n_frame, 4]                          */
+  float* delta_chi;                   /* [n_pose, n_frame, n_res, 4]                   */
+  float* lig_rmsd;                    /* [n_pose, n_frame]                             */
+} dbfr_pose_metrics_out;
+
+int dbfr_pose_metrics(const dbfr_pose_metrics_in* in, const dbfr_pose_metrics_out* out, void* hip_stream);
+
+/* PDB text of a protein (host code, all pointers host): byte-for-byte what
+ * Protein.pos_update(pos14).to_pdb() writes (druglib/utils/obj/protein.py:478-537,
+ * 678-800).  The static part of a structure is the topology; a pose replaces the
+ * atom14 coordinates of `rows` (the pocket residues inside the protein,
+ * evaluation/export.py:261-268).                                                  */
+typedef struct {
+  int32_t        n_res;
+  const int32_t* aatype;              /* [n_res] in [0, 20] (20 = 'UNK')               */
+  const float*   atom37_pos;          /* [n_res, 37, 3] coordinates of the input structure */
+  const float*   atom37_mask;         /* [n_res, 37] atoms present (>= 0.5)            */
+  const int32_t* residue_index;       /* [n_res] PDB residue numbers                   */
+  const int32_t* chain_index;         /* [n_res] 0-based chain ids (A..Z, AA, BA, ...) */
+  const double*  b_factors;           /* [n_res, 37]                                   */
+  const char*    remark;              /* first line, or NULL for none                  */
+} dbfr_pdb_topology;
+
+/* Formats one structure into out (capacity cap bytes, no terminating NUL needed) and
+ * returns the byte count; if cap is too small nothing is written and the required
+ * count is returned.  n_rows == 0: the topology's own coordinates.  rows == NULL
+ * with n_rows == n_res: pos14 covers every residue in order.  model < 0: no ENDMDL. */
+int64_t dbfr_pdb_format(const dbfr_pdb_topology* topo, int32_t n_rows, const int32_t* rows, const float* pos14,
+                        int32_t model, int32_t add_end, char* out, int64_t cap);
+
+/* Writes n_pose files: paths[i] receives the structure with pos14[i] ([n_pose, n_rows,
+ * 14, 3]) on n_threads host threads (<= 0: one per pose up to the core count).      */
+int dbfr_pdb_write_files(const dbfr_pdb_topology* topo, int32_t n_rows, const int32_t* rows, const float* pos14,
+                         int32_t n_pose, const char* const* paths, int32_t n_threads);
+
 /* Synchronises the stream and returns the device-side status word of the last
  * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
  * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last

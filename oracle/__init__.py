@@ -27,13 +27,16 @@ algorithm, each function citing the reference ``file:line`` it follows
 * ``pocket``        -- SURVEY 8(f) row f2: extract_chi_and_template, make_torsion_mask,
                        build_torsion_edges, PocketFeaturizer (prot_math.py,
                        datasets/Docking/utils.py, pocket_pipeline.py).
+* ``export``        -- SURVEY 8(f) row f3: the per-pose metrics of complex_modeling
+                       (DiffBindFR/metrics/{centroid,scrmsd,angbin,lrmsd}.py) and the PDB
+                       text of Protein.pos_update + to_pdb (druglib/utils/obj/protein.py).
 
 Pinning status (see DESIGN.md "Oracle"):
 
 * Every function whose reference source imports in the build container
   (geometry, schedule, embeddings, LayerNorm, bipartite graph, the whole
   ``tpscore.py`` / ``scFlex.py`` glue, the real-time pose transforms of
-  ``struct_init.py`` and the reference's own ``druglib.data`` collate) is checked against the reference's own
+  ``struct_init.py``, the reference's own ``druglib.data`` collate, the output-side metrics and ``to_pdb``) is checked against the reference's own
   source by ``tests/golden/make_golden.py`` (run in the build container only)
   and frozen as fixtures under ``tests/golden/``.
 * The e3nn / torch_cluster / torch_scatter arithmetic lives in un-vendored,
@@ -42,4 +45,8 @@ Pinning status (see DESIGN.md "Oracle"):
   tests or golden vectors for it => **parity unpinned at that boundary**: it is
   restated from the published algorithms and validated by property tests
   (SE(3) equivariance, Wigner-3j invariance, known-answer values) only.
+* ``export.chi_sin_cos`` restates openfold's ``atom37_to_torsion_angles`` (the
+  reference's ``chi_differ`` calls it; openfold is absent offline) => **parity
+  unpinned** for that call; cross-checked against the chi angles of the
+  reference-pinned ``extract_chi_and_template`` (tests/test_export.py).
 """

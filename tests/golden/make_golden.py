@@ -544,6 +544,172 @@ def golden_real_complex():
     np.savez_compressed(os.path.join(HERE, "real_3dbs.npz"), **out)
 
 
+# --------------------------------------------------------------------------- 8. output side
+def _parse_sdf_elements(path):
+    L = open(path).read().split("\n")
+    na = int(L[3][0:3])
+    return [L[4 + i][31:34].strip() for i in range(na) if L[4 + i][31:34].strip() != "H"]
+
+
+def _load_ref_export():
+    """The reference's own output-side functions: druglib/utils/obj/protein.py (Protein, to_pdb) and the leaf files of
+    DiffBindFR/metrics that import without rdkit / openfold (centroid, scrmsd, lrmsd.symm_rmsd)."""
+    import contextlib
+    import importlib.util
+    for nm in ["Bio.PDB.ResidueDepth", "Bio.PDB.DSSP", "Bio.PDB.Model", "druglib.ops", "druglib.ops.dssp",
+               "druglib.ops.msms", "druglib.alerts", "rdkit.Chem.rdFMCS"]:
+        if nm not in sys.modules:
+            sys.modules[nm] = ref_shims._Anything(nm)
+    import druglib
+    druglib.__version__ = "1.0.0"
+    druglib.time_limit = lambda seconds: contextlib.nullcontext()
+    prot = ref_shims._load("druglib.utils.obj.protein", "utils/obj/protein.py")
+    mods = {}
+    for leaf in ("centroid", "scrmsd", "lrmsd"):
+        spec = importlib.util.spec_from_file_location("ref_metrics_" + leaf,
+                                                      os.path.join(ref_shims.COPY, "DiffBindFR", "metrics", leaf + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[leaf] = m
+    src = open(os.path.join(ref_shims.REF, "DiffBindFR", "common", "inference_dataset.py")).read()
+    a = src.index("def add_center_pos(")
+    env = {"Tensor": torch.Tensor}
+    exec(compile(src[a: src.index("# EValuation and Inference Data Container")], "inference_dataset.py", "exec"), env)
+    return prot, mods, env["add_center_pos"]
+
+
+def golden_export():
+    """Row f3: per-pose metrics + PDB text of `complex_modeling` (DiffBindFR/evaluation/export.py:106-312) on the 3DBS
+    example: protein = the residues within 20 A of the crystal ligand (two artificial chains), pocket = within 12 A."""
+    print("[export 3DBS]")
+    from oracle import export as oex
+    prot, mods, add_center = _load_ref_export()
+    pc = ns.pc
+    ex = os.path.join(ref_shims.REF, "examples", "forward")
+    lig, bonds = _parse_sdf_heavy(os.path.join(ex, "3dbs_protein_crystal.sdf"))
+    elements = _parse_sdf_elements(os.path.join(ex, "3dbs_protein_crystal.sdf"))
+    lig = lig.astype(np.float32)
+    bf_of = {}
+    for l in open(os.path.join(ex, "3dbs_protein.pdb")):
+        if l.startswith("ATOM"):
+            bf_of.setdefault((l[21], int(l[22:26]), l[26], l[12:16].strip()), float(l[60:66]))
+    aatype, pos37, m37, resid, bfac, in_pocket = [], [], [], [], [], []
+    for key, rn, atoms in _parse_pdb_residues(os.path.join(ex, "3dbs_protein.pdb")):
+        if rn not in pc.restype_3to1:
+            continue
+        P = np.array(list(atoms.values()))
+        dmin = np.linalg.norm(P[:, None] - lig[None], axis=-1).min()
+        if dmin >= 20.0:
+            continue
+        aatype.append(pc.restype_order[pc.restype_3to1[rn]])
+        pos37.append([atoms.get(a, [0.0, 0.0, 0.0]) for a in pc.atom_types])
+        m37.append([float(a in atoms) for a in pc.atom_types])
+        bfac.append([bf_of.get(key + (a,), 0.0) for a in pc.atom_types])
+        resid.append(key[1])
+        in_pocket.append(dmin < 12.0)
+    aatype = np.asarray(aatype, np.int64)
+    pos37 = np.asarray(pos37, np.float32)
+    m37 = np.asarray(m37, np.float32)
+    bfac = np.asarray(bfac, np.float64)
+    resid = np.asarray(resid, np.int64)
+    pocket_mask = np.asarray(in_pocket)
+    n = aatype.shape[0]
+    chain = (np.arange(n) >= n // 2).astype(np.int64) * 27             # chains 'A' and 'BA' (int_id_to_str_id)
+    aatype[3] = 20                                                      # one unknown residue -> 'UNK'
+    for r in (n - 1, int(np.nonzero(pocket_mask)[0][-1])):              # terminal OXT: atom37 slot 36 has no atom14 slot, so
+        m37[r, 36] = 1.0                                                # pos_update writes it at slot 0's (N) coordinates
+        pos37[r, 36] = pos37[r, 2] + np.float32(1.2)
+    print(f"  protein {n} residues / {int(m37.sum())} atoms, pocket {int(pocket_mask.sum())} residues, ligand {lig.shape[0]}")
+    remark = "REMARK   1 CREATED WITH MDLDruglib 1.0.0, 2024-11-01"
+    P = prot.Protein(name="3dbs", atom_positions=pos37, aatype=aatype, atom_mask=m37, residue_index=resid, b_factors=bfac,
+                     chain_index=chain, remark=remark, pocket_mask=pocket_mask)
+    pocket = prot.Protein(name="3dbs_pkt", atom_positions=pos37[pocket_mask], aatype=aatype[pocket_mask],
+                          atom_mask=m37[pocket_mask], residue_index=resid[pocket_mask], b_factors=bfac[pocket_mask],
+                          chain_index=chain[pocket_mask], remark=remark)
+    # ---- trajectories: pocket-centred like the sampler's output (Decentration, pocket_pipeline.py:276-300)
+    tgt14, tmask = pocket.to_pos14(True)
+    tmask = tmask[..., 0]
+    center = torch.from_numpy(tgt14[tmask > 0].mean(0)).float()
+    tgt14_c = torch.from_numpy(tgt14).float() - center * torch.from_numpy(tmask)[..., None].float()
+    seq = torch.from_numpy(aatype[pocket_mask])
+    rng = np.random.default_rng(31)
+    n_pose, n_frame = 4, 3
+    sig = np.array([0.0, 0.05, 0.4, 1.5], np.float32)[:, None, None, None, None] * np.array([1.0, 0.5, 0.25], np.float32)[None, :, None, None, None]
+    prot_traj = tgt14_c[None, None] + torch.from_numpy(rng.standard_normal((n_pose, n_frame) + tgt14.shape).astype(np.float32) * sig)
+    swap = torch.from_numpy(T["atom14_swap"]).long()[seq]
+    prot_traj[1, 2] = torch.gather(tgt14_c, 1, swap[..., None].expand(-1, -1, 3))   # the other naming: sc-rmsd must be 0
+    prot_traj = prot_traj * torch.from_numpy(tmask)[None, None, :, :, None].float()
+    lig_c = torch.from_numpy(lig) - center
+    lig_traj = lig_c[None, None] + torch.from_numpy(rng.standard_normal((n_pose, n_frame) + lig.shape).astype(np.float32) * sig[..., 0, :, :] * 2)
+    out = dict(aatype=aatype, atom37_pos=pos37, atom37_mask=m37, residue_index=resid, chain_index=chain, b_factors=bfac,
+               pocket_mask=pocket_mask, center=npy(center), prot_traj=npy(prot_traj), lig_traj=npy(lig_traj), lig_pos=lig,
+               target_atom14=npy(tgt14_c), target_atom14_mask=tmask, remark=np.asarray(remark))
+    # ---- metrics exactly as complex_modeling calls them (export.py:139-195)
+    lt, pt = add_center(lig_traj, center), add_center(prot_traj, center)
+    close(oex.add_center_pos(lig_traj, center), lt, 0.0, "add_center_pos")
+    cen_ref = mods["centroid"].calc_lig_centroid(lt, torch.from_numpy(lig).float())
+    close(oex.calc_lig_centroid(lt, torch.from_numpy(lig).float()), cen_ref, 0.0, "calc_lig_centroid")
+    tm = torch.from_numpy(tmask).float()
+    sc_ref = mods["scrmsd"].sidechain_rmsd(pt, add_center(tgt14_c, center), tm, seq)
+    close(oex.sidechain_rmsd(pt, oex.add_center_pos(tgt14_c, center), tm, seq, T), sc_ref, 0.0, "sidechain_rmsd")
+    assert float(sc_ref[1, 2]) < 1e-5 and float(sc_ref[0, 0]) < 1e-5, "swapped naming / identical pose"
+    alt_ref = mods["scrmsd"].make_altern_atom14(tgt14_c, tm, seq)
+    alt = oex.make_altern_atom14(tgt14_c, tm, seq, T)
+    close(alt[0], alt_ref[0], 0.0, "make_altern_atom14 pos")
+    close(alt[1], alt_ref[1], 0.0, "make_altern_atom14 mask")
+    out.update(ref_centroid=npy(cen_ref), ref_sc_rmsd=npy(sc_ref))
+    # ---- symmetry-corrected ligand RMSD: the reference's graph matching gives the automorphisms (lrmsd.py:287-335)
+    el_ids = np.asarray([sorted(set(elements)).index(e) for e in elements], np.int64)
+    n_l = lig.shape[0]
+    ei = np.asarray(sorted([(a, b) for a, b in bonds] + [(b, a) for a, b in bonds], key=lambda e: e[0] * n_l + e[1]), np.int64).T
+    nxg = ns.torch_utils.to_nx(el_ids, ei)
+    perms_ref = ns.torch_utils.match_graphs(nxg, nxg, keep_self=True)
+    ha = np.ones(n_l, bool)
+    ha[5] = False                                                                 # one atom flagged as hydrogen-like
+    rm_ref = mods["lrmsd"].symm_rmsd(nxg, ha, lig, npy(lt))
+    rm = oex.symm_rmsd(perms_ref, ha, lig, npy(lt))
+    close(rm, rm_ref, 0.0, "symm_rmsd")
+    print(f"  ligand automorphisms: {len(perms_ref)}")
+    out.update(lig_elements=el_ids, lig_edge_index=ei, ha_mask=ha, ref_perms=np.stack([p[0] for p in perms_ref]),
+               ref_symm_rmsd=npy(rm_ref))
+    # ---- PDB text: prot_final.pdb / pkt_final.pdb of export.py:261-274 for two poses
+    texts = {}
+    for pid in (0, 3):
+        fp14, _ = P.to_pos14(True)
+        fp14[pocket_mask] = npy(pt[pid, -1])
+        ref_full = P.pos_update(fp14, None, False).to_pdb()
+        ref_pkt = pocket.pos_update(npy(pt[pid, -1]), None, False).to_pdb()
+        mine_full = oex.pose_pdb(aatype, pos37, m37, resid, chain, bfac, np.nonzero(pocket_mask)[0], npy(pt[pid, -1]), T, remark)
+        mine_pkt = oex.to_pdb(aatype[pocket_mask], oex.pos14_to_pos37(aatype[pocket_mask], npy(pt[pid, -1]), m37[pocket_mask], T),
+                              m37[pocket_mask], resid[pocket_mask], chain[pocket_mask], bfac[pocket_mask], T, remark)
+        assert mine_full == ref_full, f"to_pdb (protein, pose {pid})"
+        assert mine_pkt == ref_pkt, f"to_pdb (pocket, pose {pid})"
+        texts[f"ref_pdb_full_{pid}"] = np.frombuffer(ref_full.encode(), np.uint8)
+        texts[f"ref_pdb_pkt_{pid}"] = np.frombuffer(ref_pkt.encode(), np.uint8)
+    print(f"  pinned to_pdb on 2 poses x (protein {len(ref_full)} B, pocket {len(ref_pkt)} B)")
+    out.update(texts)
+    # a small synthetic strip: >26 chains, negative / 4-digit residue numbers, serial numbers past 99999 are not
+    # reachable at this size, unknown residues
+    r2 = np.random.default_rng(7)
+    n2 = 60
+    aa2 = r2.integers(0, 21, n2)
+    m2 = (T["atom37_mask"][aa2] * (r2.random((n2, 37)) > 0.1)).astype(np.float32)
+    p2 = (r2.standard_normal((n2, 37, 3)) * np.array([5.0, 80.0, 900.0])).astype(np.float32)
+    p2[0, 0] = [0.0005, -0.0005, 1234.5675]
+    p2[1, 0] = [0.0625, -9999.9995, 0.125]
+    ch2 = np.sort(r2.integers(0, 30, n2))
+    ri2 = r2.integers(-50, 3000, n2)
+    bf2 = r2.random((n2, 37)) * 120
+    S = prot.Protein(name="strip", atom_positions=p2, aatype=aa2, atom_mask=m2, residue_index=ri2, b_factors=bf2, chain_index=ch2,
+                     remark=None)
+    ref2 = S.to_pdb().split("\n", 1)[1]                      # drop the dated REMARK line
+    mine2 = oex.to_pdb(aa2, p2, m2, ri2, ch2, bf2, T, None)
+    assert mine2 == ref2, "to_pdb (synthetic strip)"
+    out.update(strip_aatype=aa2, strip_mask=m2, strip_pos=p2, strip_chain=ch2, strip_resid=ri2, strip_bfac=bf2,
+               ref_pdb_strip=np.frombuffer(ref2.encode(), np.uint8))
+    np.savez_compressed(os.path.join(HERE, "export.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_geometry()
@@ -553,4 +719,5 @@ if __name__ == "__main__":
     golden_pose_init()
     golden_pocket()
     golden_real_complex()
+    golden_export()
     print("golden fixtures written to", HERE)

@@ -153,7 +153,10 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     import ctypes as C
     import subprocess
     fields = {"dbfr_batch": ["G", "max_nr", "lig_ptr", "rot_mask_off", "sc_ptr"], "dbfr_step": ["t", "sc_gsdt"],
-              "dbfr_model_cfg": ["ns", "emb_scale", "no_sc_torsion"], "dbfr_tensor": ["numel"], "dbfr_noise": ["z_sc"]}
+              "dbfr_model_cfg": ["ns", "emb_scale", "no_sc_torsion"], "dbfr_tensor": ["numel"], "dbfr_noise": ["z_sc"],
+              "dbfr_pose_metrics_in": ["n_res", "lig_traj", "aatype", "n_perm", "perms", "heavy_mask", "center", "chi_bound"],
+              "dbfr_pose_metrics_out": ["centroid", "delta_chi", "lig_rmsd"],
+              "dbfr_pdb_topology": ["n_res", "aatype", "b_factors", "remark"]}
     body = "".join(f'printf("{s} %zu\\n", sizeof({s}));' + "".join(f'printf("{s}.{f} %zu\\n", offsetof({s},{f}));' for f in fs)
                    for s, fs in fields.items())
     src = tmp_path / "o.c"
@@ -161,7 +164,8 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     exe = tmp_path / "o"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
-    mirror = {"dbfr_batch": L.Batch, "dbfr_step": L.Step, "dbfr_model_cfg": L.ModelCfg, "dbfr_tensor": L.Tensor, "dbfr_noise": L.Noise}
+    mirror = {"dbfr_batch": L.Batch, "dbfr_step": L.Step, "dbfr_model_cfg": L.ModelCfg, "dbfr_tensor": L.Tensor, "dbfr_noise": L.Noise,
+              "dbfr_pose_metrics_in": L.PoseMetricsIn, "dbfr_pose_metrics_out": L.PoseMetricsOut, "dbfr_pdb_topology": L.PdbTopology}
     for s, cls in mirror.items():
         assert int(out[s]) == C.sizeof(cls), s
         for f in fields[s]:
@@ -185,6 +189,15 @@ def test_device_residue_tables_match_host_tables():
     assert np.array_equal(table("kChiAtoms14"), T["chi_atoms14"])
     assert np.array_equal(table("kChiMask"), T["chi_mask"].astype(int))
     assert np.array_equal(table("kAtom14Mask"), T["atom14_mask"].astype(int))
+    assert np.array_equal(table("kAtom37ToAtom14"), T["atom37_to_atom14"])
+    assert np.array_equal(table("kAtom14ToAtom37"), T["atom14_to_atom37"])
+    assert np.array_equal(table("kAtom37Mask"), T["atom37_mask"].astype(int))
+    assert np.array_equal(table("kChiPiPeriodic"), T["chi_pi_periodic"].astype(int))
+    assert np.array_equal(table("kAtom14Swap"), T["atom14_swap"])
+    names = re.search(r"kAtom37Names\[37\]\[5\] = \{([^}]*)\};", inc).group(1).replace('"', "").split(", ")
+    assert names == [str(a) for a in T["atom37_names"]]
+    res3 = re.search(r"kRestypeNames3\[21\]\[4\] = \{([^}]*)\};", inc).group(1).replace('"', "").split(", ")
+    assert res3 == [str(a) for a in T["restype_names3"]]
 
 
 def test_f1_f2_entry_points_have_no_cpu_path():
