@@ -19,29 +19,40 @@
 #undef RT_TABLE
 
 // ------------------------------------------------------------------------------------------------ device: metrics
-// A workgroup of 256 threads owns `ppb` consecutive (pose, frame) pairs -- as many as fit 256 residue rows (<= 25) -- so
-// that small pockets still fill the lanes; a pocket with more than 256 residues gets one pair per workgroup and is
-// walked in tiles of 256 rows.  The pocket rows of the workgroup's pairs are contiguous in the trajectory: they are
-// staged through LDS with coalesced float4 loads and consumed by one thread per residue.  Ligand poses sit in LDS for
-// the automorphism loop (waves over automorphisms, lanes over atoms).  All reductions run in a fixed order (bitwise
-// reproducible).  The kernel reads every trajectory byte exactly once: HBM-bound, algorithmic bytes =
-// 12 * (n_lig + 14 n_res) per (pose, frame); targets, masks and tables stay cache resident.
+// A workgroup of 256 threads owns `ppb` consecutive (pose, frame) pairs -- as many as fit PM_ROWS = 64 pocket rows -- or
+// one pair walked in 64-row tiles when the pocket is larger.  Pocket rows of the workgroup's pairs are contiguous in the
+// trajectory: staged through LDS with coalesced loads (168 B per row), then FOUR threads per residue row: thread k of a
+// row owns chi_k and a quarter of the side-chain slots, the quad combines with DPP.  Static per-row data (chi atom
+// slots, masks, the other naming's slots, target chi angles) is built once per tile into LDS and shared by the pairs.
+// Ligand poses sit in LDS for the automorphism loop: one lane per (pair, automorphism) for ligands up to 128 atoms,
+// one wave per automorphism above.  All reductions run in a fixed order (bitwise reproducible).  The kernel reads every
+// trajectory byte exactly once: HBM-bound by construction, algorithmic bytes = 12 * (n_lig + 14 n_res) per (pose, frame);
+// targets, masks and tables stay cache resident.  The ligand half and the pocket half run as two launches (different
+// pairs per workgroup); the pocket launch holds 15 KB of LDS per workgroup => 8 workgroups (32 waves) per CU.
 #define PM_THREADS 256
+#define PM_ROWS 64               // pocket rows per tile (4 threads each)
 #define PM_MAX_PPB 25
-#define PM_LIG_LDS 6144          // floats: ppb * n_lig * 3 must fit
+#define PM_LIG_LDS 3072          // floats of ligand coordinates in LDS
 #define PM_SMALL_LIG 128         // up to here: one lane per (pair, automorphism) instead of one wave
 #define PM_MAX_LIG (PM_LIG_LDS / 3)
-#define PM_NQ 10                 // per-residue partials: rmsd, has side chain, chi ok[4], chi exists[4]
 
 struct PmArgs {
   dbfr_pose_metrics_in in;
   dbfr_pose_metrics_out out;
   int ppb;                       // (pose, frame) pairs per workgroup
+  int small;                     // ligand path: 1 = lane per (pair, automorphism)
   long long n_pf;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum over the 4 lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]); every lane gets the same value
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
   return v;
 }
 
@@ -77,23 +88,21 @@ __device__ __forceinline__ float ang_diff(float ang_pred, float ang_tgt) {
   return fminf(fmaxf(fabsf(d), 0.f), pi);
 }
 
-// Static description of one pocket row, built once per tile and shared by the workgroup's pairs (LDS):
-//   chi[k]   atom14 slots of the chi_k dihedral, 4 bits each (0 if the chi does not exist for this row)
-//   bits     [0..13] atom14 mask, [14..17] chi_k exists (type has it and its 4 atoms are present), [18..21] chi_k pi-periodic
-//   swap     atom14 slot of the other naming for slots 5..13, 4 bits each (36 bits)
-//   ang[k]   chi_k of the target structure
+// Static description of one pocket row, built once per tile and shared by the workgroup's pairs (LDS)
 struct RowInfo {
-  unsigned short chi[4];
-  unsigned bits;
-  unsigned long long swap;
-  float ang[4];
+  unsigned short chi[4];     // atom14 slots of the chi_k dihedral, 4 bits each
+  unsigned char flag[4];     // bit 0: chi_k exists (type has it and its 4 atoms are present), bit 1: pi-periodic
+  unsigned mask14;           // atoms present
+  unsigned swap_lo;          // atom14 slot of the other naming for slots 5..12, 4 bits each
+  unsigned swap_hi;          // ... and for slot 13
+  float ang[4];              // chi_k of the target structure
 };
 
 __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
-  __shared__ __attribute__((aligned(16))) float tile[PM_THREADS * 42];      // pose rows; reused for the reduction partials
-  __shared__ float lig[PM_LIG_LDS];
-  __shared__ RowInfo info[PM_THREADS];
-  __shared__ float sums[PM_MAX_PPB][PM_NQ];
+  __shared__ __attribute__((aligned(16))) float tile[PM_ROWS * 42];         // pose rows; reused for per-thread partials
+  extern __shared__ float lig[];                                            // PM_LIG_LDS floats in the ligand launch, none in the pocket launch
+  __shared__ RowInfo info[PM_ROWS];
+  __shared__ float sums[PM_MAX_PPB][10];
   __shared__ float best_w[PM_MAX_PPB][PM_THREADS / 64];
   __shared__ float cen[PM_MAX_PPB + 1][3];
   __shared__ unsigned char hvy[PM_SMALL_LIG];
@@ -111,15 +120,14 @@ __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
       int c = i % 3;
       lig[i] = src[i] + (c == 0 ? cx : (c == 1 ? cy : cz));
     }
-    const bool small = in.n_lig <= PM_SMALL_LIG;
     float* ligt = lig + npf * nl3;                       // small ligands: target + heavy-atom flags next to the poses
-    if (small) {
+    if (a.small) {
       for (int i = tid; i < nl3; i += PM_THREADS) ligt[i] = in.lig_target[i];
       for (int i = tid; i < in.n_lig; i += PM_THREADS) hvy[i] = !in.heavy_mask || in.heavy_mask[i];
     }
     __syncthreads();
-    if (small) {
-      // small ligands: one lane per (pair, coordinate) / per (pair, automorphism), serial over atoms -- no cross-lane traffic
+    if (a.small) {
+      // one lane per (pair, coordinate) / per (pair, automorphism), serial over atoms -- no cross-lane traffic
       if (a.out.centroid && tid < (npf + 1) * 3) {
         const int q = tid / 3, c = tid - 3 * q;
         const float* lp = lig + q * nl3;                                     // row npf: the target's centroid
@@ -136,11 +144,10 @@ __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
 #pragma unroll 4
           for (int i = 0; i < in.n_lig; ++i) {
             const int j = perm[i];
-            const float w = (hvy[i] && hvy[j]) ? 1.f : 0.f;
             const float dx = lp[3 * j] - ligt[3 * i], dy = lp[3 * j + 1] - ligt[3 * i + 1], dz = lp[3 * j + 2] - ligt[3 * i + 2];
-            if (w != 0.f) { acc += dx * dx + dy * dy + dz * dz; cnt += 1.f; }
+            if (hvy[i] && hvy[j]) { acc += dx * dx + dy * dy + dz * dz; cnt += 1.f; }
           }
-          tile[it] = sqrtf(acc / cnt);                   // npf * n_perm values; min taken below
+          tile[it] = sqrtf(acc / cnt);                   // npf * n_perm <= PM_ROWS * 42 values; min taken below
         }
       }
       __syncthreads();
@@ -149,10 +156,7 @@ __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
           float dx = cen[tid][0] - cen[npf][0], dy = cen[tid][1] - cen[npf][1], dz = cen[tid][2] - cen[npf][2];
           a.out.centroid[pf0 + tid] = sqrtf(dx * dx + dy * dy + dz * dz);
         }
-      }
-      if (a.out.lig_rmsd) {
-        // min over the automorphisms of each pair: chunks of up to PM_THREADS * 42 results were written above
-        if (tid < npf) {
+        if (a.out.lig_rmsd) {
           float b = INFINITY;
           for (int p = 0; p < in.n_perm; ++p) b = fminf(b, tile[tid * in.n_perm + p]);
           a.out.lig_rmsd[pf0 + tid] = b;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
       }
       __syncthreads();
     } else {
-      // large ligands: waves over automorphisms, lanes over atoms
+      // large ligands / very many automorphisms: waves over automorphisms, lanes over atoms
       for (int q = 0; q < npf; ++q) {
         const float* lp = lig + q * nl3;
         if (a.out.centroid && wave == (q & 3)) {
@@ -210,85 +214,91 @@ __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
   }
   if (!(a.out.sc_rmsd || a.out.chi_rate || a.out.delta_chi)) return;
 
-  // ---- pocket: side-chain RMSD and chi differences, one thread per residue row
-  float acc[PM_NQ];
-  for (int k = 0; k < PM_NQ; ++k) acc[k] = 0.f;
-  const int seg = a.ppb > 1 ? in.n_res : PM_THREADS;
+  // ---- pocket: side-chain RMSD and chi differences, four threads per residue row
+  const int rl = tid >> 2, k = tid & 3;                  // row inside the tile, chi / slot quarter of this thread
+  float v_rmsd = 0.f, v_cnt = 0.f, v_ok = 0.f, v_ex = 0.f;
+  const int segr = a.ppb > 1 ? in.n_res : PM_ROWS;        // rows of one pair inside the workgroup's tile
   const float* psrc = in.prot_traj + (size_t)pf0 * in.n_res * 42;
-  for (int r0 = 0; r0 < (a.ppb > 1 ? 1 : in.n_res); r0 += PM_THREADS) {
-    const int trows = a.ppb > 1 ? in.n_res : min(PM_THREADS, in.n_res - r0);     // distinct target rows in this pass
-    const int rows = a.ppb > 1 ? npf * in.n_res : trows;                         // pose rows in this pass
+  for (int r0 = 0; r0 < (a.ppb > 1 ? 1 : in.n_res); r0 += PM_ROWS) {
+    const int trows = a.ppb > 1 ? in.n_res : min(PM_ROWS, in.n_res - r0);      // distinct target rows in this pass
+    const int rows = a.ppb > 1 ? npf * in.n_res : trows;                        // pose rows in this pass
     __syncthreads();
     {   // rows * 42 floats, contiguous; float2 keeps every row start aligned (42 is even)
       const float2* s2 = reinterpret_cast<const float2*>(psrc + (size_t)r0 * 42);
       float2* d2 = reinterpret_cast<float2*>(tile);
       for (int i = tid; i < rows * 21; i += PM_THREADS) d2[i] = s2[i];
     }
-    if (tid < trows) {
-      const int r = r0 + tid;
+    if (rl < trows) {                                     // static row data: thread k fills the chi_k fields
+      const int r = r0 + rl;
       const int aa = in.aatype[r];
       const float* tg = in.atom14_target + (size_t)r * 42;
       const float* mk = in.atom14_target_mask + (size_t)r * 14;
-      RowInfo ri;
-      unsigned bits = 0;
-      for (int j = 0; j < 14; ++j) bits |= (mk[j] != 0.f ? 1u : 0u) << j;
-      unsigned long long sw = 0;
-      for (int j = 5; j < 14; ++j) sw |= (unsigned long long)kAtom14Swap[aa][j] << (4 * (j - 5));
-      for (int k = 0; k < 4; ++k) {
-        float ang = 0.f;
-        unsigned short packed = 0;
-        if (kChiMask[aa][k]) {
-          const int* ia = kChiAtoms14[aa][k];
-          P3 t4[4];
-          bool all = true;
-          for (int u = 0; u < 4; ++u) {
-            t4[u] = {tg[3 * ia[u]], tg[3 * ia[u] + 1], tg[3 * ia[u] + 2]};
-            packed |= (unsigned short)(ia[u] << (4 * u));
-            all = all && ((bits >> ia[u]) & 1u);
-          }
-          float ts, tc;
-          chi_sin_cos(t4[0], t4[1], t4[2], t4[3], ts, tc);
-          ang = atan2f(ts, tc);
-          if (all) bits |= 1u << (14 + k);
-          if (kChiPiPeriodic[aa][k]) bits |= 1u << (18 + k);
+      unsigned mask14 = 0;
+      for (int j = 0; j < 14; ++j) mask14 |= (mk[j] != 0.f ? 1u : 0u) << j;
+      float ang = 0.f;
+      unsigned short packed = 0;
+      unsigned char flag = 0;
+      if (kChiMask[aa][k]) {
+        const int* ia = kChiAtoms14[aa][k];
+        P3 t4[4];
+        bool all = true;
+        for (int u = 0; u < 4; ++u) {
+          t4[u] = {tg[3 * ia[u]], tg[3 * ia[u] + 1], tg[3 * ia[u] + 2]};
+          packed |= (unsigned short)(ia[u] << (4 * u));
+          all = all && ((mask14 >> ia[u]) & 1u);
         }
-        ri.chi[k] = packed;
-        ri.ang[k] = ang;
+        float ts, tc;
+        chi_sin_cos(t4[0], t4[1], t4[2], t4[3], ts, tc);
+        ang = atan2f(ts, tc);
+        flag = (all ? 1 : 0) | (kChiPiPeriodic[aa][k] ? 2 : 0);
       }
-      ri.bits = bits;
-      ri.swap = sw;
-      info[tid] = ri;
+      info[rl].chi[k] = packed;
+      info[rl].flag[k] = flag;
+      info[rl].ang[k] = ang;
+      if (k == 0) {
+        unsigned lo = 0;
+        for (int j = 5; j < 13; ++j) lo |= (unsigned)kAtom14Swap[aa][j] << (4 * (j - 5));
+        info[rl].mask14 = mask14;
+        info[rl].swap_lo = lo;
+        info[rl].swap_hi = (unsigned)kAtom14Swap[aa][13];
+      }
     }
     __syncthreads();
-    if (tid < rows) {
-      const int q = a.ppb > 1 ? tid / in.n_res : 0;
-      const int rl = a.ppb > 1 ? tid - q * in.n_res : tid;       // row inside the tile
-      const int r = r0 + rl;
-      const RowInfo ri = info[rl];
-      const float* pr = tile + tid * 42;
+    if (rl < rows) {
+      const int q = a.ppb > 1 ? rl / in.n_res : 0;
+      const int rt = a.ppb > 1 ? rl - q * in.n_res : rl;    // row inside the pair's tile = index into info
+      const int r = r0 + rt;
+      const unsigned mask14 = info[rt].mask14, swap_lo = info[rt].swap_lo, swap_hi = info[rt].swap_hi;
+      const float* pr = tile + rl * 42;
       const float* tg = in.atom14_target + (size_t)r * 42;
-      // side chain: slots 5..13, both namings
-      float d2 = 0.f, d2a = 0.f, deno = 0.f;
-      for (int j = 5; j < 14; ++j) {
-        const int js = (int)((ri.swap >> (4 * (j - 5))) & 15u);
-        const float m = (float)((ri.bits >> j) & 1u), ma = (float)((ri.bits >> js) & 1u);
-        deno += m;
+      // side chain: slots 5..13 dealt to the quad (k: 5+k, 9+k, and 13 to k == 0), both namings
+      float d2 = 0.f, d2a = 0.f;
+      for (int t = 0; t < 3; ++t) {
+        const int j = t < 2 ? 5 + 4 * t + k : 13;
+        if (t == 2 && k != 0) break;
+        const int js = j < 13 ? (int)((swap_lo >> (4 * (j - 5))) & 15u) : (int)swap_hi;
+        const float m = (float)((mask14 >> j) & 1u), ma = (float)((mask14 >> js) & 1u);
         for (int c = 0; c < 3; ++c) {
           float cc = c == 0 ? cx : (c == 1 ? cy : cz);
           float p = (pr[3 * j + c] + cc) * m;
-          float t = (tg[3 * j + c] + cc) * m;
+          float tt = (tg[3 * j + c] + cc) * m;
           float ta = (tg[3 * js + c] + cc) * ma;
-          d2 += (t - p) * (t - p);
+          d2 += (tt - p) * (tt - p);
           d2a += (ta - p) * (ta - p);
         }
       }
-      d2 = fminf(d2, d2a);
-      if ((ri.bits >> 5) & 0x1ffu) { acc[0] += sqrtf(d2 / (deno + 1e-6f)); acc[1] += 1.f; }
-      // chi angles
-      float dl[4] = {0, 0, 0, 0};
-      for (int k = 0; k < 4; ++k) {
-        if (!((ri.bits >> (14 + k)) & 1u)) continue;
-        const unsigned pk = ri.chi[k];
+      d2 = quad_sum(d2);
+      d2a = quad_sum(d2a);
+      const unsigned scbits = (mask14 >> 5) & 0x1ffu;
+      if (k == 0 && scbits) {
+        v_rmsd += sqrtf(fminf(d2, d2a) / ((float)__popc(scbits) + 1e-6f));
+        v_cnt += 1.f;
+      }
+      // chi_k
+      float dl = 0.f;
+      const unsigned flag = info[rt].flag[k];
+      if (flag & 1u) {
+        const unsigned pk = info[rt].chi[k];
         P3 p4[4];
         for (int u = 0; u < 4; ++u) {
           const int s14 = (pk >> (4 * u)) & 15;
@@ -297,35 +307,32 @@ __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
         float ps, pc;
         chi_sin_cos(p4[0], p4[1], p4[2], p4[3], ps, pc);
         const float pi = 3.14159265358979323846f;
-        const float ap = atan2f(ps, pc), at = ri.ang[k];
-        float d = ang_diff(ap, at);
-        if ((ri.bits >> (18 + k)) & 1u) d = fminf(d, ang_diff(ap, at > 0.f ? at - pi : at + pi));     // atan2(-sin, -cos)
-        dl[k] = d;
-        acc[6 + k] += 1.f;
-        if (d < in.chi_bound) acc[2 + k] += 1.f;
+        const float ap = atan2f(ps, pc), at = info[rt].ang[k];
+        dl = ang_diff(ap, at);
+        if (flag & 2u) dl = fminf(dl, ang_diff(ap, at > 0.f ? at - pi : at + pi));     // atan2(-sin, -cos)
+        v_ex += 1.f;
+        if (dl < in.chi_bound) v_ok += 1.f;
       }
-      if (a.out.delta_chi) {
-        float4 v = {dl[0], dl[1], dl[2], dl[3]};
-        *reinterpret_cast<float4*>(a.out.delta_chi + ((size_t)(pf0 + q) * in.n_res + r) * 4) = v;
-      }
+      if (a.out.delta_chi) a.out.delta_chi[((size_t)(pf0 + q) * in.n_res + r) * 4 + k] = dl;
     }
   }
-  // ---- fixed-order reduction of the per-row partials over each pair's rows (partials overlay the pose tile)
+  // ---- fixed-order reduction of the per-thread partials over each pair's rows (partials overlay the pose tile)
   __syncthreads();
-  float* part = tile;                                  // [PM_THREADS][PM_NQ + 1]
-  for (int k = 0; k < PM_NQ; ++k) part[tid * (PM_NQ + 1) + k] = acc[k];
+  float* part = tile;                                  // [PM_THREADS][5]
+  part[tid * 5 + 0] = v_rmsd; part[tid * 5 + 1] = v_cnt; part[tid * 5 + 2] = v_ok; part[tid * 5 + 3] = v_ex;
   __syncthreads();
-  if (tid < npf * PM_NQ) {
-    const int q = tid / PM_NQ, k = tid - q * PM_NQ;
+  if (tid < npf * 10) {
+    const int q = tid / 10, w = tid - q * 10;          // w: 0 rmsd, 1 rows with a side chain, 2..5 chi ok, 6..9 chi exists
+    const int kk = w < 2 ? 0 : (w - 2) & 3, slot = w < 2 ? w : (w < 6 ? 2 : 3);
     float sacc = 0.f;
-    for (int i = 0; i < seg; ++i) sacc += part[(q * seg + i) * (PM_NQ + 1) + k];
-    sums[q][k] = sacc;
+    for (int i = 0; i < segr; ++i) sacc += part[((q * segr + i) * 4 + kk) * 5 + slot];
+    sums[q][w] = sacc;
   }
   __syncthreads();
   if (tid < npf) {
     if (a.out.sc_rmsd) a.out.sc_rmsd[pf0 + tid] = sums[tid][0] / sums[tid][1];
     if (a.out.chi_rate)
-      for (int k = 0; k < 4; ++k) a.out.chi_rate[(size_t)(pf0 + tid) * 4 + k] = sums[tid][2 + k] / sums[tid][6 + k];
+      for (int c = 0; c < 4; ++c) a.out.chi_rate[(size_t)(pf0 + tid) * 4 + c] = sums[tid][2 + c] / sums[tid][6 + c];
   }
 }
 
@@ -334,30 +341,46 @@ extern "C" int dbfr_pose_metrics(const dbfr_pose_metrics_in* in, const dbfr_pose
   if (in->n_pose < 0 || in->n_frame < 0 || in->n_lig < 0 || in->n_res < 0) { dbfr_set_error("negative size"); return DBFR_ERR_ARG; }
   const bool want_lig = out->centroid || out->lig_rmsd, want_prot = out->sc_rmsd || out->chi_rate || out->delta_chi;
   if (want_lig && (!in->lig_traj || !in->lig_target || in->n_lig < 1)) { dbfr_set_error("ligand metrics need lig_traj / lig_target"); return DBFR_ERR_ARG; }
-  if (want_lig && in->n_lig > PM_MAX_LIG) { dbfr_set_error("ligand larger than 2048 atoms"); return DBFR_ERR_ARG; }
+  if (want_lig && in->n_lig > PM_MAX_LIG) { dbfr_set_error("ligand larger than 1024 atoms"); return DBFR_ERR_ARG; }
   if (out->lig_rmsd && (in->n_perm < 1 || !in->perms)) { dbfr_set_error("lig_rmsd needs at least the identity automorphism"); return DBFR_ERR_ARG; }
   if (want_prot && (!in->prot_traj || !in->atom14_target || !in->atom14_target_mask || !in->aatype || in->n_res < 1)) {
     dbfr_set_error("pocket metrics need prot_traj / atom14_target / atom14_target_mask / aatype");
     return DBFR_ERR_ARG;
   }
   if (want_prot && ((uintptr_t)in->prot_traj & 7)) { dbfr_set_error("prot_traj must be 8-byte aligned"); return DBFR_ERR_ARG; }
-  PmArgs a;
-  a.in = *in;
-  a.out = *out;
-  a.n_pf = (long long)in->n_pose * in->n_frame;
-  if (a.n_pf == 0 || !(want_lig || want_prot)) return DBFR_OK;
-  int ppb = PM_MAX_PPB;
-  if (want_prot) ppb = std::min(ppb, std::max(1, PM_THREADS / in->n_res));
-  if (want_lig) ppb = std::min(ppb, std::max(1, PM_LIG_LDS / (3 * in->n_lig) - 1));      // poses + the target in LDS
-  if (out->lig_rmsd && in->n_lig <= PM_SMALL_LIG) {
-    if (in->n_perm > PM_THREADS * 42) { dbfr_set_error("more than 10752 automorphisms"); return DBFR_ERR_ARG; }
-    ppb = std::min(ppb, std::max(1, PM_THREADS * 42 / in->n_perm));
+  const long long n_pf = (long long)in->n_pose * in->n_frame;
+  if (n_pf == 0 || !(want_lig || want_prot)) return DBFR_OK;
+  // Two launches of the same kernel: the ligand half and the pocket half want different numbers of pairs per workgroup
+  // (a workgroup holds up to 25 ligand poses but only 64 pocket rows), and sharing one value starves the ligand lanes.
+  for (int half = 0; half < 2; ++half) {
+    if (half == 0 ? !want_lig : !want_prot) continue;
+    PmArgs a;
+    a.in = *in;
+    a.out = *out;
+    a.n_pf = n_pf;
+    a.small = 0;
+    int ppb = PM_MAX_PPB;
+    if (half == 0) {
+      a.out.sc_rmsd = a.out.chi_rate = a.out.delta_chi = nullptr;
+      const int n_perm = out->lig_rmsd ? in->n_perm : 1;
+      a.small = in->n_lig <= PM_SMALL_LIG && n_perm <= PM_ROWS * 42 && 2 * 3 * in->n_lig <= PM_LIG_LDS;
+      if (a.small) {
+        ppb = std::min(ppb, std::max(1, PM_LIG_LDS / (3 * in->n_lig) - 1));          // poses + the target in LDS
+        ppb = std::min(ppb, std::max(1, PM_ROWS * 42 / n_perm));                    // per-automorphism results in LDS
+      } else {
+        ppb = std::min(ppb, std::max(1, PM_LIG_LDS / (3 * in->n_lig)));
+      }
+    } else {
+      a.out.centroid = a.out.lig_rmsd = nullptr;
+      ppb = std::min(ppb, std::max(1, PM_ROWS / in->n_res));
+    }
+    a.ppb = ppb;
+    const long long blocks = (n_pf + ppb - 1) / ppb;
+    if (blocks > 0x7fffffffLL) { dbfr_set_error("too many (pose, frame) pairs for one launch"); return DBFR_ERR_ARG; }
+    hipLaunchKernelGGL(k_pose_metrics, dim3((unsigned)blocks), dim3(PM_THREADS), half == 0 ? PM_LIG_LDS * sizeof(float) : 0,
+                       (hipStream_t)hip_stream, a);
+    HIPCHECK(hipGetLastError());
   }
-  a.ppb = ppb;
-  const long long blocks = (a.n_pf + ppb - 1) / ppb;
-  if (blocks > 0x7fffffffLL) { dbfr_set_error("too many (pose, frame) pairs for one launch"); return DBFR_ERR_ARG; }
-  hipLaunchKernelGGL(k_pose_metrics, dim3((unsigned)blocks), dim3(PM_THREADS), 0, (hipStream_t)hip_stream, a);
-  HIPCHECK(hipGetLastError());
   return DBFR_OK;
 }
 

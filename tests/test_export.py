@@ -243,6 +243,21 @@ def test_gpu_pose_metrics_tiles_and_many_automorphisms():
     d = np.abs(out["delta_chi"].cpu().numpy() - want["delta_chi"].numpy())
     assert (d > 1e-3).sum() <= 4 and np.median(d) < 1e-5
     assert np.abs(out["chi_rate"].cpu().numpy() - want["chi_rate"].numpy()).max() < 0.02
+    # a small ligand with more automorphisms than the per-lane path keeps in LDS (falls back to waves over automorphisms)
+    n2 = 20
+    lig2 = lig[:n2]
+    many = np.stack([np.arange(n2)] + [rng.permutation(n2) for _ in range(2999)]).astype(np.int32)
+    lt2 = torch.from_numpy(lig2 - center)[None, None] + 0.3 * torch.randn(2, 3, n2, 3, generator=torch.Generator().manual_seed(3))
+    hv = rng.random(n2) > 0.2
+    got2 = pex.pose_metrics(lt2.to(dev), pt[:2, :3].float().to(dev), center, lig2, tgt, tmask, seq, perms=many, heavy_mask=hv)
+    few2 = pex.pose_metrics(lt2.to(dev), pt[:2, :3].float().to(dev), center, lig2, tgt, tmask, seq, perms=many[:50], heavy_mask=hv)
+    torch.cuda.synchronize()
+    lt2_abs = oex.add_center_pos(lt2, torch.from_numpy(center)).numpy()
+    want2 = oex.symm_rmsd([(p_, np.arange(n2)) for p_ in many], hv, lig2, lt2_abs)
+    assert np.abs(got2["lig_rmsd"].cpu().numpy() - want2.numpy()).max() < 5e-5
+    want3 = oex.symm_rmsd([(p_, np.arange(n2)) for p_ in many[:50]], hv, lig2, lt2_abs)
+    assert np.abs(few2["lig_rmsd"].cpu().numpy() - want3.numpy()).max() < 5e-5
+    assert np.abs(few2["centroid"].cpu().numpy() - got2["centroid"].cpu().numpy()).max() < 5e-5
     # only what is asked for is computed: ligand-only call
     lib_only = pex.pose_metrics(lt.to(dev), pt.float().to(dev), center, lig, tgt, tmask, seq)
     torch.cuda.synchronize()
