@@ -339,6 +339,7 @@ __global__ __launch_bounds__(PM_THREADS) void k_pose_metrics(PmArgs a) {
 extern "C" int dbfr_pose_metrics(const dbfr_pose_metrics_in* in, const dbfr_pose_metrics_out* out, void* hip_stream) {
   if (!in || !out) { dbfr_set_error("null argument"); return DBFR_ERR_ARG; }
   if (in->n_pose < 0 || in->n_frame < 0 || in->n_lig < 0 || in->n_res < 0) { dbfr_set_error("negative size"); return DBFR_ERR_ARG; }
+  if ((long long)in->n_pose * in->n_frame == 0) return DBFR_OK;          // nothing to do (empty tensors may carry null pointers)
   const bool want_lig = out->centroid || out->lig_rmsd, want_prot = out->sc_rmsd || out->chi_rate || out->delta_chi;
   if (want_lig && (!in->lig_traj || !in->lig_target || in->n_lig < 1)) { dbfr_set_error("ligand metrics need lig_traj / lig_target"); return DBFR_ERR_ARG; }
   if (want_lig && in->n_lig > PM_MAX_LIG) { dbfr_set_error("ligand larger than 1024 atoms"); return DBFR_ERR_ARG; }

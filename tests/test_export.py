@@ -141,6 +141,36 @@ def test_library_pdb_writer_is_byte_exact(tmp_path):
         topo.to_pdb(pt[0, -1], rows=np.array([0, 1]))
 
 
+def test_library_pdb_writer_equals_oracle_on_random_structures():
+    """Empty structure, single residue, and random strips (missing atoms, any chain / residue numbering, poses covering
+    all / some / no residues) -- the library text must equal the reference-pinned oracle's."""
+    rng = np.random.default_rng(101)
+    for case in range(24):
+        n = [0, 1][case] if case < 2 else int(rng.integers(2, 40))
+        aa = rng.integers(0, 21, n)
+        m37 = (T["atom37_mask"][aa] * (rng.random((n, 37)) > 0.15)).astype(np.float32)
+        if n:
+            m37[rng.integers(0, n), 36] = 1.0                                         # an OXT somewhere
+        pos = (rng.standard_normal((n, 37, 3)) * rng.choice([3.0, 60.0, 700.0])).astype(np.float32)
+        chain = np.sort(rng.integers(0, 60, n))
+        resid = rng.integers(-99, 9999, n)
+        bfac = np.round(rng.random((n, 37)) * 150, int(rng.integers(0, 5)))
+        remark = None if case % 3 == 0 else "REMARK   1 TEST %d" % case
+        topo = pex.ProteinTopology(aa, pos, m37, resid, chain, bfac, remark)
+        model = None if case % 2 else 3
+        want = oex.to_pdb(aa, pos, m37, resid, chain, bfac, T, remark, model=model, add_end=bool(case % 4))
+        got = topo.to_pdb(model=model, add_end=bool(case % 4), version="x")
+        if remark is None and model is None:
+            got = got.split("\n", 1)[1]                                               # the dated REMARK line
+        assert got == want, case
+        if n >= 2:
+            rows = np.sort(rng.choice(n, int(rng.integers(1, n + 1)), replace=False))
+            p14 = (rng.standard_normal((rows.shape[0], 14, 3)) * 30).astype(np.float32)
+            want = oex.pose_pdb(aa, pos, m37, resid, chain, bfac, rows, p14, T, "REMARK X")
+            topo.remark = "REMARK X"
+            assert topo.to_pdb(p14, rows=rows) == want, case
+
+
 def test_automorphisms_match_the_reference_matcher():
     z = fixture()
     mine = ligand.automorphisms(z["lig_elements"], z["lig_edge_index"])
@@ -214,6 +244,24 @@ def test_gpu_pose_metrics_match_reference_fixture():
     assert (d > 1e-3).sum() <= 2 and np.median(d) < 1e-5
     assert np.abs(out["chi_rate"].cpu().numpy() - want["chi_rate"].numpy()).max() < 0.02
     assert out["chi_rate"][0, 0].min().item() == 1.0 and out["delta_chi"][0, 0].abs().max().item() < 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_pose_metrics_empty_and_single():
+    dev = torch.device("cuda:0")
+    z = fixture()
+    seq = z["aatype"][z["pocket_mask"]]
+    args = (z["center"], z["lig_pos"], z["target_atom14"], z["target_atom14_mask"], seq)
+    out = pex.pose_metrics(torch.zeros(0, 3, 35, 3, device=dev), torch.zeros(0, 3, seq.shape[0], 14, 3, device=dev), *args)
+    assert out["centroid"].shape == (0, 3) and out["chi_rate"].shape == (0, 3, 4)
+    one = pex.pose_metrics(torch.from_numpy(z["lig_traj"][2:3, 1:2]).to(dev), torch.from_numpy(z["prot_traj"][2:3, 1:2]).to(dev), *args)
+    torch.cuda.synchronize()
+    assert abs(one["centroid"].item() - z["ref_centroid"][2, 1]) < TOL and abs(one["sc_rmsd"].item() - z["ref_sc_rmsd"][2, 1]) < TOL
+    a = pex.pose_metrics(torch.from_numpy(z["lig_traj"]).to(dev), torch.from_numpy(z["prot_traj"]).to(dev), *args, with_delta_chi=True)
+    b = pex.pose_metrics(torch.from_numpy(z["lig_traj"]).to(dev), torch.from_numpy(z["prot_traj"]).to(dev), *args, with_delta_chi=True)
+    torch.cuda.synchronize()
+    for key in ("centroid", "sc_rmsd", "chi_rate", "lig_rmsd", "delta_chi"):
+        assert torch.equal(a[key], b[key]), key                  # fixed-order reductions: bitwise reproducible
 
 
 @pytest.mark.gpu

@@ -1,0 +1,109 @@
+"""Whole-pipeline timing on one GPU: records -> assemble + on-device pose initialisation (row f1) -> 20-step sampler
+(rows a1-a15) -> per-pose metrics on the device + structure files (row f3).  Shows where the wall time of one batch goes
+once every stage is native; the host-side once-per-complex work (ComplexRecord) is reported separately.
+
+    python tools/pipeline_bench.py [--config 2] [--complexes 16] [--poses 40]
+
+Prints one JSON line (seconds per stage for the batch, poses/s end to end).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import diffbindfr_amd as dba  # noqa: E402
+from diffbindfr_amd import assemble, export as pex, ligand, synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=2)
+ap.add_argument("--complexes", type=int, default=16)
+ap.add_argument("--poses", type=int, default=40)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+T = synthetic.residue_tables()
+c = synthetic.CONFIGS[a.config]
+samp = dba.DiffBindFRHIP(diffusion_model=bench.seeded_params().to(dev), test_cfg={})
+raw = []
+for ci in range(a.complexes):
+    rng = np.random.default_rng([a.config, ci])
+    raw.append(synthetic.make_record(synthetic.make_pocket(rng, int(round(c["n_atoms"] * rng.uniform(0.9, 1.1)))),
+                                     synthetic.make_ligand(rng, max(4, int(round(c["n_lig"] * rng.uniform(0.85, 1.15))))), rng))
+
+
+def sync():
+    torch.cuda.synchronize(dev)
+
+
+def run():
+    t = {}
+    t0 = time.perf_counter()
+    recs = [assemble.ComplexRecord(r) for r in raw]
+    t["records_host_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pb = assemble.assemble(recs, a.poses, dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    assemble.init_poses(samp.diffusion_model, pb, assemble.draw_init_tape(pb, 10.0, gen))
+    sync()
+    t["assemble_init_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    steps, _ = samp.schedule()
+    d = pb.dims
+    z = {"tr": torch.randn(len(steps), pb.G, 3, device=dev, generator=gen), "rot": torch.randn(len(steps), pb.G, 3, device=dev, generator=gen),
+         "tor": torch.randn(len(steps), max(d["NTOR"], 1), device=dev, generator=gen),
+         "sc": torch.randn(len(steps), max(d["NSC"], 1), device=dev, generator=gen)}
+    lig, a14 = samp.sample_packed(pb, z, visualize=False)
+    sync()
+    t["sample_s"] = time.perf_counter() - t0
+    res = samp._split(pb, lig, a14)
+    # ---- row f3: metrics where the poses are, then one structure file per pose
+    t0 = time.perf_counter()
+    auto_s = 0.0
+    outs = []
+    g = 0
+    for rec in recs:
+        lt = torch.stack([res[g + i][0] for i in range(a.poses)])
+        pt = torch.stack([res[g + i][1] for i in range(a.poses)])
+        g += a.poses
+        ta = time.perf_counter()
+        perms = ligand.automorphisms(np.zeros(rec.n_l, int), np.stack([rec.bond_src.numpy(), rec.bond_dst.numpy()]), limit=20000)
+        auto_s += time.perf_counter() - ta
+        tgt = pt[0, -1]                                   # stand-in target structure (synthetic data has no crystal pose)
+        outs.append(pex.pose_metrics(lt, pt, np.zeros(3, np.float32), rec.lig_pos, tgt, rec.atom14_mask.float(), rec.sequence, perms=perms))
+    sync()
+    t["metrics_s"] = time.perf_counter() - t0
+    t["automorphisms_host_s"] = auto_s
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory() as dd:
+        g = 0
+        nbytes = 0
+        for ci, rec in enumerate(recs):
+            n = rec.n_r
+            aa = rec.sequence.numpy()
+            m37 = np.take_along_axis(rec.atom14_mask.numpy().astype(np.float32), T["atom37_to_atom14"][aa], 1) * T["atom37_mask"][aa]
+            topo = pex.ProteinTopology(aa, np.zeros((n, 37, 3), np.float32), m37, np.arange(1, n + 1), np.zeros(n, int),
+                                       np.zeros((n, 37)), "REMARK   1 pipeline_bench")
+            final = torch.stack([res[g + i][1][-1] for i in range(a.poses)]).cpu()
+            g += a.poses
+            paths = [os.path.join(dd, f"c{ci}_p{i}.pdb") for i in range(a.poses)]
+            topo.write_poses(final, paths)
+            nbytes += sum(os.path.getsize(p) for p in paths)
+    t["pdb_files_s"] = time.perf_counter() - t0
+    t["pdb_bytes"] = nbytes
+    return t
+
+
+run()                         # warm-up (workspace allocation, first launches)
+t = run()
+n = a.complexes * a.poses
+total = sum(v for k, v in t.items() if k.endswith("_s") and k != "automorphisms_host_s")
+t.update(config=a.config, complexes=a.complexes, poses_per_complex=a.poses, poses=n, total_s=total, poses_per_s_end_to_end=n / total,
+         poses_per_s_sampler_only=n / t["sample_s"])
+print(json.dumps(t))
