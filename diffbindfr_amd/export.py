@@ -55,8 +55,7 @@ def pose_metrics(lig_traj, prot_traj, center, lig_target, atom14_target, atom14_
                           (C.c_float * 3)(*c), float(chi_bound))
     cout = L.PoseMetricsOut(p(out["centroid"]), p(out["sc_rmsd"]), p(out["chi_rate"]), p(out.get("delta_chi")), p(out["lig_rmsd"]))
     L.check(lib.dbfr_pose_metrics(C.byref(cin), C.byref(cout), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    out["_keep"] = (lt, pt, lg, tg, tm, aa, pm, hm)          # inputs stay alive until the stream work is done
-    return out
+    return out          # temporaries above are released in stream order by torch's caching allocator (same stream as the launch)
 
 
 @dataclass
