@@ -19,6 +19,9 @@ def init(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # dmabuf IPC is the only mode the host driver supports (RCCL's hipIpcGetMemHandle fails otherwise); must be in the
+        # environment before the HSA runtime starts, i.e. before the first device call of this process
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # DBFR_DIST_BACKEND=gloo: developer override to walk the multi-rank path on a box with fewer GPUs than ranks

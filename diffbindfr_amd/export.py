@@ -137,3 +137,88 @@ class ProteinTopology:
         arr = (C.c_char_p * len(paths))(*[str(x).encode() for x in paths])
         L.check(lib.dbfr_pdb_write_files(C.byref(topo), n_rows, None if r is None else r.ctypes.data_as(C.c_void_p),
                                          a.ctypes.data_as(C.c_void_p), len(paths), arr, int(threads)))
+
+
+@dataclass
+class ComplexOutput:
+    """What ``complex_modeling`` reads per complex from the reference's dataset objects
+    (``PD.traj_group[name]``, ``proteins[key]``, ``ligands[key]``; export.py:125-137,150-159,198-203)."""
+    name: str
+    ligand_traj: torch.Tensor                 # [N_pose, N_traj, N_l, 3] pocket-centred (device)
+    protein_traj: torch.Tensor                # [N_pose, N_traj, N_r, 14, 3] pocket-centred (device)
+    pocket_center_pos: np.ndarray             # proteinmeta.pocket_center_pos
+    ligand_pos: np.ndarray                    # ligandmeta.ligand.atom_positions (absolute)
+    ligand_labels: np.ndarray                 # atom types / elements (automorphisms must preserve them)
+    ligand_edge_index: np.ndarray             # [2,E] covalent bonds, both directions
+    topology: ProteinTopology                 # proteinmeta.protein with pocket_rows = nonzero(pocket_mask)
+    atom14_position: np.ndarray               # proteinmeta.atom14_position (pocket-centred), [N_r,14,3]
+    atom14_mask: np.ndarray                   # proteinmeta.atom14_mask
+    aatype: np.ndarray                        # proteinmeta.pocket.aatype
+    row: Optional[dict] = None                # the pair_frame row copied onto every pose (export.py:143-148)
+    heavy_mask: Optional[np.ndarray] = None
+
+
+def rmsd_to_str(rmsd):
+    """export.py:32-36."""
+    return str(round(rmsd, 2)).replace('.', '_')
+
+
+def complex_modeling(entries, export_dir=None, calc_metrics=False, lrmsd_naming=False, complex_name_split=None,
+                     ligand_writer=None, threads=0, **kwargs):
+    """``complex_modeling`` (DiffBindFR/evaluation/export.py:106-312) over ``ComplexOutput`` entries: same flags
+    (``export_fullp``, ``export_pkt``), same directory layout (``<export_dir>/<name>/sample_<i>[_<rmsd>]/prot_final.pdb`` /
+    ``pkt_final.pdb``), same frame columns (``centroid``, ``chi1_15``, ``sc-rmsd``, ``l-rmsd``, ``sample_id``, ``docked_lig``,
+    ``protein_pdb``) and the same ``arr_df`` dict.  Differences: the metrics of all poses come from one device launch per complex;
+    ``l-rmsd`` is the heavy-atom RMSD minimised over the graph automorphisms (the reference asks RDKit for the symmetry
+    classes); ``lig_final.sdf`` is written by ``ligand_writer(entry, pose_index, final_pos[N_l,3], path)`` if given (RDKit's
+    SDWriter in the reference); the trajectory flags (``export_fullp_traj`` / ``export_pkt_traj``: ligand HETATM records + XTC)
+    are not supported."""
+    import pandas as pd
+    from collections import defaultdict
+    from . import ligand as _ligand
+    if kwargs.get("export_fullp_traj") or kwargs.get("export_pkt_traj"):
+        raise NotImplementedError("trajectory export (PLComplex.to_pdb + MDAnalysis XTC) stays with the reference")
+    fullp, pkt = bool(kwargs.get("export_fullp", False)), bool(kwargs.get("export_pkt", False))
+    df, pd_df = defaultdict(list), defaultdict(list)
+    for e in entries:
+        n_pose = int(e.ligand_traj.shape[0])
+        center = torch.as_tensor(np.asarray(e.pocket_center_pos), dtype=torch.float32).reshape(3)
+        for k, v in (e.row or {}).items():
+            pd_df[k].extend([v] * n_pose)
+        lrmsd = None
+        if calc_metrics:
+            perms = _ligand.automorphisms(e.ligand_labels, e.ligand_edge_index)
+            m = pose_metrics(e.ligand_traj, e.protein_traj, center, e.ligand_pos, e.atom14_position, e.atom14_mask, e.aatype,
+                             perms=perms, heavy_mask=e.heavy_mask)
+            last = {k: m[k][:, -1].cpu() for k in ("centroid", "sc_rmsd", "lig_rmsd")}
+            chi1 = m["chi_rate"][:, -1, 0].cpu()
+            for col, val in (("centroid", last["centroid"]), ("chi1_15", chi1), ("sc-rmsd", last["sc_rmsd"])):
+                df[col].append(val.tolist())
+                pd_df[col].extend(val.tolist())
+            lrmsd = last["lig_rmsd"].tolist()
+        if not (fullp or pkt) or export_dir is None:
+            continue                                       # like the reference (:198): no 'l-rmsd' / 'sample_id' columns without export
+        if calc_metrics:
+            pd_df["l-rmsd"].extend(lrmsd)
+            df["l-rmsd"].append(lrmsd)
+        import os
+        name = e.name.split(complex_name_split)[-1] if complex_name_split is not None else e.name
+        compl_dir = os.path.join(str(export_dir), name)
+        ids = [f"sample_{i + 1}" + (f"_{rmsd_to_str(lrmsd[i])}" if (calc_metrics and lrmsd_naming) else "") for i in range(n_pose)]
+        dirs = [os.path.join(compl_dir, s) for s in ids]
+        for d in dirs:
+            os.makedirs(d, exist_ok=True)
+        final_prot = (e.protein_traj[:, -1] + center.to(e.protein_traj.device)).cpu()        # add_center_pos, export.py:136
+        if fullp:
+            e.topology.write_poses(final_prot, [os.path.join(d, "prot_final.pdb") for d in dirs], threads=threads)
+        if pkt:
+            e.topology.pocket().write_poses(final_prot, [os.path.join(d, "pkt_final.pdb") for d in dirs], threads=threads)
+        final_lig = (e.ligand_traj[:, -1] + center.to(e.ligand_traj.device)).cpu().numpy() if ligand_writer is not None else None
+        for i, d in enumerate(dirs):
+            pd_df["sample_id"].append(ids[i])
+            sdf = os.path.join(d, "lig_final.sdf")
+            if ligand_writer is not None:
+                ligand_writer(e, i, final_lig[i], sdf)
+            pd_df["docked_lig"].append(sdf)
+            pd_df["protein_pdb"].append(os.path.join(d, "prot_final.pdb" if fullp else "pkt_final.pdb"))
+    return pd.DataFrame(pd_df), ({k: np.array(v) for k, v in df.items()} if calc_metrics else None)

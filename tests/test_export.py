@@ -347,3 +347,37 @@ def test_gpu_metrics_of_sampled_poses_stay_on_the_device():
         got_rate, want_rate = out["chi_rate"].cpu().numpy(), want["chi_rate"].numpy()
         assert (np.isnan(got_rate) == np.isnan(want_rate)).all()       # a chi no residue of the pocket has: 0 / 0 in both
         assert np.abs(np.nan_to_num(got_rate) - np.nan_to_num(want_rate)).max() < 0.05
+
+
+@pytest.mark.gpu
+def test_gpu_complex_modeling_frame_and_files(tmp_path):
+    """The reference-shaped entry point: frame columns / arr_df like export.py:106-312, files equal to the reference text."""
+    z = fixture()
+    dev = torch.device("cuda:0")
+    seq = z["aatype"][z["pocket_mask"]]
+    e = pex.ComplexOutput(name="set:3dbs", ligand_traj=torch.from_numpy(z["lig_traj"]).to(dev), protein_traj=torch.from_numpy(z["prot_traj"]).to(dev),
+                          pocket_center_pos=z["center"], ligand_pos=z["lig_pos"], ligand_labels=z["lig_elements"],
+                          ligand_edge_index=z["lig_edge_index"], topology=topology(z), atom14_position=z["target_atom14"],
+                          atom14_mask=z["target_atom14_mask"], aatype=seq, row={"protein": "3dbs_protein.pdb", "ligand": "x.sdf"},
+                          heavy_mask=z["ha_mask"])
+    written = []
+    frame, arr = pex.complex_modeling([e, e], export_dir=tmp_path, calc_metrics=True, lrmsd_naming=True, complex_name_split=":",
+                                      export_fullp=True, export_pkt=True,
+                                      ligand_writer=lambda ent, i, pos, path: written.append((i, pos.shape, os.path.basename(path))))
+    assert list(frame.columns) == ["protein", "ligand", "centroid", "chi1_15", "sc-rmsd", "l-rmsd", "sample_id", "docked_lig", "protein_pdb"]
+    assert len(frame) == 8 and arr["centroid"].shape == (2, 4) and set(arr) == {"centroid", "chi1_15", "sc-rmsd", "l-rmsd"}
+    assert np.abs(arr["centroid"][0] - z["ref_centroid"][:, -1]).max() < TOL
+    assert np.abs(arr["sc-rmsd"][1] - z["ref_sc_rmsd"][:, -1]).max() < TOL
+    assert np.abs(arr["l-rmsd"][0] - z["ref_symm_rmsd"][:, -1]).max() < TOL
+    assert frame["sample_id"][3] == "sample_4_" + pex.rmsd_to_str(float(arr["l-rmsd"][0][3])) and len(written) == 8
+    for pid in (0, 3):
+        d = os.path.join(tmp_path, "3dbs", frame["sample_id"][pid])
+        assert open(os.path.join(d, "prot_final.pdb")).read() == bytes(z[f"ref_pdb_full_{pid}"]).decode()
+        assert open(os.path.join(d, "pkt_final.pdb")).read() == bytes(z[f"ref_pdb_pkt_{pid}"]).decode()
+        assert frame["protein_pdb"][pid] == os.path.join(d, "prot_final.pdb")
+    with pytest.raises(NotImplementedError):
+        pex.complex_modeling([e], export_dir=tmp_path, export_pkt_traj=True)
+    frame2, arr2 = pex.complex_modeling([e])
+    assert arr2 is None and list(frame2.columns) == ["protein", "ligand"] and len(frame2) == 4
+    frame3, arr3 = pex.complex_modeling([e], calc_metrics=True)          # metrics without export: no l-rmsd (export.py:198 precedes :215)
+    assert list(frame3.columns) == ["protein", "ligand", "centroid", "chi1_15", "sc-rmsd"] and set(arr3) == {"centroid", "chi1_15", "sc-rmsd"}
