@@ -61,7 +61,7 @@ void launch_extract_templates(int n_res, const int* aatype, const float* pos14, 
                               float* rigid, float* angle, hipStream_t st);
 void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st);
 
-// AF2 residue constant tables (data only; generated from the reference's protein_constants.py by tools/make_residue_tables.py)
+// AF2 residue constant tables (data only; generated from the reference's protein_constants.py by tests/golden/make_residue_tables.py)
 #define RT_TABLE static const
 #include "residue_tables.inc"
 #undef RT_TABLE

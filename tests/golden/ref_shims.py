@@ -1,6 +1,6 @@
 """Load the reference's own Python sources in the BUILD CONTAINER ONLY.
 
-Used by tests/golden/make_golden.py (and tools/make_residue_tables.py) to pin
+Used by tests/golden/make_golden.py (and tests/golden/make_residue_tables.py) to pin
 the oracle against the reference implementation and to freeze golden vectors.
 /root/reference does not exist on the GPU box and nothing under tests/ that
 runs there imports this module.

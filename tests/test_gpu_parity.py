@@ -373,7 +373,7 @@ def test_oversized_inputs_are_rejected(setup, dev):
 @pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
 def test_random_ragged_batches_vs_oracle(setup, dev, case):
     """Seeded fuzz: 1-4 graphs of random pocket / ligand sizes (2-40 ligand atoms, rigid ligands included), random
-    initial spread and denoise step (tools/fuzz_scores.py runs the long version)."""
+    initial spread and denoise step (tests/tools/fuzz_scores.py runs the long version)."""
     rng = np.random.default_rng(1000 + case)
     items = []
     for _ in range(int(rng.integers(1, 5))):

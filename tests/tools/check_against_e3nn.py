@@ -1,7 +1,7 @@
 """Run on any machine that HAS e3nn==0.5.1 installed (the build container has not): pins the one boundary
 this repo cannot pin offline -- oracle/e3nn_lite.py against the real e3nn arithmetic the reference calls.
 
-    pip install e3nn==0.5.1 && python tools/check_against_e3nn.py
+    pip install e3nn==0.5.1 && python tests/tools/check_against_e3nn.py
 
 Checks: spherical harmonics (component normalisation), every Wigner-3j tensor the model touches (incl. the
 global sign), FullyConnectedTensorProduct (weight layout, path normalisation) for the 6 conv signatures, and
@@ -12,7 +12,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import e3nn_lite as lite  # noqa: E402
 
 try:

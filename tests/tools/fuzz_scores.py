@@ -1,5 +1,5 @@
 """Developer script (GPU box): seeded fuzz of the HIP score network against the CPU oracle on random ragged batches.
-    python tools/fuzz_scores.py [n_cases]
+    python tests/tools/fuzz_scores.py [n_cases]
 Test infrastructure (imports oracle/)."""
 import copy
 import os
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import diffbindfr_amd as dba
 from diffbindfr_amd import synthetic
 from oracle import sampler as osampler, schedule as osched, score_model as sm

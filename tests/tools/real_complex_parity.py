@@ -10,7 +10,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 import diffbindfr_amd as dba  # noqa: E402
 from diffbindfr_amd import assemble, pocket, synthetic  # noqa: E402

@@ -5,7 +5,7 @@
 Prints one JSON line: time per dbfr_pose_metrics call = two k_pose_metrics launches, ligand half + pocket half (hip events
 on the launch stream), achieved GB/s against the
 algorithmic bytes 12 * (n_lig + 14 n_res) per (pose, frame), and PDB text throughput (structures/s, MB/s) of the
-library writer next to the CPU restatement of the reference's Python writer (oracle/export.to_pdb, 'port').
+library writer (the CPU restatement of the reference's Python writer is timed by tests/tools/pdb_writer_cpu_port.py).
 """
 import argparse
 import json
@@ -84,11 +84,4 @@ with tempfile.TemporaryDirectory() as d:
     res["pdb_bytes_per_structure"] = size
     res["pdb_structures_per_s"] = 40 / dt
     res["pdb_MBs"] = 40 * size / dt / 1e6
-from oracle import export as oex  # noqa: E402  (CPU baseline leg: the restated reference writer)
-rows = np.nonzero(z["pocket_mask"])[0]
-t0 = time.perf_counter()
-for i in range(4):
-    oex.pose_pdb(z["aatype"], z["atom37_pos"], z["atom37_mask"], z["residue_index"], z["chain_index"], z["b_factors"], rows, pose[i], T,
-                 str(z["remark"]))
-res["cpu_port_pdb_structures_per_s"] = 4 / (time.perf_counter() - t0)
 print(json.dumps(res))
