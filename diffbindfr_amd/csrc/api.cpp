@@ -59,6 +59,8 @@ void launch_set_int(int* p, int v, hipStream_t st);
 void launch_init_poses(const dbfr_batch& b, const dbfr_init_tape& z, const int* a14_group, float* atom14_out, hipStream_t st);
 void launch_extract_templates(int n_res, const int* aatype, const float* pos14, float* transl, float* rots, float* frames,
                               float* rigid, float* angle, hipStream_t st);
+void launch_select_pocket(int n_prot, int n_res_total, const int* res_ptr, int m, const float* pos, const float* mask, const int* ref_ptr,
+                          const float* ref, float cut2, int max_neighbors, float* d2, unsigned char* out, hipStream_t st);
 void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st);
 
 // AF2 residue constant tables (data only; generated from the reference's protein_constants.py by tests/golden/make_residue_tables.py)
@@ -804,6 +806,19 @@ extern "C" int dbfr_extract_templates(int32_t n_res, const int32_t* aatype, cons
     return fail(DBFR_ERR_ARG, "null argument");
   launch_extract_templates(n_res, aatype, atom14_pos, backbone_transl, backbone_rots, default_frame, rigid_group_positions,
                            torsion_angle, (hipStream_t)hip_stream);
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_select_pocket(int32_t n_prot, int32_t n_res_total, const int32_t* res_ptr, int32_t atoms_per_res, const float* atom_pos,
+                                  const float* atom_mask, const int32_t* ref_ptr, const float* ref_pos, double cutoff,
+                                  int32_t max_neighbors, float* min_dist2, uint8_t* res_mask, void* hip_stream) {
+  if (n_prot < 0 || n_res_total < 0 || atoms_per_res < 1) return fail(DBFR_ERR_ARG, "bad size");
+  if (n_prot == 0 || n_res_total == 0) return DBFR_OK;
+  if (!res_ptr || !atom_pos || !atom_mask || !ref_ptr || !ref_pos || !min_dist2 || !res_mask) return fail(DBFR_ERR_ARG, "null argument");
+  // the reference compares float32 distances with the Python double cutoff ** 2 cast to float32
+  launch_select_pocket(n_prot, n_res_total, res_ptr, atoms_per_res, atom_pos, atom_mask, ref_ptr, ref_pos, (float)(cutoff * cutoff),
+                       max_neighbors, min_dist2, res_mask, (hipStream_t)hip_stream);
   HIPCHECK(hipGetLastError());
   return DBFR_OK;
 }

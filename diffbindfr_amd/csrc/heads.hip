@@ -569,6 +569,80 @@ void launch_extract_templates(int n_res, const int* aatype, const float* pos14, 
                        frames, rigid, angle);
 }
 
+// ------------------------------------------------------------------------------------------------ pocket residue selection
+// select_bs (druglib/utils/bio_utils/select_pocket.py:12-99) for any number of proteins in one pass: thread per residue finds
+// its protein by bisection in res_ptr, then the minimum squared distance between its present atoms and the protein's
+// reference points (float32, summed x, y, z in that order like the reference's torch.sum; absent atoms count as 1e20).
+__global__ void k_pocket_min_dist(int n_prot, int n_res_total, const int* __restrict__ res_ptr, int m, const float* __restrict__ pos,
+                                  const float* __restrict__ mask, const int* __restrict__ ref_ptr, const float* __restrict__ ref,
+                                  float* __restrict__ d2out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_res_total) return;
+  int lo = 0, hi = n_prot;                       // res_ptr[lo] <= r < res_ptr[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (res_ptr[mid] <= r) lo = mid; else hi = mid;
+  }
+  const int l0 = ref_ptr[lo], l1 = ref_ptr[lo + 1];
+  float best = 1e20f;
+  for (int a = 0; a < m; ++a) {
+    if (mask[(size_t)r * m + a] == 0.f) continue;
+    const float x = pos[((size_t)r * m + a) * 3], y = pos[((size_t)r * m + a) * 3 + 1], z = pos[((size_t)r * m + a) * 3 + 2];
+    for (int l = l0; l < l1; ++l) {
+      const float dx = x - ref[3 * l], dy = y - ref[3 * l + 1], dz = z - ref[3 * l + 2];
+      best = fminf(best, dx * dx + dy * dy + dz * dz);
+    }
+  }
+  d2out[r] = best;
+}
+
+// One workgroup per protein: the nearest residue is always kept (first index on ties, like torch.argmin); with a neighbour
+// cap only the max_neighbors nearest selected residues stay (ties by index).
+__global__ __launch_bounds__(256) void k_pocket_finalize(const int* __restrict__ res_ptr, const float* __restrict__ d2, float cut2,
+                                                         int max_neighbors, unsigned char* __restrict__ out) {
+  __shared__ float sd[256];
+  __shared__ int si[256];
+  const int r0 = res_ptr[blockIdx.x], n = res_ptr[blockIdx.x + 1] - r0;
+  const int tid = threadIdx.x;
+  float bd = INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < n; i += 256) {
+    float v = d2[r0 + i];
+    if (v < bd) { bd = v; bi = i; }              // ascending i per thread: keeps the first minimum
+  }
+  sd[tid] = bd; si[tid] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      if (sd[tid + s] < sd[tid] || (sd[tid + s] == sd[tid] && si[tid + s] < si[tid])) { sd[tid] = sd[tid + s]; si[tid] = si[tid + s]; }
+    }
+    __syncthreads();
+  }
+  const int amin = si[0];
+  for (int i = tid; i < n; i += 256) {
+    const float v = d2[r0 + i];
+    bool in = v <= cut2 || i == amin;
+    if (in && max_neighbors > 0) {
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const float w = d2[r0 + j];
+        const bool jin = w <= cut2 || j == amin;
+        rank += (jin && (w < v || (w == v && j < i))) ? 1 : 0;
+      }
+      in = rank < max_neighbors;
+    }
+    out[r0 + i] = in ? 1 : 0;
+  }
+}
+
+void launch_select_pocket(int n_prot, int n_res_total, const int* res_ptr, int m, const float* pos, const float* mask, const int* ref_ptr,
+                          const float* ref, float cut2, int max_neighbors, float* d2, unsigned char* out, hipStream_t st) {
+  if (n_prot <= 0 || n_res_total <= 0) return;
+  hipLaunchKernelGGL(k_pocket_min_dist, dim3((n_res_total + 127) / 128), dim3(128), 0, st, n_prot, n_res_total, res_ptr, m, pos, mask,
+                     ref_ptr, ref, d2);
+  hipLaunchKernelGGL(k_pocket_finalize, dim3(n_prot), dim3(256), 0, st, res_ptr, d2, cut2, max_neighbors, out);
+}
+
 // ------------------------------------------------------------------------------------------------ small utilities
 __global__ void k_fill(float* p, float v, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

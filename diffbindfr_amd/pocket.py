@@ -126,3 +126,73 @@ def pocket_records(aatype, atom14_position, atom14_mask, res_ptr=None, device="c
         d["pocket_center_pos"] = centre[p]
         out.append(d)
     return out
+
+
+def select_pocket(atom_pos, atom_mask, ref_pos, cutoff=12.0, max_neighbors=None, res_ptr=None, ref_ptr=None, atoms_id=None):
+    """Binding-site residues on the device -- ``Protein.query_region`` / ``select_bs_any`` / ``select_bs_atoms`` /
+    ``select_bs_centroid`` (druglib/utils/obj/protein.py:154-240, druglib/utils/bio_utils/select_pocket.py:12-199; the shipped
+    pipeline: mode 'any', cutoff 12 A, all ligand atoms, diffbindfr_ts.py:33-41).
+
+    atom_pos [N_res, M, 3] (atom37 / atom14, or [N_res, 3] centroids), atom_mask [N_res, M] (or [N_res]), ref_pos [N_ref, 3];
+    several proteins at once: rows res_ptr[p]..res_ptr[p+1] belong to protein p and use the reference points
+    ref_ptr[p]..ref_ptr[p+1].  ``atoms_id``: atom columns to use (the reference's atom-name / element modes).
+    Returns (mask bool [N_res], min_dist2 float [N_res]) on the device."""
+    lib = L.load()
+    dev = atom_pos.device
+    if dev.type != "cuda":
+        raise L.DbfrError("select_pocket needs a ROCm device (no CPU path)")
+    pos = atom_pos.to(torch.float32)
+    msk = torch.as_tensor(atom_mask).to(device=dev, dtype=torch.float32)
+    if pos.dim() == 2:                                  # centroid mode: one point per residue, present if any atom is
+        pos = pos[:, None, :]
+        msk = (msk.reshape(pos.shape[0], -1) != 0).any(dim=-1, keepdim=True).float()
+    if atoms_id is not None:
+        idx = torch.as_tensor(list(atoms_id), device=dev, dtype=torch.long)
+        pos, msk = pos[:, idx], msk[:, idx]
+    pos, msk = pos.contiguous(), msk.contiguous()
+    n, m = int(pos.shape[0]), int(pos.shape[1])
+    ref = torch.as_tensor(ref_pos).to(device=dev, dtype=torch.float32).contiguous()
+    i32 = lambda x, default: torch.as_tensor(default if x is None else x).to(device=dev, dtype=torch.int32).contiguous()
+    rp, fp = i32(res_ptr, [0, n]), i32(ref_ptr, [0, int(ref.shape[0])])
+    if rp.numel() != fp.numel():
+        raise L.DbfrError("res_ptr and ref_ptr must describe the same number of proteins")
+    d2 = torch.empty(n, device=dev)
+    out = torch.empty(n, device=dev, dtype=torch.uint8)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    L.check(lib.dbfr_select_pocket(int(rp.numel()) - 1, n, p(rp), m, p(pos), p(msk), p(fp), p(ref), float(cutoff),
+                                   0 if max_neighbors is None else int(max_neighbors), p(d2), p(out),
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out.bool(), d2
+
+
+@torch.no_grad()
+def atom37_to_atom14(aatype, atom37_pos, atom37_mask):
+    """``Protein.to_pos14(consider_missing_atoms=True)`` (druglib/utils/obj/prot_math.py:18-43) on the device: the atom14 slots of
+    every residue gathered from its atom37 row, masked by (atom present) x (slot used by the residue type).
+    Returns (atom14_pos [N,14,3], atom14_mask bool [N,14])."""
+    dev = atom37_pos.device
+    tb = _tables(dev)
+    aa = torch.as_tensor(aatype).to(dev).long()
+    m = tb["atom14_to_atom37"][aa]                                                  # [N,14] atom37 id of each slot
+    mask14 = torch.gather(torch.as_tensor(atom37_mask).to(dev).float(), 1, m) * tb["atom14_mask"][aa].float()
+    pos14 = torch.gather(atom37_pos.float(), 1, m[..., None].expand(-1, -1, 3)) * mask14[..., None]
+    return pos14, mask14.bool()
+
+
+@torch.no_grad()
+def pockets_from_proteins(aatype, atom37_pos, atom37_mask, ref_pos, cutoff=12.0, max_neighbors=None, res_ptr=None, ref_ptr=None,
+                          decentre=True):
+    """The protein side of ``test_pre_transform_prot`` after ``LoadProtein`` (diffbindfr_ts.py:33-45): SCPocketFinderDefault
+    (selection by the ligand's atoms + template extraction), PocketGraphBuilder, PocketFeaturizer, Decentration -- for any
+    number of (protein, reference ligand) pairs in one pass.  Returns (records: list of pocket halves as ``pocket_records``
+    gives them, pocket_mask bool [N_res_total] on the device)."""
+    dev = atom37_pos.device
+    mask, _ = select_pocket(atom37_pos, atom37_mask, ref_pos, cutoff, max_neighbors, res_ptr, ref_ptr)
+    n = int(mask.shape[0])
+    rp = torch.tensor([0, n], device=dev) if res_ptr is None else torch.as_tensor(res_ptr).to(dev).long()
+    csum = torch.cat([mask.new_zeros(1, dtype=torch.long), torch.cumsum(mask.long(), 0)])
+    pocket_ptr = csum[rp]                                                           # residues kept before each protein
+    keep = torch.nonzero(mask).flatten()
+    aa = torch.as_tensor(aatype).to(dev).long()[keep]
+    pos14, m14 = atom37_to_atom14(aa, atom37_pos[keep], torch.as_tensor(atom37_mask).to(dev)[keep])
+    return pocket_records(aa, pos14, m14, pocket_ptr, device=dev, decentre=decentre), mask

@@ -211,6 +211,21 @@ int dbfr_extract_templates(int32_t n_res, const int32_t* aatype, const float* at
                            float* backbone_rots, float* default_frame, float* rigid_group_positions,
                            float* torsion_angle, void* hip_stream);
 
+/* Binding-site residues of n_prot proteins in one pass (ahead of row f2): what
+ * Protein.query_region / select_bs computes (druglib/utils/obj/protein.py:154-240,
+ * druglib/utils/bio_utils/select_pocket.py:12-99; SCPocketFinderDefault uses mode
+ * 'any', cutoff 12, all ligand atoms, pocket_pipeline.py:147-161).  Residue r of
+ * protein p (rows res_ptr[p]..res_ptr[p+1]) is selected iff the squared distance
+ * between one of its present atoms and one of the protein's reference points
+ * (rows ref_ptr[p]..ref_ptr[p+1] of ref_pos) is <= cutoff^2; the nearest residue is
+ * always selected; max_neighbors > 0 keeps only that many nearest selected
+ * residues.  atoms_per_res = 37 / 14 (mode 'any'), a column subset (atom modes) or
+ * 1 (centroids).  All pointers are device pointers; min_dist2 [n_res_total] and
+ * res_mask [n_res_total] (0/1 bytes) are outputs.                                   */
+int dbfr_select_pocket(int32_t n_prot, int32_t n_res_total, const int32_t* res_ptr, int32_t atoms_per_res,
+                       const float* atom_pos, const float* atom_mask, const int32_t* ref_ptr, const float* ref_pos,
+                       double cutoff, int32_t max_neighbors, float* min_dist2, uint8_t* res_mask, void* hip_stream);
+
 /* ---- output side: what `complex_modeling`
  * (DiffBindFR/evaluation/export.py:106-312) does with the trajectories dbfr_sample
  * returns -- the per-pose metrics and the PDB text of every pose.                  */

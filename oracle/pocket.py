@@ -148,3 +148,24 @@ def pocket_features(aatype, atom14_mask, tables):
     bb = torch.zeros(aatype.shape[0], 14)
     bb[:, :4] = 1.
     return torch.stack(cols + [bb], dim=-1).float() * atom14_mask.bool().unsqueeze(-1)
+
+
+def select_bs(ref_pos, atom_positions, atom_mask, cutoff=10.0, max_neighbors=None, big_value=1e20):
+    """druglib/utils/bio_utils/select_pocket.py:12-99 (`select_bs` with `_select_min` and `_max_neig_trunc`), the rule behind
+    `Protein.query_region` (protein.py:154-240) / `SCPocketFinderDefault` (pocket_pipeline.py:147-161; the shipped config uses mode
+    'any', cutoff 12, all ligand atoms).  ref_pos [N_l,3], atom_positions [N_res,M,3], atom_mask [N_res,M] ->
+    (bool [N_res], per-residue minimum squared distance).  A residue is in iff its nearest present atom is within the cutoff
+    (inclusive) of some reference point; the nearest residue is always in; with max_neighbors only that many nearest stay."""
+    m = atom_mask.bool()
+    d = torch.sum((atom_positions[..., None, :] - ref_pos[None, None, :, :]) ** 2, dim=-1)          # [N_res,M,N_l]
+    d = torch.maximum(d, (~m)[..., None].float() * big_value)
+    per_res = torch.amin(d, dim=(-2, -1))
+    mask = per_res <= cutoff ** 2
+    mask[torch.argmin(per_res)] = True
+    if max_neighbors is not None:
+        dd = per_res.clone()
+        dd[~mask] = big_value
+        keep = torch.zeros_like(mask)
+        keep[torch.sort(dd)[1][:max_neighbors]] = True
+        mask = mask & keep
+    return mask, per_res

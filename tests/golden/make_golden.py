@@ -710,6 +710,43 @@ def golden_export():
     np.savez_compressed(os.path.join(HERE, "export.npz"), **out)
 
 
+def golden_pocket_select():
+    """The residue selection ahead of row f2 (druglib/utils/bio_utils/select_pocket.py, Protein.query_region): the reference's
+    own torch functions on the 281-residue 3DBS cut of export.npz (inputs live there), several cutoffs / neighbour caps /
+    atom selections."""
+    print("[pocket selection 3DBS]")
+    from oracle import pocket as opk
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("druglib.utils.bio_utils.select_pocket",
+                                                  os.path.join(ref_shims.COPY, "druglib", "utils", "bio_utils", "select_pocket.py"))
+    sp = importlib.util.module_from_spec(spec)
+    sp.__package__ = "druglib.utils.bio_utils"
+    spec.loader.exec_module(sp)
+    z = np.load(os.path.join(HERE, "export.npz"))
+    pos, msk, lig = torch.from_numpy(z["atom37_pos"]), torch.from_numpy(z["atom37_mask"]), torch.from_numpy(z["lig_pos"])
+    out = {}
+    cases = [("any12", 12.0, None, None), ("any8", 8.0, None, None), ("any12_top40", 12.0, 40, None), ("any3", 3.0, None, None),
+             ("far", 0.5, None, None), ("ca10", 10.0, None, (1,)), ("bb9_top25", 9.0, 25, (0, 1, 2, 4))]
+    for name, cut, cap, atoms in cases:
+        if atoms is None:
+            ref = sp.select_bs_any(lig.clone(), pos.clone(), msk.clone(), cutoff=cut, max_neighbors=cap)
+            mine, d2 = opk.select_bs(lig, pos, msk, cut, cap)
+        else:
+            ref = sp.select_bs_atoms(lig.clone(), pos.clone(), msk.clone(), atoms, cutoff=cut, max_neighbors=cap)
+            mine, d2 = opk.select_bs(lig, pos[:, list(atoms)], msk[:, list(atoms)], cut, cap)
+        assert torch.equal(ref, mine), name
+        out["ref_" + name] = npy(ref)
+        out["d2_" + name] = npy(d2)
+        print(f"  pinned select_bs {name:12s} {int(ref.sum()):4d} residues")
+    assert int(out["ref_any12"].sum()) == int(z["pocket_mask"].sum()) and int(out["ref_far"].sum()) == 1
+    cen = (pos * msk[..., None]).sum(1) / msk.sum(1, keepdim=True)
+    ref = sp.select_bs_centroid(lig.clone(), cen.clone(), msk.clone(), cutoff=9.0, max_neighbors=None)
+    mine, d2 = opk.select_bs(lig, cen[:, None], msk.bool().any(-1, keepdim=True), 9.0, None)
+    assert torch.equal(ref, mine), "centroid"
+    out["ref_centroid9"], out["d2_centroid9"], out["centroids"] = npy(ref), npy(d2), npy(cen)
+    np.savez_compressed(os.path.join(HERE, "pocket_select.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_geometry()
@@ -720,4 +757,5 @@ if __name__ == "__main__":
     golden_pocket()
     golden_real_complex()
     golden_export()
+    golden_pocket_select()
     print("golden fixtures written to", HERE)

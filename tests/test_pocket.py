@@ -113,3 +113,99 @@ def test_gpu_pocket_records_to_poses():
     samp = dba.DiffBindFRHIP(diffusion_model=bench.seeded_params().to(dev), test_cfg={})
     res = samp.sample_complexes(crs, 2, dev, seed=1)
     assert len(res) == 4 and all(torch.isfinite(l).all() and torch.isfinite(a).all() for l, a in res)
+
+
+# ------------------------------------------------------------------------------------------------ residue selection
+
+def select_fixture():
+    return np.load(os.path.join(GOLDEN, "export.npz")), np.load(os.path.join(GOLDEN, "pocket_select.npz"))
+
+
+SELECT_CASES = [("any12", 12.0, None, None), ("any8", 8.0, None, None), ("any12_top40", 12.0, 40, None), ("any3", 3.0, None, None),
+                ("far", 0.5, None, None), ("ca10", 10.0, None, (1,)), ("bb9_top25", 9.0, 25, (0, 1, 2, 4))]
+
+
+def test_oracle_pocket_selection_matches_reference_fixture():
+    z, ref = select_fixture()
+    pos, msk, lig = torch.from_numpy(z["atom37_pos"]), torch.from_numpy(z["atom37_mask"]), torch.from_numpy(z["lig_pos"])
+    for name, cut, cap, atoms in SELECT_CASES:
+        cols = slice(None) if atoms is None else list(atoms)
+        mask, d2 = opk.select_bs(lig, pos[:, cols], msk[:, cols], cut, cap)
+        assert np.array_equal(mask.numpy(), ref["ref_" + name]), name
+        assert np.abs(d2.numpy() - ref["d2_" + name]).max() <= 1e-4 * max(1.0, float(ref["d2_" + name][ref["d2_" + name] < 1e19].max()))
+    assert int(ref["ref_any12"].sum()) == 105 and np.array_equal(ref["ref_any12"], z["pocket_mask"]) and int(ref["ref_far"].sum()) == 1
+    mask, _ = opk.select_bs(lig, torch.from_numpy(ref["centroids"])[:, None], msk.bool().any(-1, keepdim=True), 9.0, None)
+    assert np.array_equal(mask.numpy(), ref["ref_centroid9"])
+
+
+def test_select_pocket_has_no_cpu_path():
+    z, _ = select_fixture()
+    with pytest.raises(Exception):
+        pocket.select_pocket(torch.from_numpy(z["atom37_pos"]), z["atom37_mask"], z["lig_pos"])
+
+
+@pytest.mark.gpu
+def test_gpu_select_pocket_matches_reference_fixture():
+    z, ref = select_fixture()
+    dev = torch.device("cuda:0")
+    pos, msk, lig = torch.from_numpy(z["atom37_pos"]).to(dev), torch.from_numpy(z["atom37_mask"]).to(dev), torch.from_numpy(z["lig_pos"]).to(dev)
+    for name, cut, cap, atoms in SELECT_CASES:
+        mask, d2 = pocket.select_pocket(pos, msk, lig, cut, cap, atoms_id=atoms)
+        assert np.array_equal(mask.cpu().numpy(), ref["ref_" + name]), name
+        assert np.array_equal(d2.cpu().numpy(), ref["d2_" + name]), name            # same fp32 operation order: bit-equal distances
+    mask, _ = pocket.select_pocket(torch.from_numpy(ref["centroids"]).to(dev), msk, lig, 9.0)
+    assert np.array_equal(mask.cpu().numpy(), ref["ref_centroid9"])
+
+
+@pytest.mark.gpu
+def test_gpu_select_pocket_many_proteins_vs_oracle():
+    """A target-fishing style batch: 37 ragged proteins (1..400 residues, one with no atoms at all in a residue), each with its
+    own reference points, one launch; every protein must equal the oracle run on it alone."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    sizes = [1, 2, 400] + [int(rng.integers(3, 300)) for _ in range(34)]
+    nref = [int(rng.integers(1, 60)) for _ in sizes]
+    pos = [(rng.standard_normal((n, 14, 3)) * 2 + rng.standard_normal((n, 1, 3)) * 15).astype(np.float32) for n in sizes]
+    msk = [(rng.random((n, 14)) > 0.2).astype(np.float32) for n in sizes]
+    msk[2][5] = 0.0
+    refs = [(rng.standard_normal((k, 3)) * 8).astype(np.float32) for k in nref]
+    res_ptr, ref_ptr = np.concatenate([[0], np.cumsum(sizes)]), np.concatenate([[0], np.cumsum(nref)])
+    for cut, cap in ((12.0, None), (6.5, 16), (0.01, None)):
+        mask, d2 = pocket.select_pocket(torch.from_numpy(np.concatenate(pos)).to(dev), torch.from_numpy(np.concatenate(msk)).to(dev),
+                                        torch.from_numpy(np.concatenate(refs)).to(dev), cut, cap, res_ptr=res_ptr, ref_ptr=ref_ptr)
+        mask, d2 = mask.cpu().numpy(), d2.cpu().numpy()
+        for p_, n in enumerate(sizes):
+            want, wd = opk.select_bs(torch.from_numpy(refs[p_]), torch.from_numpy(pos[p_]), torch.from_numpy(msk[p_]), cut, cap)
+            sl = slice(res_ptr[p_], res_ptr[p_ + 1])
+            assert np.array_equal(mask[sl], want.numpy()), (cut, cap, p_)
+            assert np.allclose(d2[sl], wd.numpy(), rtol=1e-6, atol=0)
+            assert mask[sl].sum() >= 1                                       # the nearest residue is always kept
+
+
+@pytest.mark.gpu
+def test_gpu_protein_to_pocket_records_chain():
+    """LoadProtein's arrays -> selection -> atom14 -> templates / masks / features in one call, two proteins at once; the 3DBS
+    pocket it finds is the fixture's, its templates the reference's (real_3dbs.npz was frozen from the same PDB file)."""
+    z, ref = select_fixture()
+    real = np.load(os.path.join(GOLDEN, "real_3dbs.npz"))
+    dev = torch.device("cuda:0")
+    aa = z["aatype"].copy()
+    aa[3] = 0 if aa[3] == 20 else aa[3]
+    n = aa.shape[0]
+    pos = torch.from_numpy(np.concatenate([z["atom37_pos"], z["atom37_pos"] + 100.0])).to(dev)
+    msk = torch.from_numpy(np.concatenate([z["atom37_mask"], z["atom37_mask"]])).to(dev)
+    lig = torch.from_numpy(np.concatenate([z["lig_pos"], z["lig_pos"][:10] + 100.0])).to(dev)
+    recs, mask = pocket.pockets_from_proteins(np.concatenate([aa, aa]), pos, msk, lig, 12.0, res_ptr=[0, n, 2 * n],
+                                              ref_ptr=[0, 35, 45])
+    assert np.array_equal(mask[:n].cpu().numpy(), z["pocket_mask"]) and len(recs) == 2
+    assert 0 < int(mask[n:].sum()) < int(mask[:n].sum())                   # fewer reference atoms -> smaller pocket
+    r0 = recs[0]
+    same = (r0["sequence"].numpy() == real["aatype"])
+    assert r0["sequence"].shape[0] == 105 and same.sum() >= 104
+    d = ang_diff(r0["torsion_angle"].numpy(), real["ref_torsion_angle"]) * same[:, None]
+    assert d.max() < 2e-4
+    assert np.abs((r0["rigid_group_positions"].numpy() - real["ref_rigid_group_positions"]) * same[:, None, None]).max() < TOL
+    m14 = np.asarray(real["atom14_mask"]).astype(bool)
+    keep_rows = same & (z["atom37_mask"][z["pocket_mask"]][:, 36] == 0)     # rows the export fixture did not edit
+    assert np.array_equal(r0["atom14_mask"].numpy()[keep_rows], m14[keep_rows])
+    assert abs(float(r0["atom14_position"][r0["atom14_mask"]][:, 0].mean())) < 3.0   # decentred
