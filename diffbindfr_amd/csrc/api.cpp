@@ -354,8 +354,18 @@ extern "C" int dbfr_conv_paths(int32_t kind, int32_t* t10, int32_t max_paths, in
   return n;
 }
 
+static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tensors, int32_t n_tensors, dbfr_model** out);
+
 extern "C" int dbfr_model_create(const dbfr_model_cfg* cfg, const dbfr_tensor* tensors, int32_t n_tensors,
                                  dbfr_model** out) {
+  try {   // weight re-tiling allocates on the host: no exception crosses the C ABI
+    return model_create_impl(cfg, tensors, n_tensors, out);
+  } catch (const std::exception& e) {
+    return fail(DBFR_ERR_ARG, std::string("dbfr_model_create: ") + e.what());
+  }
+}
+
+static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tensors, int32_t n_tensors, dbfr_model** out) {
   if (!cfg || !tensors || !out) return fail(DBFR_ERR_ARG, "null argument");
   if (cfg->ns != NS || cfg->nv != NV || cfg->sh_lmax != 2 || cfg->distance_embed_dim != EMB ||
       cfg->sigma_embed_dim != EMB || cfg->num_conv_layers < 1 || cfg->num_conv_layers > 8)

@@ -491,17 +491,23 @@ int check_topology(const dbfr_pdb_topology* t, int n_rows, const int32_t* rows, 
 
 extern "C" int64_t dbfr_pdb_format(const dbfr_pdb_topology* topo, int32_t n_rows, const int32_t* rows, const float* pos14, int32_t model,
                                    int32_t add_end, char* out, int64_t cap) {
-  std::vector<int> row_of;
-  int rc = check_topology(topo, n_rows, rows, pos14, row_of);
-  if (rc) return rc;
-  std::string s;
-  format_structure(*topo, row_of, pos14, model, add_end, s);
-  if ((int64_t)s.size() <= cap && out) memcpy(out, s.data(), s.size());
-  return (int64_t)s.size();
+  try {                                   // no exception crosses the C ABI
+    std::vector<int> row_of;
+    int rc = check_topology(topo, n_rows, rows, pos14, row_of);
+    if (rc) return rc;
+    std::string s;
+    format_structure(*topo, row_of, pos14, model, add_end, s);
+    if ((int64_t)s.size() <= cap && out) memcpy(out, s.data(), s.size());
+    return (int64_t)s.size();
+  } catch (const std::exception& e) {
+    dbfr_set_error(std::string("dbfr_pdb_format: ") + e.what());
+    return DBFR_ERR_ARG;
+  }
 }
 
 extern "C" int dbfr_pdb_write_files(const dbfr_pdb_topology* topo, int32_t n_rows, const int32_t* rows, const float* pos14, int32_t n_pose,
                                     const char* const* paths, int32_t n_threads) {
+  try {                                   // no exception crosses the C ABI (thread creation / allocation may throw)
   std::vector<int> row_of;
   int rc = check_topology(topo, n_rows, rows, pos14, row_of);
   if (rc) return rc;
@@ -512,22 +518,30 @@ extern "C" int dbfr_pdb_write_files(const dbfr_pdb_topology* topo, int32_t n_row
   int nt = n_threads > 0 ? n_threads : std::min(hw, (int)n_pose);
   nt = std::max(1, std::min(nt, (int)n_pose));
   std::atomic<int> next(0), failed(-1);
-  auto work = [&]() {
-    std::string s;
-    for (;;) {
-      int i = next.fetch_add(1);
-      if (i >= n_pose) break;
-      format_structure(*topo, row_of, pos14 + (size_t)i * n_rows * 42, -1, 1, s);
-      FILE* f = fopen(paths[i], "wb");
-      bool ok = f && fwrite(s.data(), 1, s.size(), f) == s.size();
-      if (f) ok = (fclose(f) == 0) && ok;
-      if (!ok) { int e = -1; failed.compare_exchange_strong(e, i); }
-    }
+  auto work = [&]() noexcept {
+    try {
+      std::string s;
+      for (;;) {
+        int i = next.fetch_add(1);
+        if (i >= n_pose) break;
+        format_structure(*topo, row_of, pos14 + (size_t)i * n_rows * 42, -1, 1, s);
+        FILE* f = fopen(paths[i], "wb");
+        bool ok = f && fwrite(s.data(), 1, s.size(), f) == s.size();
+        if (f) ok = (fclose(f) == 0) && ok;
+        if (!ok) { int e = -1; failed.compare_exchange_strong(e, i); }
+      }
+    } catch (...) { int e = -1; failed.compare_exchange_strong(e, 0); }
   };
   std::vector<std::thread> th;
-  for (int k = 1; k < nt; ++k) th.emplace_back(work);
+  for (int k = 1; k < nt; ++k) {
+    try { th.emplace_back(work); } catch (...) { break; }      // fewer helpers: the calling thread picks up the rest
+  }
   work();
   for (auto& x : th) x.join();
   if (failed.load() >= 0) { dbfr_set_error(std::string("cannot write ") + paths[failed.load()]); return DBFR_ERR_ARG; }
   return DBFR_OK;
+  } catch (const std::exception& e) {
+    dbfr_set_error(std::string("dbfr_pdb_write_files: ") + e.what());
+    return DBFR_ERR_ARG;
+  }
 }
