@@ -19,6 +19,7 @@ struct GraphArgs {
   int lig_cap, atom_cap, dynamic_cross;
   EdgeSet set[N_SETS];
   int* err;
+  int step, lds_nl, lds_na;
 };
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
 void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
@@ -53,7 +54,7 @@ struct SdeLigArgs {
 };
 void launch_sde_ligand(const SdeLigArgs& a, hipStream_t st);
 void launch_sidechain(const dbfr_batch& b, const float* score, const float* z, float dt, float g2, float gsdt,
-                      const int* a14_group, float* atom14_out, float* traj14, hipStream_t st);
+                      const int* a14_group, float* atom14_out, float* traj14, const int* err, hipStream_t st);
 void launch_fill(float* p, float v, int n, hipStream_t st);
 void launch_set_int(int* p, int v, hipStream_t st);
 void launch_init_poses(const dbfr_batch& b, const dbfr_init_tape& z, const int* a14_group, float* atom14_out, hipStream_t st);
@@ -526,7 +527,7 @@ static int check_batch(const dbfr_model* m, const dbfr_batch* B) {
   if (!m || !B) return fail(DBFR_ERR_ARG, "null argument");
   if (B->G <= 0 || B->NL <= 0 || B->NA <= 0 || B->NR <= 0) return fail(DBFR_ERR_ARG, "empty batch");
   if (B->max_nl > 256) return fail(DBFR_ERR_ARG, "ligand with more than 256 heavy atoms is not supported");
-  if (B->max_na > 2048) return fail(DBFR_ERR_ARG, "pocket with more than 2048 heavy atoms is not supported");
+  if (B->max_na > 8192) return fail(DBFR_ERR_ARG, "pocket with more than 8192 heavy atoms is not supported");
   if (B->max_nl <= 0 || B->max_na <= 0 || B->max_nr <= 0) return fail(DBFR_ERR_ARG, "max_nl/max_na/max_nr must be set");
   return DBFR_OK;
 }
@@ -548,7 +549,10 @@ static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int ma
   a.tab1 = tab1; a.ld1 = ld1; a.idx1 = idx1; a.tab2 = tab2; a.ld2 = ld2; a.idx2 = idx2; a.x = x; a.ldx = ldx;
   a.w = cw; a.msg = msg;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool prof = m->profile && cw.K == 144;   // the dominant kernel k_conv<144> only (k_conv<96>: 3 short launches per step)
+  // the dominant kernel k_conv<144> only (k_conv<96>: 3 short launches per step).  profile 1: HIP events around every
+  // launch (convs serialised on the main stream) + flop counter; profile 2: flop counter only, streams as in production
+  const bool prof = m->profile == 1 && cw.K == 144;
+  const bool count = m->profile && cw.K == 144;
   if (prof) {
     if (m->ev_used + 2 > m->ev.size()) {
       size_t old = m->ev.size();
@@ -559,8 +563,8 @@ static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int ma
     (void)hipEventRecord(e0, st);
   }
   launch_conv(a, st);
-  if (prof) {
-    (void)hipEventRecord(e1, st);
+  if (prof) (void)hipEventRecord(e1, st);
+  if (count) {
     // algorithmic flops per edge: radial MLP 2K(K + W) + tensor-product contraction 2*(sum_paths mul1*mulo*dim_o)
     // second counter: HBM bytes the reference's two-kernel form moves per edge (the [E,W] weights once,
     // gathered irreps, harmonics, two int64 indices); the fused kernel never materialises them
@@ -569,7 +573,7 @@ static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int ma
 }
 
 static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, const dbfr_scores* out, Ws& w,
-                     hipStream_t st) {
+                     hipStream_t st, int step = 0) {
   const dbfr_model_cfg& cfg = m->cfg;
   const int G = B->G, NL = B->NL, NA = B->NA;
   launch_time_embed(c->t, G, cfg.emb_scale, w.temb, st);
@@ -581,7 +585,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   ga.cross_cut2 = cfg.dynamic_max_cross ? 1.0f : cfg.cross_cutoff * cfg.cross_cutoff;
   ga.lig_cap = cfg.lig_max_neighbors; ga.atom_cap = cfg.atom_max_neighbors; ga.dynamic_cross = cfg.dynamic_max_cross;
   for (int k = 0; k < N_SETS; ++k) ga.set[k] = w.set[k];
-  ga.err = w.err;
+  ga.err = w.err; ga.step = step; ga.lds_nl = ga.lds_na = 0;
   launch_edges(ga, false, st);
   // ---- embeddings
   {
@@ -615,7 +619,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
     float *lnew = w.lig_x[cur ^ 1], *anew = w.atom_x[cur ^ 1];
     const EdgeSet &LL = w.set[SET_LL], &AA = w.set[SET_AA], &AL = w.set[SET_AL], &LA = w.set[SET_LA];
-    if (!w.multi || m->profile) {   // profiling times each conv alone on the main stream
+    if (!w.multi || m->profile == 1) {   // profiling times each conv alone on the main stream
       conv_call(m, m->layer[l][0], LL.n_edges, LL.cap, LL.tgt, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0], st);
       launch_reduce_ln(w.msg[0], LL.row_start, LL.row_cnt, NL, Do, m->layer[l][0].ln, lx, Di, lnew, Do, 0, st);
       conv_call(m, m->layer[l][1], AL.n_edges, AL.cap, AL.tgt, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[0], st);
@@ -737,16 +741,18 @@ extern "C" int dbfr_score(dbfr_model* m, const dbfr_batch* b, const dbfr_cond* c
   return DBFR_OK;
 }
 
-extern "C" int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps,
-                           const dbfr_noise* noise, float* atom14_out, float* traj_lig, float* traj_atom14,
-                           void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream) {
+extern "C" int dbfr_sample_range(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps,
+                                 int32_t step_begin, const dbfr_noise* noise, float* atom14_out, float* traj_lig,
+                                 float* traj_atom14, void* workspace, size_t workspace_bytes, const dbfr_limits* lim,
+                                 void* hip_stream) {
   if (!steps || n_steps <= 0 || !noise) return fail(DBFR_ERR_ARG, "null argument");
+  if (step_begin < 0 || step_begin >= n_steps) return fail(DBFR_ERR_ARG, "step_begin out of range");
   hipStream_t st = (hipStream_t)hip_stream;
   Ws w;
   int rc = begin(m, b, workspace, workspace_bytes, lim, &w, st);
   if (rc) return rc;
   const int G = b->G;
-  for (int s = 0; s < n_steps; ++s) {
+  for (int s = step_begin; s < n_steps; ++s) {
     const dbfr_step& sp = steps[s];
     // set_time (scFlex.py:104-122): uniform conditioning over the batch
     launch_fill(w.c_t, sp.t, G, st);
@@ -756,7 +762,7 @@ extern "C" int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* 
     launch_fill(w.c_sc_n2, sp.tor_score_norm2, b->NSC, st);
     dbfr_cond c = {w.c_t, w.c_tr_sigma, w.c_rot_norm, w.c_tor_n2, w.c_sc_n2};
     dbfr_scores sc = {w.s_tr, w.s_rot, w.s_tor, w.s_sc};
-    rc = run_score(m, b, &c, &sc, w, st);
+    rc = run_score(m, b, &c, &sc, w, st, s);
     if (rc) return rc;
     SdeLigArgs la;
     la.b = *b; la.tr_score = w.s_tr; la.rot_score = w.s_rot; la.tor_score = w.s_tor;
@@ -770,10 +776,30 @@ extern "C" int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* 
     if (!m->cfg.no_sc_torsion) {
       const bool last = s == n_steps - 1;
       launch_sidechain(*b, w.s_sc, noise->z_sc + (size_t)s * b->NSC, sp.dt, sp.sc_g2, sp.sc_gsdt, m->a14_group,
-                       last ? atom14_out : nullptr, traj_atom14 ? traj_atom14 + (size_t)s * b->NR * 42 : nullptr, st);
+                       last ? atom14_out : nullptr, traj_atom14 ? traj_atom14 + (size_t)s * b->NR * 42 : nullptr, w.err, st);
     }
   }
   HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps,
+                           const dbfr_noise* noise, float* atom14_out, float* traj_lig, float* traj_atom14,
+                           void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream) {
+  return dbfr_sample_range(m, b, steps, n_steps, 0, noise, atom14_out, traj_lig, traj_atom14, workspace, workspace_bytes, lim,
+                           hip_stream);
+}
+
+extern "C" int dbfr_capacity_report(void* workspace, void* hip_stream, int32_t* first_failed_step, int64_t* needed_edges) {
+  if (!workspace) return fail(DBFR_ERR_ARG, "null workspace");
+  HIPCHECK(hipStreamSynchronize((hipStream_t)hip_stream));
+  int h[16];
+  HIPCHECK(hipMemcpy(h, workspace, sizeof h, hipMemcpyDeviceToHost));   // err block @0 (plan())
+  if (first_failed_step) *first_failed_step = h[1] - 1;
+  if (needed_edges) {   // dbfr_status_sync's counter order: lig, atom, cross(al), -, tor, sc_tor, cross(la), -
+    needed_edges[0] = h[8 + SET_LL]; needed_edges[1] = h[8 + SET_AA]; needed_edges[2] = h[8 + SET_AL]; needed_edges[3] = 0;
+    needed_edges[4] = h[8 + SET_TOR]; needed_edges[5] = h[8 + SET_SC]; needed_edges[6] = h[8 + SET_LA]; needed_edges[7] = 0;
+  }
   return DBFR_OK;
 }
 

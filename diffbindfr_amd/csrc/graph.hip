@@ -16,8 +16,9 @@
 // radius_graph queries max+1 then drops the self loop.
 #include "common.h"
 
-#define MAX_NL 256
-#define MAX_NA 2048
+#define MAX_NL 256      // per-graph ligand atoms (the ligand kernels of heads.hip keep a conformer in static LDS)
+#define MAX_NA 8192     // per-graph pocket atoms: the graph's coordinates are staged in dynamic LDS sized by the batch's
+                        // largest graph (16 B per atom, 128 KB of the CU's 160 KB at the limit)
 
 enum SetKind { SET_LL = 0, SET_AA = 1, SET_AL = 2, SET_LA = 3, SET_TOR = 4, SET_SC = 5, N_SETS = 6 };
 
@@ -31,7 +32,10 @@ struct GraphArgs {
   float lig_cut2, atom_cut2, cross_cut2;
   int lig_cap, atom_cap, dynamic_cross;
   EdgeSet set[N_SETS];
-  int* err;               // device status word
+  int* err;               // device status block: [0] status bits, [1] first step (+1) whose edge lists overflowed,
+                          // [2+k] set k overflowed in THIS step, [8+k] largest edge count seen for set k
+  int step;               // sampler step index (0 for dbfr_score)
+  int lds_nl, lds_na;     // LDS staging capacities (>= max_nl / max_na of the batch)
 };
 
 __device__ __forceinline__ float d2_rn(float ax, float ay, float az, float bx, float by, float bz) {
@@ -63,13 +67,21 @@ __device__ __forceinline__ float vec_sh(float vx, float vy, float vz, float* sh9
   return nrm;
 }
 
-// shared staging of one graph
+// shared staging of one graph (views into the dynamic LDS block)
 struct GraphLds {
-  float lx[MAX_NL], ly[MAX_NL], lz[MAX_NL];
-  float ax[MAX_NA], ay[MAX_NA], az[MAX_NA];
-  int thr[MAX_NA];        // radius_graph cap threshold per centre
-  int scan[256];
+  float *lx, *ly, *lz;
+  float *ax, *ay, *az;
+  int* thr;               // radius_graph cap threshold per centre
+  int* scan;              // [256]
 };
+
+__device__ __forceinline__ void lds_views(GraphLds& s, float* base, int nl, int na) {
+  s.scan = reinterpret_cast<int*>(base);
+  s.lx = base + 256; s.ly = s.lx + nl; s.lz = s.ly + nl;
+  s.ax = s.lz + nl; s.ay = s.ax + na; s.az = s.ay + na;
+  s.thr = reinterpret_cast<int*>(s.az + na);      // max(nl, na) entries
+}
+static size_t lds_bytes(int nl, int na) { return 4 * (256 + 3 * (size_t)nl + 3 * (size_t)na + (size_t)(na > nl ? na : nl)); }
 
 __device__ void load_graph(GraphLds& s, const GraphArgs& A, int g, int kind, int& l0, int& nl, int& a0, int& na) {
   l0 = A.b.lig_ptr[g];
@@ -231,10 +243,15 @@ __device__ __forceinline__ void target_range(const GraphArgs& A, int kind, int g
 
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
-  __shared__ GraphLds s;
+  extern __shared__ float dyn_lds[];
+  GraphLds s;
+  lds_views(s, dyn_lds, A.lds_nl, A.lds_na);
   const int g = blockIdx.x, kind = blockIdx.y;
   const EdgeSet& S = A.set[kind];
   if (S.cap == 0) return;
+  // this set did not fit its capacity in this step: leave it EMPTY (row_cnt 0) so that nothing downstream reads past
+  // the buffers; the host re-plans with the counted sizes and resumes from this step (dbfr_capacity_report)
+  const bool overflow = EMIT && A.err[2 + kind] != 0;
   int l0, nl, a0, na;
   load_graph(s, A, g, kind, l0, nl, a0, na);
   if (kind == SET_LL) cap_thresholds(s, s.lx, s.ly, s.lz, nl, A.lig_cut2, A.lig_cap);
@@ -248,7 +265,8 @@ __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
     int cnt = 0;
     if (t < nt) {
       if (EMIT) {
-        cnt = S.row_cnt[t0 + t];
+        cnt = overflow ? 0 : S.row_cnt[t0 + t];
+        if (overflow) S.row_cnt[t0 + t] = 0;
       } else if (kind <= SET_LA) {
         cnt = target_edges<false>(s, A, kind, g, t, l0, nl, a0, na, 0);
       } else if (kind == SET_TOR) {
@@ -274,9 +292,10 @@ __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
     const int incl = s.scan[threadIdx.x], chunk_total = s.scan[255];
     __syncthreads();
     if (EMIT && t < nt) {
-      const int base = running + incl - cnt;
+      const int base = overflow ? 0 : running + incl - cnt;
       S.row_start[t0 + t] = base;
-      if (kind <= SET_LA) {
+      if (overflow) {
+      } else if (kind <= SET_LA) {
         target_edges<true>(s, A, kind, g, t, l0, nl, a0, na, base);
       } else if (kind == SET_TOR) {
         int k = A.b.tor_bond[t0 + t];
@@ -316,16 +335,29 @@ __global__ __launch_bounds__(256) void k_edges_scan(GraphArgs A) {
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (running > S.cap) { atomicOr(A.err, 1); running = 0; }
+    atomicMax(&A.err[8 + blockIdx.x], running);
+    const bool over = running > S.cap;
+    A.err[2 + blockIdx.x] = over;
+    if (over) { atomicOr(A.err, 1); atomicCAS(&A.err[1], 0, A.step + 1); running = 0; }
     *S.n_edges = running;
   }
 }
 
-void launch_edges(const GraphArgs& A, bool with_heads_only, hipStream_t st) {
+void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
   (void)with_heads_only;
-  hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G, N_SETS), dim3(256), 0, st, A);
+  GraphArgs A = A0;
+  A.lds_nl = (A.b.max_nl + 63) & ~63;
+  A.lds_na = (A.b.max_na + 63) & ~63;
+  const size_t lds = lds_bytes(A.lds_nl, A.lds_na);
+  static size_t granted = 64 * 1024;   // above the default 64 KB a kernel has to be told once
+  if (lds > granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    granted = 160 * 1024 - 64;
+  }
+  hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G, N_SETS), dim3(256), lds, st, A);
   hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(k_edges<true>, dim3(A.b.G, N_SETS), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_edges<true>, dim3(A.b.G, N_SETS), dim3(256), lds, st, A);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(128) void k_sde_ligand(SdeLigArgs a) {
   __shared__ float sh_c[3], sh_R[9], sh_t[3], sh_v[3];
   __shared__ double sh_H[9], sh_ca[3], sh_cb[3];
   const int g = blockIdx.x, tid = threadIdx.x;
+  if (a.err[0] & 1) return;   // an edge list overflowed: the state stays at the beginning of that step (dbfr_capacity_report)
   const int l0 = a.b.lig_ptr[g], nl = a.b.lig_ptr[g + 1] - l0;
   const int k0 = a.b.tor_ptr[g], nt = a.b.tor_ptr[g + 1] - k0;
   for (int i = tid; i < nl; i += blockDim.x) {
@@ -311,9 +312,9 @@ void launch_sde_ligand(const SdeLigArgs& a, hipStream_t st) {
 }
 
 // chi[mask] += perturb   (scFlex.py:208-210)
-__global__ void k_sc_update(dbfr_batch b, const float* score, const float* z, float dt, float g2, float gsdt) {
+__global__ void k_sc_update(dbfr_batch b, const float* score, const float* z, float dt, float g2, float gsdt, const int* err) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= b.NSC) return;
+  if (k >= b.NSC || (err[0] & 1)) return;   // frozen after an edge-capacity overflow (see k_sde_ligand)
   int rc = b.sc_res_chi[k];
   int res = rc >> 2, chi = rc & 3;
   float* t = b.torsion_angle + (size_t)res * 5 + 1 + chi;
@@ -379,8 +380,8 @@ __global__ void k_atom14(dbfr_batch b, const int* a14_group /*[21][14]*/, float*
 }
 
 void launch_sidechain(const dbfr_batch& b, const float* score, const float* z, float dt, float g2, float gsdt,
-                      const int* a14_group, float* atom14_out, float* traj14, hipStream_t st) {
-  if (b.NSC > 0) hipLaunchKernelGGL(k_sc_update, dim3((b.NSC + 255) / 256), dim3(256), 0, st, b, score, z, dt, g2, gsdt);
+                      const int* a14_group, float* atom14_out, float* traj14, const int* err, hipStream_t st) {
+  if (b.NSC > 0) hipLaunchKernelGGL(k_sc_update, dim3((b.NSC + 255) / 256), dim3(256), 0, st, b, score, z, dt, g2, gsdt, err);
   if (b.NR > 0) hipLaunchKernelGGL(k_atom14, dim3((b.NR + 63) / 64), dim3(64), 0, st, b, a14_group, atom14_out, traj14);
 }
 
@@ -654,8 +655,9 @@ void launch_fill(float* p, float v, int n, hipStream_t st) {
 __global__ void k_set_int(int* p, int v) { *p = v; }
 void launch_set_int(int* p, int v, hipStream_t st) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, p, v); }
 __global__ void k_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter) {
-  counter[0] += flops_per_edge * (double)*n_edges;
-  counter[1] += bytes_per_edge * (double)*n_edges;
+  // atomics: in profile mode 2 the four convs of a layer run on four streams
+  atomicAdd(&counter[0], flops_per_edge * (double)*n_edges);
+  atomicAdd(&counter[1], bytes_per_edge * (double)*n_edges);
 }
 void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st) {
   hipLaunchKernelGGL(k_acc_flops, dim3(1), dim3(1), 0, st, n_edges, flops_per_edge, bytes_per_edge, counter);

@@ -90,3 +90,97 @@ def max_over_ranks(x, device):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+# ------------------------------------------------------------------------------------------------ the sharded job driver
+def plan_batches(job_poses, batch_poses):
+    """Cut a rank's job list into device batches: jobs stay whole (their static tensors are assembled once per batch), a
+    job with more poses than ``batch_poses`` is cut into chunks at multiples of ``batch_poses``, and the jobs are spread
+    over ceil(total / batch_poses) batches of near-equal pose count (no tiny last batch).
+    ``job_poses``: list of (job index, poses).  Returns list of batches = list of (job index, first pose, n poses)."""
+    units = []
+    for j, p in job_poses:
+        for p0 in range(0, p, batch_poses):
+            units.append((j, p0, min(batch_poses, p - p0)))
+    total = sum(u[2] for u in units)
+    if total == 0:
+        return []
+    n_b = max(1, -(-total // batch_poses))
+    target = total / n_b
+    out, cur, acc, done = [], [], 0, 0
+    for u in units:
+        # close the current batch when adding this unit would overshoot the running target by more than stopping short
+        if cur and (acc + u[2] > batch_poses or (len(out) < n_b - 1 and done + acc + u[2] / 2.0 > target * (len(out) + 1))):
+            out.append(cur); done += acc; cur, acc = [], 0
+        cur.append(u); acc += u[2]
+    if cur:
+        out.append(cur)
+    return out
+
+
+def shard_jobs(jobs, poses, world):
+    """LPT over the jobs' pose-step cost (``ComplexRecord.cost`` x poses); all poses of a job stay on one rank."""
+    reps = [poses] * len(jobs) if isinstance(poses, int) else list(poses)
+    return shard_lpt([j.cost * p for j, p in zip(jobs, reps)], world), reps
+
+
+def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_max=10.0, gather=True, on_batch=None):
+    """The multi-GPU product entry: a job list in, poses out in job order.
+
+        jobs    list of ``assemble.ComplexRecord`` -- the (protein, ligand) pair table of the reference
+                (DiffBindFR/common/dataframe.py:190-234).  Forward screen (BASELINE config 3): the records share ONE
+                ``PocketRecord``; target fishing (config 4): they share ONE ``LigandRecord``; the shared half is
+                replicated on every rank and uploaded once per device.
+        poses   poses per job (int or list)
+
+    Every rank holds the whole (cheap, host-side) job table, takes its LPT share, runs it in batches of <= ``batch_poses``
+    poses through ``sample_complexes`` (per-job random streams => the result does not depend on the sharding), writes
+    fixed-size pose records [ligand N_l,max x 3 | atom14 N_r,max x 14 x 3] and ONE ``all_gather_into_tensor`` brings them to
+    every rank (RCCL over xGMI; the reference's counterpart is the pickled all_gather of
+    druglib/core/runner/engine/test_utils.py:96-145).  No collective on the data path before that.
+    Returns list[len(jobs)] of (lig [P, N_l, 3], atom14 [P, N_r, 14, 3]) device tensors in job order (None when
+    ``gather=False`` on ranks that did not run the job)."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    dev = torch.device(device)
+    shards, reps = shard_jobs(jobs, poses, world)
+    max_nl = max(j.n_l for j in jobs)
+    max_nr = max(j.n_r for j in jobs)
+    R = 3 * max_nl + 42 * max_nr
+    # record rows of a rank: its jobs in shard order, poses consecutive
+    row0 = [{} for _ in range(world)]
+    n_rows = [0] * world
+    for r in range(world):
+        for j in shards[r]:
+            row0[r][j] = n_rows[r]
+            n_rows[r] += reps[j]
+    n_max = max(n_rows)
+    local = torch.zeros(max(n_max, 1), R, device=dev)
+    for bi, batch in enumerate(plan_batches([(j, reps[j]) for j in shards[rank]], batch_poses)):
+        recs = [jobs[j] for j, _, _ in batch]
+        pb, lig, a14 = sampler.run_complexes(recs, [n for _, _, n in batch], device=dev, tr_sigma_max=tr_sigma_max,
+                                             seeds=[sampler.job_seed(seed, j, p0) for j, p0, _ in batch])
+        lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
+        g = 0
+        for j, p0, n in batch:          # the n poses of a job are consecutive, equal-sized graphs: two strided copies per job
+            nl, nr = jobs[j].n_l, jobs[j].n_r
+            rows = local[row0[rank][j] + p0: row0[rank][j] + p0 + n]
+            rows[:, :3 * nl] = lig[-1, lp[g]:lp[g + n]].reshape(n, 3 * nl)
+            rows[:, 3 * max_nl: 3 * max_nl + 42 * nr] = a14[-1, rp[g]:rp[g + n]].reshape(n, 42 * nr)
+            g += n
+        if on_batch is not None:
+            on_batch(bi, sum(n for _, _, n in batch))
+    if world > 1 and gather:
+        allr = gather_records(local, world).view(world, max(n_max, 1), R)
+    else:
+        allr = local.view(1, max(n_max, 1), R) if world == 1 else None
+    res = [None] * len(jobs)
+    for r in range(world):
+        if allr is None and r != rank:
+            continue
+        src = allr[r] if allr is not None else local
+        for j in shards[r]:
+            rows = src[row0[r][j]: row0[r][j] + reps[j]]
+            nl, nr = jobs[j].n_l, jobs[j].n_r
+            res[j] = (rows[:, :3 * nl].reshape(reps[j], nl, 3), rows[:, 3 * max_nl: 3 * max_nl + 42 * nr].reshape(reps[j], nr, 14, 3))
+    return res

@@ -54,7 +54,8 @@ def pose_metrics(lig_traj, prot_traj, center, lig_target, atom14_target, atom14_
     cin = L.PoseMetricsIn(P, Tn, n_lig, n_res, p(lt), p(pt), p(lg), p(tg), p(tm), p(aa), int(pm.shape[0]), p(pm), p(hm),
                           (C.c_float * 3)(*c), float(chi_bound))
     cout = L.PoseMetricsOut(p(out["centroid"]), p(out["sc_rmsd"]), p(out["chi_rate"]), p(out.get("delta_chi")), p(out["lig_rmsd"]))
-    L.check(lib.dbfr_pose_metrics(C.byref(cin), C.byref(cout), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    with torch.cuda.device(dev):
+        L.check(lib.dbfr_pose_metrics(C.byref(cin), C.byref(cout), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return out          # temporaries above are released in stream order by torch's caching allocator (same stream as the launch)
 
 
@@ -187,7 +188,12 @@ def complex_modeling(entries, export_dir=None, calc_metrics=False, lrmsd_naming=
             pd_df[k].extend([v] * n_pose)
         lrmsd = None
         if calc_metrics:
-            perms = _ligand.automorphisms(e.ligand_labels, e.ligand_edge_index)
+            try:
+                perms = _ligand.automorphisms(e.ligand_labels, e.ligand_edge_index)
+            except ValueError as err:       # highly symmetric ligand: like the reference after its matcher timeout
+                import warnings             # (metrics/lrmsd.py:299-309: identity mapping only), not an aborted export
+                warnings.warn(f"{e.name}: {err}; l-rmsd without symmetry correction")
+                perms = None
             m = pose_metrics(e.ligand_traj, e.protein_traj, center, e.ligand_pos, e.atom14_position, e.atom14_mask, e.aatype,
                              perms=perms, heavy_mask=e.heavy_mask)
             last = {k: m[k][:, -1].cpu() for k in ("centroid", "sc_rmsd", "lig_rmsd")}

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdbfr.so")
 
 DBFR_OK = 0
+DBFR_ERR_CAPACITY = -3
 ERRORS = {-1: "DBFR_ERR_ARG", -2: "DBFR_ERR_HIP", -3: "DBFR_ERR_CAPACITY", -4: "DBFR_ERR_SELFTEST",
           -5: "DBFR_ERR_NUMERIC"}
 
@@ -82,6 +83,7 @@ class PdbTopology(C.Structure):
 
 # every symbol include/dbfr.h declares (tests check that the library exports all of them)
 SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
+           "dbfr_sample_range", "dbfr_capacity_report",
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
            "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_reduce_ln",
            "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket"]
@@ -111,6 +113,9 @@ def load():
                                C.POINTER(Limits), vp]
     lib.dbfr_sample.argtypes = [vp, C.POINTER(Batch), C.POINTER(Step), i32, C.POINTER(Noise), vp, vp, vp, vp,
                                 C.c_size_t, C.POINTER(Limits), vp]
+    lib.dbfr_sample_range.argtypes = [vp, C.POINTER(Batch), C.POINTER(Step), i32, i32, C.POINTER(Noise), vp, vp, vp, vp,
+                                      C.c_size_t, C.POINTER(Limits), vp]
+    lib.dbfr_capacity_report.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_int64)]
     lib.dbfr_init_poses.argtypes = [vp, C.POINTER(Batch), C.POINTER(InitTape), vp, vp]
     lib.dbfr_extract_templates.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dbfr_status_sync.argtypes = [vp, vp, C.POINTER(C.c_int64)]

@@ -45,9 +45,10 @@ def extract_templates(aatype, atom14_position):
                default_frame=torch.empty(n, 8, 4, 4, device=dev), rigid_group_positions=torch.empty(n, 14, 3, device=dev),
                torsion_angle=torch.empty(n, 5, device=dev))
     p = lambda x: C.c_void_p(x.data_ptr())
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    L.check(lib.dbfr_extract_templates(n, p(aa), p(pos), p(out["backbone_transl"]), p(out["backbone_rots"]),
-                                       p(out["default_frame"]), p(out["rigid_group_positions"]), p(out["torsion_angle"]), stream))
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(lib.dbfr_extract_templates(n, p(aa), p(pos), p(out["backbone_transl"]), p(out["backbone_rots"]),
+                                           p(out["default_frame"]), p(out["rigid_group_positions"]), p(out["torsion_angle"]), stream))
     return out
 
 
@@ -159,9 +160,10 @@ def select_pocket(atom_pos, atom_mask, ref_pos, cutoff=12.0, max_neighbors=None,
     d2 = torch.empty(n, device=dev)
     out = torch.empty(n, device=dev, dtype=torch.uint8)
     p = lambda x: C.c_void_p(x.data_ptr())
-    L.check(lib.dbfr_select_pocket(int(rp.numel()) - 1, n, p(rp), m, p(pos), p(msk), p(fp), p(ref), float(cutoff),
-                                   0 if max_neighbors is None else int(max_neighbors), p(d2), p(out),
-                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    with torch.cuda.device(dev):
+        L.check(lib.dbfr_select_pocket(int(rp.numel()) - 1, n, p(rp), m, p(pos), p(msk), p(fp), p(ref), float(cutoff),
+                                       0 if max_neighbors is None else int(max_neighbors), p(d2), p(out),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return out.bool(), d2
 
 

@@ -88,49 +88,107 @@ class DiffBindFRHIP(nn.Module):
         recs, steps = self.schedule()
         T = len(recs)
         d = pb.dims
-        ws = model.workspace(pb, dev)
-        a14 = torch.zeros(d["NR"], 14, 3, device=dev)
-        traj_l = torch.empty(T, d["NL"], 3, device=dev) if visualize else None
-        traj_a = torch.empty(T, d["NR"], 14, 3, device=dev) if visualize else None
-        nz = L.Noise(*(C.c_void_p(noise[k].data_ptr()) for k in ("tr", "rot", "tor", "sc")))
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
-        L.check(lib.dbfr_sample(model.handle(), C.byref(pb.c), steps, T, C.byref(nz), ptr(a14), ptr(traj_l), ptr(traj_a),
-                                C.c_void_p(ws.data_ptr()), ws.numel(), C.byref(model.limits), stream))
-        if sync:
-            L.check(lib.dbfr_status_sync(C.c_void_p(ws.data_ptr()), stream, None))
+        with torch.cuda.device(dev):        # everything the library creates (streams, events, weights) follows the current device
+            a14 = torch.zeros(d["NR"], 14, 3, device=dev)
+            traj_l = torch.empty(T, d["NL"], 3, device=dev) if visualize else None
+            traj_a = torch.empty(T, d["NR"], 14, 3, device=dev) if visualize else None
+            nz = L.Noise(*(C.c_void_p(noise[k].data_ptr()) for k in ("tr", "rot", "tor", "sc")))
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+            first = 0
+            while True:
+                ws = model.workspace(pb, dev)
+                L.check(lib.dbfr_sample_range(model.handle(dev), C.byref(pb.c), steps, T, first, C.byref(nz), ptr(a14), ptr(traj_l),
+                                              ptr(traj_a), C.c_void_p(ws.data_ptr()), ws.numel(), C.byref(model.limits), stream))
+                if not sync:
+                    break
+                rc = lib.dbfr_status_sync(C.c_void_p(ws.data_ptr()), stream, None)
+                if rc == L.DBFR_ERR_CAPACITY and model.auto_grow:
+                    # an edge list of step `first` outgrew its budget: the device froze the poses at the beginning of that
+                    # step; re-plan the workspace with the counted sizes and resume there (no step is computed twice)
+                    first = model.grow_limits(pb, ws, stream)
+                    continue
+                L.check(rc)
+                break
         if visualize:
             return traj_l, traj_a
         return pb.lig_pos.unsqueeze(0), a14.unsqueeze(0)
 
+    # ---- random tapes.  One generator stream PER JOB (complex), seeded from (seed, job id): the poses of a job do not
+    # depend on which other jobs share its batch or on which rank runs it, so a sharded run reproduces the 1-GPU run.
+    @staticmethod
+    def job_seed(seed, job_id, chunk=0):
+        x = (int(seed) * 0x9E3779B97F4A7C15 + int(job_id) * 0xBF58476D1CE4E5B9 + int(chunk) * 0x94D049BB133111EB + 1) & (2 ** 64 - 1)
+        x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        x ^= x >> 27; x = (x * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        x ^= x >> 31
+        return x & (2 ** 63 - 1)
+
+    def draw_tapes(self, records, poses, seeds, dev, tr_sigma_max=10.0):
+        """Initialisation tape (``assemble.draw_init_tape`` layout) and SDE noise tape of a complex-major batch, drawn
+        complex by complex on the device from ``torch.Generator(seed_c)``."""
+        from . import assemble
+        recs_, _ = self.schedule()
+        T = len(recs_)
+        reps = [poses] * len(records) if isinstance(poses, int) else list(poses)
+        init = {k: [] for k in ("tor", "rot", "tr", "sc")}
+        z = {k: [] for k in ("tr", "rot", "tor", "sc")}
+        gen = torch.Generator(device=dev)
+        for r, P, s in zip(records, reps, seeds):
+            gen.manual_seed(int(s))
+            t = assemble.draw_init_tape_dims(P, P * r.n_tor, P * r.n_r, dev, tr_sigma_max, gen)
+            for k in init:
+                init[k].append(t[k])
+            z["tr"].append(torch.randn(T, P, 3, device=dev, generator=gen))
+            z["rot"].append(torch.randn(T, P, 3, device=dev, generator=gen))
+            z["tor"].append(torch.randn(T, P * r.n_tor, device=dev, generator=gen))
+            z["sc"].append(torch.randn(T, P * r.n_sc, device=dev, generator=gen))
+        init = {k: torch.cat(v, 0) for k, v in init.items()}
+        z = {k: torch.cat(v, 1) for k, v in z.items()}
+        for k in ("tor", "sc"):
+            if z[k].shape[1] == 0:
+                z[k] = torch.zeros(T, 1, device=dev)
+        if init["tor"].numel() == 0:
+            init["tor"] = torch.zeros(1, device=dev)
+        for s_, r_ in enumerate(recs_):
+            if r_.noise_free:
+                for v in z.values():
+                    v[s_].zero_()
+        return init, {k: v.contiguous() for k, v in z.items()}
+
     @torch.no_grad()
     def sample_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0,
-                         keep_on_device=False):
+                         keep_on_device=False, job_ids=None, seeds=None):
         """Records in, poses out: the reference's `_prepare_test_sample` x num_poses + collate + `sample`
         (inference_dataset.py:578-612, struct_init.py, scFlex.py:124-250) with everything per-pose on the device.
         ``records``: list of ``assemble.ComplexRecord`` (or reference-format per-complex dicts); ``poses``: int or
-        per-complex list.  Both random tapes (initialisation, SDE noise) come from one torch device generator.
+        per-complex list.  Both random tapes (initialisation, SDE noise) come from per-complex device generators seeded
+        from (``seed``, ``job_ids[c]``) (or given outright as ``seeds``); ``seed=None`` takes a fresh seed from torch's global generator (the reference
+        draws from the global RNG), so two unseeded calls give different poses.
         Returns list[G] of (lig [T,N_l,3], atom14 [T,N_r,14,3]) CPU tensors, complex-major; ``keep_on_device`` leaves them
         in HBM (for ``export.pose_metrics``, which consumes them there)."""
+        pb, lig, a14 = self.run_complexes(records, poses, device, seed, visualize, tr_sigma_max, job_ids, seeds)
+        return self._split(pb, lig, a14) if keep_on_device else self._split(pb, lig.cpu(), a14.cpu())
+
+    @torch.no_grad()
+    def run_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0, job_ids=None,
+                      seeds=None):
+        """``sample_complexes`` without the per-graph split: (packed batch, lig [T,NL,3], atom14 [T,NR,14,3]) on the device;
+        graphs are complex-major, so the poses of complex c are rows ``pb.lig_ptr_host[g0] .. [g0 + poses_c]``."""
         from . import assemble
         dev = torch.device(device)
         recs = [r if isinstance(r, assemble.ComplexRecord) else assemble.ComplexRecord(r) for r in records]
-        pb = assemble.assemble(recs, poses, dev)
-        gen = torch.Generator(device=dev)
-        if seed is not None:
-            gen.manual_seed(int(seed))
-        assemble.init_poses(self.diffusion_model, pb, assemble.draw_init_tape(pb, tr_sigma_max, gen))
-        steps, _ = self.schedule()
-        T, d = len(steps), pb.dims
-        z = {"tr": torch.randn(T, pb.G, 3, device=dev, generator=gen), "rot": torch.randn(T, pb.G, 3, device=dev, generator=gen),
-             "tor": torch.randn(T, max(d["NTOR"], 1), device=dev, generator=gen),
-             "sc": torch.randn(T, max(d["NSC"], 1), device=dev, generator=gen)}
-        for s, r in enumerate(steps):
-            if r.noise_free:
-                for v in z.values():
-                    v[s].zero_()
-        lig, a14 = self.sample_packed(pb, z, visualize=visualize)
-        return self._split(pb, lig, a14) if keep_on_device else self._split(pb, lig.cpu(), a14.cpu())
+        if seeds is None:
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            job_ids = list(range(len(recs))) if job_ids is None else list(job_ids)
+            seeds = [self.job_seed(seed, j) for j in job_ids]
+        with torch.cuda.device(dev):
+            pb = assemble.assemble(recs, poses, dev)
+            init, z = self.draw_tapes(recs, poses, seeds, dev, tr_sigma_max)
+            assemble.init_poses(self.diffusion_model, pb, init)
+            lig, a14 = self.sample_packed(pb, z, visualize=visualize)
+        return pb, lig, a14
 
     def _split(self, pb, lig, a14):
         lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()

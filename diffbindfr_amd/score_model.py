@@ -2,8 +2,11 @@
 
 Level-1 boundary of SURVEY.md section 8(b): same constructor (``cfg`` = the ConfigDict of
 DiffBindFR/configs/diffbindfr_ts.py:107-142), same ``forward(data) -> (tr, rot, tor,
-sc_tor)``, same ``state_dict`` keys as druglib/models/Docking/interaction/tpscore.py:202-573
-(so ``load_checkpoint(strict=True)`` of DiffBindFR/common/engines.py:137-165 works), but
+sc_tor)``, same ``state_dict`` keys as druglib/models/Docking/interaction/tpscore.py:202-573, and
+``tp`` / ``final_tp_tor`` children that absorb the e3nn buffers of a real checkpoint, so
+the reference's own loader (druglib/core/runner/checkpoint.py:32-100: a recursive
+``_load_from_state_dict`` walk, ``strict=True`` from DiffBindFR/app/predict.py:118-125)
+accepts it -- pinned by tests/test_host.py::test_reference_loader_fixture; but
 the arithmetic runs in libdbfr.so (hand-written HIP for gfx950) through the C ABI of
 include/dbfr.h.  There is no CPU path: without the library / a GPU it raises.
 """
@@ -50,9 +53,25 @@ class _LayerNormParams(nn.Module):
         self.affine_bias = nn.Parameter(torch.zeros(n0e))
 
 
+class _KeySink(nn.Module):
+    """Stands where the reference holds an e3nn module (``TensorProductConvLayer.tp`` tpscore.py:163,
+    ``final_tp_tor`` :373).  With ``shared_weights=False`` those own no parameters, only buffers whose names depend
+    on the e3nn build (``weight`` (empty), ``output_mask``, Wigner-3j constants of the generated code).  The
+    reference's loader walks ``_load_from_state_dict`` module by module: this child takes every key under its
+    prefix so that ``strict=True`` passes, and remembers them (``absorbed``)."""
+
+    def __init__(self):
+        super().__init__()
+        self.absorbed = []
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        self.absorbed = [k for k in state_dict if k.startswith(prefix)]
+
+
 class _Conv(nn.Module):
     def __init__(self, nef, W, out_blocks):
         super().__init__()
+        self.tp = _KeySink()
         self.fc = _SimpleLinear(nef, W, nef)
         self.batch_norm = _LayerNormParams(out_blocks)
 
@@ -131,6 +150,7 @@ class TensorProductModelHIP(nn.Module):
         self.final_conv = _Conv(2 * ns, wn[4], [(2, 1, -1), (2, 1, 1)])
         self.tr_final_layer = _SimpleLinear(1 + se, 1, ns)
         self.rot_final_layer = _SimpleLinear(1 + se, 1, ns)
+        self.final_tp_tor = _KeySink()
         self.tor_edge_embedding = _SimpleLinear(de, ns)
         self.tor_bond_conv = _Conv(3 * ns, wn[5], [(ns, 0, -1), (ns, 0, 1)])
         self.tor_final_layer = _SimpleLinear(2 * ns, 1, ns, bias=False, act="tanh")
@@ -138,31 +158,37 @@ class TensorProductModelHIP(nn.Module):
             self.sc_edge_embedding = _SimpleLinear(de, ns)
             self.sc_tor_bond_conv = _Conv(3 * ns, wn[5], [(ns, 0, -1), (ns, 0, 1)])
             self.sc_tor_final_layer = _SimpleLinear(2 * ns, 1, ns, bias=False, act="tanh")
-        self._handle = None
-        self._ws = None
+        self._handles = {}      # device index -> (fingerprint of the parameters, dbfr_model*)
+        self._ws = {}           # device index -> uint8 workspace tensor
         self.limits = L.Limits(24, 64)
-        self.ignored_keys = []
+        self.auto_grow = True   # on DBFR_ERR_CAPACITY: raise the limits to what the device counted and resume
+        self.regrown = 0        # how often that happened (tests / diagnostics)
 
-    # ---- checkpoint compatibility: e3nn modules contribute buffers whose names are unknown offline
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        mine = set(self.state_dict().keys())
-        kept = {}
-        self.ignored_keys = []
-        for k, v in state_dict.items():
-            if k in mine:
-                kept[k] = v
-            elif ".tp." in k or k.startswith("final_tp_tor.") or ".final_tp_tor." in k:
-                self.ignored_keys.append(k)     # e3nn buffers: no parameters live there (shared_weights=False)
-            else:
-                kept[k] = v                     # genuinely unexpected -> let torch complain if strict
-        out = super().load_state_dict(kept, strict=strict, **kw)
-        self.release()
-        return out
+    def grow_limits(self, pb, ws, stream):
+        """After DBFR_ERR_CAPACITY: read what the step needed (``dbfr_capacity_report``), raise ``self.limits`` with 25 %
+        head-room (they stay raised for later batches).  Returns the first step that has to be re-run."""
+        lib = L.load()
+        first, need = C.c_int32(), (C.c_int64 * 8)()
+        L.check(lib.dbfr_capacity_report(C.c_void_p(ws.data_ptr()), stream, C.byref(first), need))
+        d = pb.dims
+        aa = -(-int(need[1] * 1.25) // max(d["NA"], 1)) + 1
+        cross = -(-int(max(need[2], need[6]) * 1.25) // max(d["NL"], 1)) - 2 * d["max_nr"] + 1
+        new = L.Limits(max(self.limits.aa_avg_neighbors, aa), max(self.limits.cross_avg_neighbors, cross))
+        if (new.aa_avg_neighbors, new.cross_avg_neighbors) == (self.limits.aa_avg_neighbors, self.limits.cross_avg_neighbors):
+            raise L.DbfrError(f"DBFR_ERR_CAPACITY with nothing to grow (needed {list(need)})")
+        self.limits = new
+        self.regrown += 1
+        return max(int(first.value), 0)
+
+    @property
+    def ignored_keys(self):
+        """Checkpoint keys the e3nn stand-ins took during the last load."""
+        return [k for m in self.modules() if isinstance(m, _KeySink) for k in m.absorbed]
 
     def release(self):
-        if self._handle is not None:
-            L.load().dbfr_model_destroy(self._handle)
-            self._handle = None
+        for _, h in self._handles.values():
+            L.load().dbfr_model_destroy(h)
+        self._handles = {}
 
     def __del__(self):
         try:
@@ -170,28 +196,51 @@ class TensorProductModelHIP(nn.Module):
         except Exception:
             pass
 
-    def handle(self):
-        """Pack the current parameters into the device-resident model (once)."""
-        if self._handle is None:
-            lib = L.load()
-            sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
-            arr = (L.Tensor * len(sd))()
-            for i, (k, v) in enumerate(sd.items()):
-                arr[i].name = k.encode()
-                arr[i].data = C.c_void_p(v.data_ptr())
-                arr[i].numel = v.numel()
-            h = C.c_void_p()
+    def _fingerprint(self):
+        # whatever route new weights take (load_state_dict, the reference's per-module loader, .to(), in-place
+        # edits), either the storage or the version counter of a tensor changes
+        return tuple((v.data_ptr(), v._version) for v in self.state_dict(keep_vars=True).values())
+
+    def handle(self, device=None):
+        """The device-resident packed model of the CURRENT parameters on ``device`` (default: the current HIP device).
+        Re-packed when a parameter changed since the last call; one handle per device."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        fp = self._fingerprint()
+        cur = self._handles.get(idx)
+        if cur is not None and cur[0] == fp:
+            return cur[1]
+        lib = L.load()
+        if cur is not None:
+            lib.dbfr_model_destroy(cur[1])
+            del self._handles[idx]
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+        arr = (L.Tensor * len(sd))()
+        for i, (k, v) in enumerate(sd.items()):
+            arr[i].name = k.encode()
+            arr[i].data = C.c_void_p(v.data_ptr())
+            arr[i].numel = v.numel()
+        h = C.c_void_p()
+        with torch.cuda.device(idx):            # the library allocates on the current device
             L.check(lib.dbfr_model_create(C.byref(self.mcfg), arr, len(sd), C.byref(h)))
-            self._handle = h
-        return self._handle
+        self._handles[idx] = (fp, h)
+        return h
 
     def workspace(self, batch, device):
         lib = L.load()
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
         nbytes = C.c_size_t()
-        L.check(lib.dbfr_workspace_bytes(self.handle(), C.byref(batch.c), C.byref(self.limits), C.byref(nbytes)))
-        if self._ws is None or self._ws.numel() < nbytes.value or self._ws.device != torch.device(device):
-            self._ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
-        return self._ws
+        L.check(lib.dbfr_workspace_bytes(self.handle(dev), C.byref(batch.c), C.byref(self.limits), C.byref(nbytes)))
+        ws = self._ws.get(idx)
+        if ws is None or ws.numel() < nbytes.value:
+            ws = self._ws[idx] = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        return ws
+
+    def workspace_of(self, device):
+        """The workspace last used on ``device`` (for ``dbfr_status_sync`` / edge counters)."""
+        dev = torch.device(device)
+        return self._ws[dev.index if dev.index is not None else torch.cuda.current_device()]
 
     @staticmethod
     def _device_of(data):
@@ -213,14 +262,22 @@ class TensorProductModelHIP(nn.Module):
         G = pb.G
         out = dict(tr=torch.empty(G, 3, device=dev), rot=torch.empty(G, 3, device=dev),
                    tor=torch.empty(max(pb.dims["NTOR"], 1), device=dev), sc=torch.empty(max(pb.dims["NSC"], 1), device=dev))
-        ws = self.workspace(pb, dev)
         cond = L.Cond(*(C.c_void_p(x.data_ptr()) for x in (t, tr_sigma, rot_score_norm, tor_n2, sc_n2)))
         sc = L.Scores(*(C.c_void_p(out[k].data_ptr()) for k in ("tr", "rot", "tor", "sc")))
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        L.check(lib.dbfr_score(self.handle(), C.byref(pb.c), C.byref(cond), C.byref(sc), C.c_void_p(ws.data_ptr()),
-                               ws.numel(), C.byref(self.limits), stream))
-        if sync:
-            L.check(lib.dbfr_status_sync(C.c_void_p(ws.data_ptr()), stream, None))
+        with torch.cuda.device(dev):            # streams, events and allocations of the library follow the current device
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            while True:
+                ws = self.workspace(pb, dev)
+                L.check(lib.dbfr_score(self.handle(dev), C.byref(pb.c), C.byref(cond), C.byref(sc), C.c_void_p(ws.data_ptr()),
+                                       ws.numel(), C.byref(self.limits), stream))
+                if not sync:
+                    break
+                rc = lib.dbfr_status_sync(C.c_void_p(ws.data_ptr()), stream, None)
+                if rc == L.DBFR_ERR_CAPACITY and self.auto_grow:
+                    self.grow_limits(pb, ws, stream)      # the edge budgets were too small: re-plan with the counted sizes
+                    continue
+                L.check(rc)
+                break
         return out["tr"], out["rot"], out["tor"][:pb.dims["NTOR"]], out["sc"][:pb.dims["NSC"]]
 
     def forward(self, data):

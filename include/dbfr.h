@@ -180,6 +180,20 @@ int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int3
                 const dbfr_noise* noise, float* atom14_out, float* traj_lig, float* traj_atom14,
                 void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream);
 
+/* The same, steps [step_begin, n_steps) only: `steps`, `noise` and the trajectory buffers are indexed by the absolute
+ * step.  Used to RESUME after DBFR_ERR_CAPACITY: once an edge list of step s does not fit, that set is left empty,
+ * the pose updates of step s and of every later step are skipped (the state stays as it was at the beginning of step
+ * s) and the device remembers s and the edge counts it needed.  The caller reads them with dbfr_capacity_report,
+ * raises dbfr_limits, sizes a new workspace and calls dbfr_sample_range(step_begin = s).                           */
+int dbfr_sample_range(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps, int32_t step_begin,
+                      const dbfr_noise* noise, float* atom14_out, float* traj_lig, float* traj_atom14,
+                      void* workspace, size_t workspace_bytes, const dbfr_limits* lim, void* hip_stream);
+
+/* After dbfr_status_sync returned DBFR_ERR_CAPACITY: the first step whose edge lists overflowed (-1: none) and the
+ * largest edge count each set needed so far, [8] int64 in dbfr_status_sync's counter order
+ * {lig, atom, cross lig<-atom, 0, tor, sc_tor, cross atom<-lig, 0}.  Synchronises the stream.                      */
+int dbfr_capacity_report(void* workspace, void* hip_stream, int32_t* first_failed_step, int64_t* needed_edges);
+
 /* ---- pose initialisation, on the device.
  * Replaces the per-pose real-time transforms LigInit + SCProtInit +
  * Atom14ToAllAtomsRepr (druglib/datasets/Docking/struct_init.py:16-53,114-138;
@@ -319,6 +333,8 @@ int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* 
  * the launch stream when profiling is enabled.  conv_flops = algorithmic FLOP
  * (2K(K+W) per edge); ref_form_bytes = HBM bytes the reference's two-kernel form
  * of the same launches would move (4(W+D_in+9)+16 per edge).        */
+/* on = 1: events + counters, the independent convs of a layer serialised on the caller's stream so that each is timed
+ * alone; on = 2: counters only (launch pattern as in production); 0: off.                                        */
 int dbfr_profile_enable(dbfr_model* m, int32_t on);
 int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops,
                       double* ref_form_bytes, int32_t reset);

@@ -163,14 +163,47 @@ def test_capacity_overflow_is_reported(setup, dev):
     sc = osched.step_scalars(osched.default_sample_cfg(), 0)
     dd = namespace_to(osampler.set_time(copy.deepcopy(d), sc, d.num_graphs), dev)
     old = model.limits
+    ref = [x.clone() for x in model(dd)]
     model.limits = L.Limits(1, 1)
-    model._ws = None
+    model._ws = {}
+    model.auto_grow = False
     try:
         with pytest.raises(L.DbfrError, match="CAPACITY"):
             model(dd)
     finally:
+        model.auto_grow = True
+    # with auto_grow (the default) the budgets are raised to what the device counted and the call is repeated
+    try:
+        n0 = model.regrown
+        out = model(dd)
+        assert model.regrown > n0 and model.limits.aa_avg_neighbors > 1 and model.limits.cross_avg_neighbors >= 1
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    finally:
         model.limits = old
-        model._ws = None
+        model._ws = {}
+
+
+def test_sampler_resumes_after_capacity_overflow(setup, dev):
+    """Budgets far too small for the golden batch: the sampler must grow them step by step (the device freezes the
+    poses at the step that overflowed and the host resumes there) and still reproduce the reference's trajectory."""
+    mcfg, params, model = setup
+    d, z = load_golden_batch()
+    samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
+    pb = PackedBatch(namespace_to(d, dev), dev)
+    noise = {k: torch.from_numpy(z[f"noise_{k}"]).to(dev).contiguous() for k in ("tr", "rot", "tor", "sc")}
+    old = model.limits
+    model.limits = L.Limits(2, 1)
+    model._ws = {}
+    try:
+        n0 = model.regrown
+        lig, a14 = samp.sample_packed(pb, noise, visualize=True)
+        assert model.regrown > n0
+        assert (lig.cpu() - torch.from_numpy(z["traj_lig"])).norm(dim=-1).max() < POSE_ATOL
+        assert (a14.cpu() - torch.from_numpy(z["traj_atom14"])).norm(dim=-1).max() < POSE_ATOL
+    finally:
+        model.limits = old
+        model._ws = {}
 
 
 # ---- size-independent properties at the BASELINE.json shapes (the oracle would take minutes there)
@@ -221,7 +254,7 @@ def test_graph_permutation_invariance(setup, dev):
                                             (-1, 0, "final_conv"), (-2, 0, "tor_bond_conv"), (-3, 0, "sc_tor_bond_conv")])
 def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name):
     mcfg, p, model = setup
-    lib, h = L.load(), model.handle()
+    lib, h = L.load(), model.handle(dev)
     g = torch.Generator().manual_seed(5 + abs(layer))
     i, shirr, o, nef = sm.conv_specs(mcfg)[name]
     Din, Dout = o3.Irreps(i).dim, o3.Irreps(o).dim
@@ -304,12 +337,12 @@ def test_model_create_reports_missing_and_misshaped_tensors(dev):
     del bad["atom_conv_layers.3.fc.lin.3.bias"]
     with mock.patch.object(type(model), "state_dict", lambda self, *a, **k: bad):
         with pytest.raises(L.DbfrError, match="atom_conv_layers.3.fc.lin.3.bias"):
-            model.handle()
+            model.handle(dev)
     bad2 = dict(sd)
     bad2["tr_final_layer.lin.0.weight"] = torch.zeros(5, 5)
     with mock.patch.object(type(model), "state_dict", lambda self, *a, **k: bad2):
         with pytest.raises(L.DbfrError, match="tr_final_layer.lin.0.weight"):
-            model.handle()
+            model.handle(dev)
 
 
 def test_pocket_without_side_chain_torsions(setup, dev):
@@ -384,4 +417,15 @@ def test_random_ragged_batches_vs_oracle(setup, dev, case):
             lg["rot_node_mask"] = lg["rot_node_mask"][:0]
         items.append((pk, lg) + synthetic.init_pose(rng, pk, lg, tr_sigma=float(rng.choice([0.5, 3.0, 10.0]))))
     errs = _oracle_vs_hip_scores(setup, dev, synthetic.collate(items), step=int(rng.integers(0, 20)))
+    assert max(errs) < SCORE_RTOL, errs
+
+
+def test_pocket_larger_than_the_old_2048_atom_limit(setup, dev):
+    """A 2 500-atom pocket (`-dr`-style large region; the edge builder stages a graph's coordinates in dynamic LDS
+    sized by the batch's largest graph, up to 8192 atoms): scores equal the oracle's."""
+    rng = np.random.default_rng(23)
+    pk, lg = synthetic.make_pocket(rng, 2500), synthetic.make_ligand(rng, 14)
+    d = synthetic.collate([(pk, lg) + synthetic.init_pose(rng, pk, lg, tr_sigma=2.0)])
+    assert int(d.rec_atm_pos.shape[0]) > 2048
+    errs = _oracle_vs_hip_scores(setup, dev, d)
     assert max(errs) < SCORE_RTOL, errs

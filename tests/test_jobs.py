@@ -1,0 +1,256 @@
+"""The sharded job driver: job list -> LPT shards -> per-rank batches -> one gather, results in job
+order; BASELINE configs 3 (forward screen: one receptor shared by every job) and 4 (target fishing: one ligand shared).
+
+CPU part: batch planning, sharding, the shared-half assembly, and the whole driver over gloo with world_size 2 on a
+stand-in sampler (host logic + gather only).  GPU part (-m gpu): HIP vs the CPU oracle on small cfg 3 / cfg 4 job lists
+(scores and 20-step poses from the same initial poses and noise), and a 2-rank run on one GPU (gloo-staged gather) that
+must reproduce the 1-rank result bit for bit in job order."""
+import copy
+import os
+import socket
+import subprocess
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from diffbindfr_amd import assemble, dist as ddist, synthetic
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def make_jobs(cfg_id, n_jobs, n_atoms, n_lig, seed=0):
+    """Raw records + ComplexRecords of a small job list of the named BASELINE config: cfg 3 shares the PocketRecord,
+    cfg 4 the LigandRecord, anything else shares nothing."""
+    shared = synthetic.CONFIGS[cfg_id].get("shared")
+    srng = np.random.default_rng(1000 * cfg_id + seed)
+    sp = synthetic.make_pocket(srng, n_atoms) if shared == "receptor" else None
+    sl = synthetic.make_ligand(srng, n_lig) if shared == "ligand" else None
+    raw, halves = [], []
+    for j in range(n_jobs):
+        rng = np.random.default_rng([cfg_id, seed, j])
+        pk = sp or synthetic.make_pocket(rng, int(round(n_atoms * rng.uniform(0.8, 1.2))))
+        lg = sl or synthetic.make_ligand(rng, max(4, int(round(n_lig * rng.uniform(0.7, 1.3)))))
+        raw.append(synthetic.make_record(pk, lg, np.random.default_rng([7, cfg_id, seed, 0 if shared else j])))
+    pocket0 = assemble.PocketRecord(raw[0]) if shared == "receptor" else None
+    lig0 = assemble.LigandRecord(raw[0]) if shared == "ligand" else None
+    if shared == "receptor":          # one psi/chi record of the receptor for all jobs
+        for r in raw[1:]:
+            for k in ("torsion_angle",):
+                r[k] = raw[0][k]
+    jobs = [assemble.ComplexRecord(r, lig=lig0, pocket=pocket0) for r in raw]
+    return raw, jobs
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_plan_batches_keeps_jobs_whole_and_balanced():
+    b = ddist.plan_batches([(j, 40) for j in range(17)], 640)
+    assert [sum(u[2] for u in x) for x in b] == [360, 320]
+    assert sorted(u[0] for x in b for u in x) == list(range(17))
+    b = ddist.plan_batches([(3, 1500), (5, 3)], 640)                 # an oversized job is cut at multiples of the batch size
+    assert [u for x in b for u in x] == [(3, 0, 640), (3, 640, 640), (3, 1280, 220), (5, 0, 3)]
+    assert all(sum(u[2] for u in x) <= 640 for x in b)
+    assert ddist.plan_batches([], 640) == []
+
+
+def test_shared_halves_are_assembled_once_and_equal_the_unshared_batch():
+    for cfg in (3, 4):
+        raw, jobs = make_jobs(cfg, 3, 60, 10)
+        pb = assemble.assemble(jobs, [2, 1, 3], "cpu")
+        ref = assemble.assemble([assemble.ComplexRecord(copy.deepcopy(r)) for r in raw], [2, 1, 3], "cpu")
+        assert pb.dims == ref.dims
+        for k in pb.t:
+            assert torch.equal(pb.t[k], ref.t[k]), (cfg, k)
+        shared = jobs[0].pocket if cfg == 3 else jobs[0].lig
+        assert all((j.pocket if cfg == 3 else j.lig) is shared for j in jobs)
+        assert len(shared._dev) == 1                                      # one cached upload per device
+
+
+def test_shard_jobs_by_cost():
+    raw, jobs = make_jobs(2, 7, 60, 10)
+    shards, reps = ddist.shard_jobs(jobs, [4, 4, 8, 2, 4, 4, 6], 2)
+    assert sorted(shards[0] + shards[1]) == list(range(7))
+    load = [sum(jobs[j].cost * reps[j] for j in s) for s in shards]
+    assert abs(load[0] - load[1]) <= max(j.cost * r for j, r in zip(jobs, reps))
+    assert jobs[0].cost == ddist.complex_cost(jobs[0].n_a, jobs[0].n_l, jobs[0].n_cab)
+
+
+class _StandInSampler:
+    """Host-side stand-in with the driver-facing interface of DiffBindFRHIP (run_complexes, job_seed): poses are a
+    deterministic function of the job's seed, so the gathered result can be checked without a GPU."""
+    from diffbindfr_amd.sampler import DiffBindFRHIP as _D
+    job_seed = staticmethod(_D.job_seed)
+
+    def run_complexes(self, records, poses, device, tr_sigma_max, seeds):
+        lig, a14, lp, rp = [], [], [0], [0]
+        for r, n, s in zip(records, poses, seeds):
+            g = torch.Generator().manual_seed(s)
+            lig.append(torch.randn(n * r.n_l, 3, generator=g))
+            a14.append(torch.randn(n * r.n_r, 14, 3, generator=g))
+            for _ in range(n):
+                lp.append(lp[-1] + r.n_l)
+                rp.append(rp[-1] + r.n_r)
+        pb = SimpleNamespace(lig_ptr_host=torch.tensor(lp), res_ptr_host=torch.tensor(rp))
+        return pb, torch.cat(lig)[None], torch.cat(a14)[None]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddist.init(backend="gloo")
+    raw, jobs = make_jobs(3, 5, 60, 10)
+    res = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 4, 1, 2], seed=11, device="cpu", batch_poses=4)
+    q.put((rank, [(l.numpy(), a.numpy()) for l, a in res]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_sharded_over_gloo_world2_equals_one_rank():
+    import torch.multiprocessing as mp
+    raw, jobs = make_jobs(3, 5, 60, 10)
+    one = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 4, 1, 2], seed=11, device="cpu", batch_poses=4)
+    assert [tuple(l.shape) for l, _ in one] == [(p, j.n_l, 3) for p, j in zip([3, 2, 4, 1, 2], jobs)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=180) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, res in got:                      # every rank holds every job's poses, in job order, bit for bit
+        for (l, a), (l1, a1) in zip(res, one):
+            assert np.array_equal(l, l1.numpy()) and np.array_equal(a, a1.numpy())
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _hip(dev):
+    import diffbindfr_amd as dba
+    from oracle import score_model as sm
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=1)
+    model = dba.TensorProductModelHIP({}).to(dev)
+    model.load_state_dict(params, strict=True)
+    return mcfg, params, model, dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
+
+
+def _shared_config_vs_oracle(cfg_id):
+    from oracle import sampler as osampler, schedule as osched, score_model as sm
+    from tests.helpers import oracle_batch_from_packed, rel_err
+    dev = torch.device("cuda:0")
+    mcfg, params, model, samp = _hip(dev)
+    raw, jobs = make_jobs(cfg_id, 3, 70, 12, seed=2)
+    poses = [2, 1, 2]
+    pb = assemble.assemble(jobs, poses, dev)
+    init, z = samp.draw_tapes(jobs, poses, [samp.job_seed(5, j) for j in range(3)], dev, tr_sigma_max=3.0)
+    assemble.init_poses(model, pb, init)
+    torch.cuda.synchronize()
+    d = oracle_batch_from_packed(raw, poses, pb)
+    G = d.num_graphs
+    # one score evaluation on the initial poses
+    sc = osched.step_scalars(osched.default_sample_cfg(), 4)
+    dd = osampler.set_time(copy.deepcopy(d), sc, G)
+    ref = sm.forward(params, mcfg, copy.deepcopy(dd))
+    scn, scm = dd.sc_tor_score_norm2, dd.sc_torsion_edge_mask.bool()
+    out = model.score_packed(pb, dd.t, dd.tr_sigma, dd.rot_score_norm, dd.tor_score_norm2, scn[scm])
+    for nm, a, b in zip(("tr", "rot", "tor", "sc_tor"), out, ref):
+        assert rel_err(a, b) < 1e-4, (cfg_id, nm, rel_err(a, b))
+    # the whole 20-step trajectory from the same poses and noise
+    noise = SimpleNamespace(tr=z["tr"].cpu(), rot=z["rot"].cpu(), tor=z["tor"].cpu()[:, :int(d.tor_edge_mask.sum())],
+                            sc=z["sc"].cpu()[:, :int(d.sc_torsion_edge_mask.sum())])
+    T = synthetic.residue_tables()
+    lig_ref, a14_ref = osampler.sample(params, mcfg, osched.default_sample_cfg(), copy.deepcopy(d), noise,
+                                       torch.from_numpy(T["atom14_to_group"]).long())
+    lig, a14 = samp.sample_packed(pb, z)
+    assert (lig[0].cpu() - lig_ref[0]).norm(dim=-1).max() < 1e-3
+    assert (a14[0].cpu() - a14_ref[0]).norm(dim=-1).max() < 1e-3
+    # and through the job driver: same seeds => the same poses, in job order
+    res = ddist.run_sharded(samp, jobs, poses, seed=5, device=dev, tr_sigma_max=3.0)
+    lp = pb.lig_ptr_host.tolist()
+    g = 0
+    for j, p in enumerate(poses):
+        assert torch.equal(res[j][0].reshape(-1, 3), lig[0, lp[g]:lp[g + p]]), j
+        g += p
+
+
+@pytest.mark.gpu
+def test_cfg3_shared_receptor_vs_oracle():
+    _shared_config_vs_oracle(3)
+
+
+@pytest.mark.gpu
+def test_cfg4_shared_ligand_vs_oracle():
+    _shared_config_vs_oracle(4)
+
+
+@pytest.mark.gpu
+def test_unseeded_calls_differ_and_seeded_calls_repeat():
+    dev = torch.device("cuda:0")
+    _, _, _, samp = _hip(dev)
+    _, jobs = make_jobs(2, 2, 50, 8)
+    a = samp.sample_complexes(jobs, 2, device=dev)
+    b = samp.sample_complexes(jobs, 2, device=dev)
+    assert not torch.equal(a[0][0], b[0][0])
+    c = samp.sample_complexes(jobs, 2, device=dev, seed=9)
+    e = samp.sample_complexes(jobs, 2, device=dev, seed=9)
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(c, e))
+    # a job's poses do not depend on its batch mates
+    f = samp.sample_complexes(jobs[1:], 2, device=dev, seed=9, job_ids=[1])
+    assert torch.equal(f[0][0], c[2][0]) and torch.equal(f[1][1], c[3][1])
+
+
+_RANK_SCRIPT = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from diffbindfr_amd import dist as ddist
+from tests.test_jobs import make_jobs, _hip
+rank, world, local = ddist.init()
+dev = torch.device("cuda:0")
+_, _, _, samp = _hip(dev)
+raw, jobs = make_jobs(int(sys.argv[3]), 6, 70, 12, seed=4)
+res = ddist.run_sharded(samp, jobs, [3, 2, 4, 1, 2, 3], seed=21, device=dev, batch_poses=6)
+np.savez(sys.argv[2] + f".rank{rank}.npz", **{f"lig{j}": l.cpu().numpy() for j, (l, a) in enumerate(res)},
+         **{f"a14_{j}": a.cpu().numpy() for j, (l, a) in enumerate(res)})
+ddist.barrier()
+if world > 1:
+    import torch.distributed as dist
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_id", [3, 4])
+def test_two_ranks_on_one_gpu_reproduce_one_rank_bit_for_bit(tmp_path, cfg_id):
+    """torchrun-style spawn of 2 ranks sharing cuda:0 (records staged through the host for the gloo gather): every
+    rank's gathered result must equal the 1-rank result, bitwise and in job order."""
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out1 = str(tmp_path / "one")
+    subprocess.run([sys.executable, str(script), ROOT, out1, str(cfg_id)], check=True, timeout=900,
+                   env=dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    out2 = str(tmp_path / "two")
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, out2, str(cfg_id)],
+                              env=dict(base, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_PORT=port,
+                                       DBFR_DIST_BACKEND="gloo")) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    one = np.load(out1 + ".rank0.npz")
+    for r in range(2):
+        two = np.load(out2 + f".rank{r}.npz")
+        assert sorted(two.files) == sorted(one.files)
+        for k in one.files:
+            assert np.array_equal(one[k], two[k]), (r, k)

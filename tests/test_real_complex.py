@@ -131,5 +131,5 @@ def test_gpu_real_complex_scores_match_oracle():
         assert rel_err(a, b) < 1e-4, (nm, rel_err(a, b))
     counters = (C.c_int64 * 8)()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    L.check(L.load().dbfr_status_sync(C.c_void_p(model._ws.data_ptr()), stream, counters))
+    L.check(L.load().dbfr_status_sync(C.c_void_p(model.workspace_of(dev).data_ptr()), stream, counters))
     assert counters[1] == 9002 and counters[0] == 458 + 80          # pocket edges; ligand radius + bond edges
