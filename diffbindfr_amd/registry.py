@@ -1,6 +1,6 @@
 """mmcv-style registries: the reference's operator/plugin boundary for this path.
 
-Mirrors druglib/utils/registry.py:60-358 (``Registry.register_module(name=, force=)``,
+Mirrors druglib/utils/registry.py:60-358 (``Registry.register_module(name=, overwrite=, module=)``,
 ``Registry.build(cfg, default_args=)`` popping ``type``) and the registry objects of
 druglib/models/builder.py:7-17.  When ``druglib`` itself is importable the classes of
 this package are ALSO registered into the reference's own ``INTERACTION`` /
@@ -33,20 +33,23 @@ class Registry:
     def get(self, key):
         return self._module_dict.get(key)
 
-    def _register(self, cls, name=None, force=False):
+    def _register(self, cls, name=None, overwrite=False):
         names = [name or cls.__name__] if not isinstance(name, (list, tuple)) else list(name)
         for n in names:
-            if not force and n in self._module_dict:
-                raise KeyError(f"{n} is already registered in {self._name}")
+            if not overwrite and n in self._module_dict:
+                raise KeyError(f"{n} is already registered, in {self._name}")
             self._module_dict[n] = cls
 
-    def register_module(self, name=None, force=False, module=None):
+    def register_module(self, name=None, overwrite=False, module=None):
+        """registry.py:285-340: decorator or ``register_module(module=cls)``; ``overwrite`` replaces an existing entry."""
+        if not isinstance(overwrite, bool):
+            raise KeyError(f'"overwrite" must be a boolean, but got a type "{type(overwrite)}"')
         if module is not None:
-            self._register(module, name, force)
+            self._register(module, name, overwrite)
             return module
 
         def deco(cls):
-            self._register(cls, name, force)
+            self._register(cls, name, overwrite)
             return cls
         return deco
 
@@ -81,8 +84,6 @@ def register_into_druglib():
         return False
     for reg, ref in ((INTERACTION, REF_I), (MLDOCK_BUILDER, REF_M)):
         for n, cls in reg.module_dict.items():
-            try:
-                ref.register_module(name=n, module=cls)
-            except Exception:
-                pass
+            if ref.get(n) is not cls:
+                ref.register_module(name=n, overwrite=ref.get(n) is not None, module=cls)
     return True

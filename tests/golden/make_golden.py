@@ -747,6 +747,129 @@ def golden_pocket_select():
     np.savez_compressed(os.path.join(HERE, "pocket_select.npz"), **out)
 
 
+
+# --------------------------------------------------------------------------- boundary: the reference's REAL registry + checkpoint loader
+def _ref_function_source(path, start_marker, stop_marker):
+    """Source text of one top-level function of a reference file, read at run time (never stored)."""
+    src = open(path).read()
+    a = src.index(start_marker)
+    return src[a: src.index(stop_marker, a)]
+
+
+def golden_boundary():
+    """DiffBindFRHIP / TensorProductModelHIP registered into the reference's OWN registries
+    (druglib/utils/registry.py, druglib/models/builder.py), built by its `build_task_model`, and a checkpoint carrying
+    e3nn-style buffers + `ema_` duplicates + `module.` prefixes loaded through its OWN `load_checkpoint` /
+    `load_state_dict` walk (druglib/core/runner/checkpoint.py:32-100,403-460) with predict.py's arguments
+    (strict=True, drop_keys=['^ema_'], DiffBindFR/app/predict.py:118-125).  Freezes the checkpoint's key list / shapes
+    as tests/golden/boundary.npz; tests/test_host.py replays it without the reference."""
+    print("[boundary: real registry + real checkpoint loader]")
+    import importlib.util
+    import re
+    from collections import OrderedDict
+    d = os.path.join(ref_shims.COPY, "druglib")
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(d, rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    utils = sys.modules["druglib.utils"]
+    load("druglib.utils.misc", "utils/misc.py")
+    reg = load("druglib.utils.registry", "utils/registry.py")
+    utils.Registry, utils.build_from_cfg = reg.Registry, reg.build_from_cfg        # the REAL ones from here on
+    builder = load("druglib.models.builder", "models/builder.py")
+    load("druglib.models.Docking.default_MLDockBuilder", "models/Docking/default_MLDockBuilder.py")
+    import diffbindfr_amd as dba
+    assert dba.register_into_druglib() is True
+    assert builder.INTERACTION.get("TensorProductModelHIP") is dba.TensorProductModelHIP
+    assert builder.MLDOCK_BUILDER.get("DiffBindFRHIP") is dba.DiffBindFRHIP
+    # the keyword of the reference is `overwrite` (registry.py:285-288); the package's mirror takes the same
+    try:
+        builder.INTERACTION.register_module(name="TensorProductModelHIP", module=dba.TensorProductModelHIP)
+        raise AssertionError("re-registration without overwrite must fail")
+    except KeyError:
+        pass
+    builder.INTERACTION.register_module(name="TensorProductModelHIP", overwrite=True, module=dba.TensorProductModelHIP)
+    try:
+        dba.INTERACTION.register_module(name="TensorProductModelHIP", module=dba.TensorProductModelHIP)
+        raise AssertionError("mirror: re-registration without overwrite must fail")
+    except KeyError:
+        pass
+    dba.INTERACTION.register_module(name="TensorProductModelHIP", overwrite=True, module=dba.TensorProductModelHIP)
+    # built the way engines.py:147-148 does: cfg.model with --cfg-options model.type=DiffBindFRHIP
+    scfg = schedule.default_sample_cfg()
+    mcfg_model = ED(type="DiffBindFRHIP", task="mldock", train_cfg=None,
+                    diffusion_model=ED(type="TensorProductModelHIP", cfg=ref_model_cfg()))
+    model = builder.build_task_model(mcfg_model, test_cfg=ED(sample_cfg=ED(vars(scfg))))
+    assert isinstance(model, dba.DiffBindFRHIP) and isinstance(model.diffusion_model, dba.TensorProductModelHIP)
+    # a checkpoint as the reference's trainer writes it: the reference model's own keys under `diffusion_model.`,
+    # e3nn 0.5.1's persistent buffers where the reference holds e3nn modules (`tp` of every conv, `final_tp_tor`), EMA
+    # copies under `ema_` with dots replaced by underscores (hooks/ema.py), everything behind DDP's `module.`
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=5)
+    ref_model = ns.tpscore.TensorProductModel(ref_model_cfg())
+    assert sorted(ref_model.state_dict()) == sorted(params)
+    ck = OrderedDict()
+    for k, v in ref_model.state_dict().items():
+        ck["module.diffusion_model." + k] = params[k].clone()
+    convs = [f"{f}.{l}" for f in ("lig_conv_layers", "atom_conv_layers", "cross_al_conv_layers", "cross_la_conv_layers")
+             for l in range(6)] + ["final_conv", "tor_bond_conv", "sc_tor_bond_conv"]
+    e3 = []
+    for c in convs:
+        e3 += [(f"{c}.tp.weight", torch.empty(0)), (f"{c}.tp.output_mask", torch.ones(7)),
+               (f"{c}.tp._compiled_main_left_right._w3j_1_1_0", torch.zeros(3, 3, 1))]
+    e3 += [("final_tp_tor.weight", torch.empty(0)), ("final_tp_tor.output_mask", torch.ones(45)),
+           ("final_tp_tor._compiled_main_left_right._w3j_2_2_1", torch.zeros(5, 5, 3))]
+    for k, v in e3:
+        ck["module.diffusion_model." + k] = v
+    for k in list(ck):
+        ck["ema_" + k[len("module."):].replace(".", "_")] = ck[k].clone()
+    # the reference's own loader functions, executed from its source
+    path = os.path.join(d, "core/runner/checkpoint.py")
+    env = {"nn": torch.nn, "OrderedDict": OrderedDict, "Optional": __import__("typing").Optional, "logging": __import__("logging"),
+           "Union": __import__("typing").Union, "Any": __import__("typing").Any, "List": list, "Tuple": tuple, "re": re,
+           "get_dist_info": lambda: (0, 1)}
+    preg = types.ModuleType("parallel_registry")
+    preg.MODULE_WRAPPERS = reg.Registry("module wrapper")
+    preg.MODULE_WRAPPERS.register_module(module=torch.nn.parallel.DataParallel)
+    preg.MODULE_WRAPPERS.register_module(module=torch.nn.parallel.DistributedDataParallel)
+    penv = {"nn": torch.nn, "MODULE_WRAPPERS": preg.MODULE_WRAPPERS}
+    exec(_ref_function_source(os.path.join(d, "core/runner/parallel/utils.py"), "def is_module_wrapper(", "\ndef "), penv)
+    env["is_module_wrapper"] = penv["is_module_wrapper"]
+    exec(_ref_function_source(path, "def load_state_dict(", "\ndef get_torchvision_models"), env)
+    exec(_ref_function_source(path, "\ndef load_checkpoint(\n        model", "\ndef weights_to_cpu"), env)
+    env["_load_checkpoint"] = lambda filename, map_location, logger: {"state_dict": ck, "meta": {}}
+    env["load_checkpoint"](model, "diffbindfr_paper.pth", map_location="cpu", strict=True, logger=None,
+                           revise_keys=[(r"^module\.", "")], drop_keys=[r"^ema_"], use_ema=False)
+    got = model.diffusion_model.state_dict()
+    for k, v in params.items():
+        assert torch.equal(got[k], v), k
+    absorbed = sorted(model.diffusion_model.ignored_keys)
+    assert absorbed == sorted("diffusion_model." + k for k, _ in e3), "the e3nn stand-ins must take exactly the e3nn keys"
+    print(f"  reference load_checkpoint(strict=True): {len(params)} tensors loaded, {len(absorbed)} e3nn buffers absorbed")
+    # a genuinely unexpected / missing key must still fail under strict
+    for bad in ("extra", "missing"):
+        ck2 = OrderedDict(ck)
+        if bad == "extra":
+            ck2["module.diffusion_model.lig_conv_layers.0.fc.lin.9.weight"] = torch.zeros(1)
+        else:
+            del ck2["module.diffusion_model.final_conv.fc.lin.0.bias"]
+        env["_load_checkpoint"] = lambda filename, map_location, logger, c=ck2: {"state_dict": c}
+        try:
+            env["load_checkpoint"](model, "x.pth", strict=True, drop_keys=[r"^ema_"])
+            raise AssertionError(f"strict load must reject a checkpoint with an {bad} key")
+        except RuntimeError:
+            pass
+    keys = [k for k in ck]
+    np.savez_compressed(os.path.join(HERE, "boundary.npz"),
+                        keys=np.asarray(keys), shapes=np.asarray([",".join(map(str, ck[k].shape)) for k in keys]),
+                        absorbed=np.asarray(absorbed), n_params=np.asarray(len(params)))
+
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_geometry()
@@ -758,4 +881,5 @@ if __name__ == "__main__":
     golden_real_complex()
     golden_export()
     golden_pocket_select()
+    golden_boundary()           # last: swaps the stand-in registry for the reference's real one
     print("golden fixtures written to", HERE)

@@ -72,6 +72,75 @@ def test_state_dict_contract():
         model.load_state_dict(bad, strict=True)
 
 
+def _walk_load(module, state_dict, strict=True):
+    """The module-by-module walk of the reference's loader (druglib/core/runner/checkpoint.py:62-93: recursive
+    ``_load_from_state_dict`` with strict=True, then the unexpected / missing key check) -- NOT torch's
+    ``load_state_dict``, which predict.py never calls."""
+    unexpected, missing, errs = [], [], []
+    state_dict = state_dict.copy()
+
+    def load(m, prefix=""):
+        m._load_from_state_dict(state_dict, prefix, {}, True, missing, unexpected, errs)
+        for name, child in m._modules.items():
+            if child is not None:
+                load(child, prefix + name + ".")
+    load(module)
+    missing = [k for k in missing if "num_batches_tracked" not in k]
+    if strict and (unexpected or missing or errs):
+        raise RuntimeError(f"unexpected {unexpected} missing {missing} {errs}")
+    return unexpected, missing
+
+
+def test_reference_loader_fixture():
+    """tests/golden/boundary.npz = key list / shapes of a checkpoint that the reference's OWN `load_checkpoint(strict=True,
+    drop_keys=['^ema_'])` accepted for `DiffBindFRHIP` built by the reference's own `build_task_model` (frozen by
+    tests/golden/make_golden.py::golden_boundary in the build container): e3nn buffers under every `tp` /
+    `final_tp_tor`, `ema_` duplicates, DDP's `module.` prefix.  Replayed here on the same walk."""
+    import os
+    import re
+    from collections import OrderedDict
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "boundary.npz"))
+    g = torch.Generator().manual_seed(0)
+    ck = OrderedDict()
+    for k, shp in zip(z["keys"].tolist(), z["shapes"].tolist()):
+        shape = tuple(int(x) for x in shp.split(",")) if shp else ()
+        ck[k] = torch.rand(shape, generator=g)
+    # predict.py:118-125 -> checkpoint.py:442-453: drop ^ema_, strip ^module.
+    sd = OrderedDict((re.sub(r"^module\.", "", k), v) for k, v in ck.items() if not re.match(r"^ema_", k))
+    model = dba.MLDOCK_BUILDER.build(dict(type="DiffBindFRHIP", diffusion_model=dict(type="TensorProductModelHIP", cfg={})),
+                                     default_args=dict(train_cfg=None, test_cfg=None))
+    fp0 = model.diffusion_model._fingerprint()
+    _walk_load(model, sd, strict=True)
+    assert sorted(model.diffusion_model.ignored_keys) == sorted(z["absorbed"].tolist())
+    own = model.state_dict()
+    assert len(own) == int(z["n_params"])
+    for k, v in own.items():
+        assert torch.equal(v, sd[k]), k
+    assert model.diffusion_model._fingerprint() != fp0           # the packed device model is rebuilt on the next call
+    # torch's own loader takes the same checkpoint too
+    model.load_state_dict(sd, strict=True)
+    # a genuinely unknown key / a missing tensor still fail under strict
+    bad = OrderedDict(sd)
+    bad["diffusion_model.lig_conv_layers.0.fc.lin.9.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        _walk_load(model, bad, strict=True)
+    bad = OrderedDict(sd)
+    del bad["diffusion_model.final_conv.fc.lin.0.bias"]
+    with pytest.raises(RuntimeError):
+        _walk_load(model, bad, strict=True)
+
+
+def test_registry_keyword_is_overwrite_like_the_reference():
+    """druglib/utils/registry.py:285-358: `register_module(name=None, overwrite=False, module=None)`."""
+    with pytest.raises(KeyError):
+        dba.INTERACTION.register_module(name="TensorProductModelHIP", module=dba.TensorProductModelHIP)
+    dba.INTERACTION.register_module(name="TensorProductModelHIP", overwrite=True, module=dba.TensorProductModelHIP)
+    with pytest.raises(KeyError):
+        dba.INTERACTION.register_module(overwrite="yes")
+    with pytest.raises(TypeError):
+        dba.INTERACTION.register_module(force=True)
+
+
 def test_registry_builds_like_the_reference():
     cfg = dict(type="DiffBindFRHIP", diffusion_model=dict(type="TensorProductModelHIP", cfg=dict(ns=48, nv=12)),
                test_cfg=dict(sample_cfg=dict(inference_steps=22, actual_steps=20)))
