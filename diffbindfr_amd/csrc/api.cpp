@@ -19,7 +19,7 @@ struct GraphArgs {
   int lig_cap, atom_cap, dynamic_cross;
   EdgeSet set[N_SETS];
   int* err;
-  int step, lds_nl, lds_na;
+  int step, lds_nl, lds_na, n_chunk;
 };
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
 void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
@@ -505,7 +505,7 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   for (int k = 0; k < N_SETS; ++k) {
     if (caps[k] > 0x7fffff00L) return fail(DBFR_ERR_ARG, "batch too large for int32 edge indices; split it");
     static const char* names[N_SETS] = {"ll", "aa", "al", "la", "tor", "sc"};
-    edge_set_take(b, w->set[k], (int)caps[k], ntg[k] + 1, G, w->n_edges6 ? w->n_edges6 + k : nullptr, names[k]);
+    edge_set_take(b, w->set[k], (int)caps[k], ntg[k] + 1, G * ((B->max_na + 255) / 256), w->n_edges6 ? w->n_edges6 + k : nullptr, names[k]);
     maxcap = std::max(maxcap, caps[k]);
   }
   w->c_tgt = b.take<int>(NL); w->c_gth = b.take<int>(NL); w->c_dist = b.take<float>(NL); w->c_sh = b.take<float>((size_t)NL * SH_LD, "center.sh");
@@ -585,7 +585,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   ga.cross_cut2 = cfg.dynamic_max_cross ? 1.0f : cfg.cross_cutoff * cfg.cross_cutoff;
   ga.lig_cap = cfg.lig_max_neighbors; ga.atom_cap = cfg.atom_max_neighbors; ga.dynamic_cross = cfg.dynamic_max_cross;
   for (int k = 0; k < N_SETS; ++k) ga.set[k] = w.set[k];
-  ga.err = w.err; ga.step = step; ga.lds_nl = ga.lds_na = 0;
+  ga.err = w.err; ga.step = step; ga.lds_nl = ga.lds_na = ga.n_chunk = 0;
   launch_edges(ga, false, st);
   // ---- embeddings
   {
@@ -655,6 +655,16 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   const int D = dims[std::min(cfg.num_conv_layers, 3)];
   if (D != MAXD) return fail(DBFR_ERR_ARG, "heads need num_conv_layers >= 3");
   const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
+  // ---- the three heads are independent: in the small-batch (multi-stream) regime the two torsion heads run on side streams
+  const bool fork_heads = w.multi && m->profile != 1;
+  hipStream_t s_tor = fork_heads ? m->side[0] : st, s_sc = fork_heads ? m->side[1] : st;
+  float* msg_tor = fork_heads ? w.msg[1] : w.msg[0];
+  float* msg_sc = fork_heads ? w.msg[2] : w.msg[0];
+  if (fork_heads) {
+    HIPCHECK(hipEventRecord(m->ev_fork, st));
+    HIPCHECK(hipStreamWaitEvent(s_tor, m->ev_fork, 0));
+    HIPCHECK(hipStreamWaitEvent(s_sc, m->ev_fork, 0));
+  }
   // ---- translation / rotation head
   launch_center_edges(*B, w.c_tgt, w.c_gth, w.c_dist, w.c_sh, w.c_row_start, w.c_row_cnt, st);
   {
@@ -674,30 +684,36 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   // ---- ligand torsion head
   if (B->NTOR > 0) {
     const EdgeSet& T = w.set[SET_TOR];
-    launch_bond_attr(lx, D, B->bond_src, B->bond_dst, B->tor_bond, 0, B->NTOR, w.tor_attr, st);
+    launch_bond_attr(lx, D, B->bond_src, B->bond_dst, B->tor_bond, 0, B->NTOR, w.tor_attr, s_tor);
     {
       MlpArgs a; memset(&a, 0, sizeof a);
       a.w = m->tor_edge_emb; a.mode = IN_G; a.n_rows_dev = T.n_edges; a.n_rows_max = T.cap; a.dist = T.dist;
       a.gs_offset = m->gs_lig_off; a.gs_coeff = m->gs_lig_c; a.out = T.emb;
-      launch_mlp(a, st);
+      launch_mlp(a, s_tor);
     }
-    conv_call(m, m->tor_conv, T.n_edges, T.cap, T.tgt, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg[0], st);
-    launch_reduce_ln(w.msg[0], T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
-    launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, st);
+    conv_call(m, m->tor_conv, T.n_edges, T.cap, T.tgt, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, msg_tor, s_tor);
+    launch_reduce_ln(msg_tor, T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, s_tor);
+    launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, s_tor);
   }
   // ---- side-chain torsion head
   if (!cfg.no_sc_torsion && B->NSC > 0) {
     const EdgeSet& S = w.set[SET_SC];
-    launch_bond_attr(ax, D, B->sc_bond, nullptr, nullptr, 2, B->NSC, w.sc_attr, st);
+    launch_bond_attr(ax, D, B->sc_bond, nullptr, nullptr, 2, B->NSC, w.sc_attr, s_sc);
     {
       MlpArgs a; memset(&a, 0, sizeof a);
       a.w = m->sc_edge_emb; a.mode = IN_G; a.n_rows_dev = S.n_edges; a.n_rows_max = S.cap; a.dist = S.dist;
       a.gs_offset = m->gs_atom_off; a.gs_coeff = m->gs_atom_c; a.out = S.emb;
-      launch_mlp(a, st);
+      launch_mlp(a, s_sc);
     }
-    conv_call(m, m->sc_conv, S.n_edges, S.cap, S.tgt, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg[0], st);
-    launch_reduce_ln(w.msg[0], S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, st);
-    launch_tor_final(w.sc_feat, m->sc_final, c->sc_tor_score_norm2, cfg.scale_by_sigma, B->NSC, out->sc_tor, st);
+    conv_call(m, m->sc_conv, S.n_edges, S.cap, S.tgt, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, msg_sc, s_sc);
+    launch_reduce_ln(msg_sc, S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, s_sc);
+    launch_tor_final(w.sc_feat, m->sc_final, c->sc_tor_score_norm2, cfg.scale_by_sigma, B->NSC, out->sc_tor, s_sc);
+  }
+  if (fork_heads) {
+    HIPCHECK(hipEventRecord(m->ev_join[0], s_tor));
+    HIPCHECK(hipEventRecord(m->ev_join[1], s_sc));
+    HIPCHECK(hipStreamWaitEvent(st, m->ev_join[0], 0));
+    HIPCHECK(hipStreamWaitEvent(st, m->ev_join[1], 0));
   }
   return DBFR_OK;
 }

@@ -89,8 +89,8 @@ struct EdgeSet {           // one per-step edge list, grouped (CSR) by scatter-t
   float* emb;          // [cap][NS] edge embedding after its SimpleLinear
   int* row_start;      // [n_targets]
   int* row_cnt;        // [n_targets]
-  int* g_cnt;          // [G] per-graph totals (count pass)
-  int* g_base;         // [G] per-graph base offset (scan)
+  int* g_cnt;          // [G * n_chunk] per-(graph, target chunk) totals (count pass)
+  int* g_base;         // [G * n_chunk] base offset of each chunk's first edge (scan)
 };
 
 struct ConvArgs {

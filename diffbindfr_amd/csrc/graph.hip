@@ -36,6 +36,7 @@ struct GraphArgs {
                           // [2+k] set k overflowed in THIS step, [8+k] largest edge count seen for set k
   int step;               // sampler step index (0 for dbfr_score)
   int lds_nl, lds_na;     // LDS staging capacities (>= max_nl / max_na of the batch)
+  int n_chunk;            // 256-target chunks per graph the pocket-atom-targeted sets are split into (own workgroup each)
 };
 
 __device__ __forceinline__ float d2_rn(float ax, float ay, float az, float bx, float by, float bz) {
@@ -246,24 +247,32 @@ __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
   extern __shared__ float dyn_lds[];
   GraphLds s;
   lds_views(s, dyn_lds, A.lds_nl, A.lds_na);
-  const int g = blockIdx.x, kind = blockIdx.y;
+  const int C = A.n_chunk;
+  const int g = blockIdx.x / C, chunk = blockIdx.x - g * C, kind = blockIdx.y;
   const EdgeSet& S = A.set[kind];
   if (S.cap == 0) return;
+  // Sets whose targets are pocket atoms (up to thousands per graph) are cut into chunks of 256 targets, one workgroup
+  // each (a single 866-atom pocket would otherwise be one workgroup per set: 1.5 ms per step at BASELINE config 1);
+  // the other sets (<= 256 ligand atoms / a few dozen torsions per graph) are done by chunk 0 alone.
+  const bool split = kind == SET_AA || kind == SET_LA;
+  if (!split && chunk > 0) { if (!EMIT) S.g_cnt[blockIdx.x] = 0; return; }
   // this set did not fit its capacity in this step: leave it EMPTY (row_cnt 0) so that nothing downstream reads past
   // the buffers; the host re-plans with the counted sizes and resumes from this step (dbfr_capacity_report)
   const bool overflow = EMIT && A.err[2 + kind] != 0;
+  int t0, nt;  // first global target id of the graph, number of targets
+  target_range(A, kind, g, t0, nt);
+  const int c_begin = split ? chunk * 256 : 0, c_end = split ? min(nt, c_begin + 256) : nt;
+  if (c_begin >= nt) { if (!EMIT) S.g_cnt[blockIdx.x] = 0; return; }
   int l0, nl, a0, na;
   load_graph(s, A, g, kind, l0, nl, a0, na);
   if (kind == SET_LL) cap_thresholds(s, s.lx, s.ly, s.lz, nl, A.lig_cut2, A.lig_cap);
   if (kind == SET_AA) cap_thresholds(s, s.ax, s.ay, s.az, na, A.atom_cut2, A.atom_cap);
-  int t0, nt;  // first global target id of the graph, number of targets
-  target_range(A, kind, g, t0, nt);
-  int running = EMIT ? S.g_base[g] : 0;
+  int running = EMIT ? S.g_base[blockIdx.x] : 0;
   int total = 0;
-  for (int c0 = 0; c0 < nt; c0 += 256) {  // chunks of 256 targets, block scan inside each
+  for (int c0 = c_begin; c0 < c_end; c0 += 256) {  // chunks of 256 targets, block scan inside each
     const int t = c0 + threadIdx.x;
     int cnt = 0;
-    if (t < nt) {
+    if (t < c_end) {
       if (EMIT) {
         cnt = overflow ? 0 : S.row_cnt[t0 + t];
         if (overflow) S.row_cnt[t0 + t] = 0;
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
     }
     const int incl = s.scan[threadIdx.x], chunk_total = s.scan[255];
     __syncthreads();
-    if (EMIT && t < nt) {
+    if (EMIT && t < c_end) {
       const int base = overflow ? 0 : running + incl - cnt;
       S.row_start[t0 + t] = base;
       if (overflow) {
@@ -309,15 +318,15 @@ __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
     running += chunk_total;
     total += chunk_total;
   }
-  if (!EMIT && threadIdx.x == 0) S.g_cnt[g] = total;
+  if (!EMIT && threadIdx.x == 0) S.g_cnt[blockIdx.x] = total;
 }
 
-// exclusive scan of the per-graph totals; one block per edge set
+// exclusive scan of the per-(graph, chunk) totals; one block per edge set
 __global__ __launch_bounds__(256) void k_edges_scan(GraphArgs A) {
   __shared__ int sc[256];
   const EdgeSet& S = A.set[blockIdx.x];
   if (S.cap == 0) { if (threadIdx.x == 0 && S.n_edges) *S.n_edges = 0; return; }
-  const int G = A.b.G;
+  const int G = A.b.G * A.n_chunk;
   int running = 0;
   for (int c0 = 0; c0 < G; c0 += 256) {
     int g = c0 + threadIdx.x;
@@ -355,9 +364,10 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     granted = 160 * 1024 - 64;
   }
-  hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G, N_SETS), dim3(256), lds, st, A);
+  A.n_chunk = (A.b.max_na + 255) / 256;      // must match plan() in api.cpp (g_cnt / g_base hold G * n_chunk entries)
+  hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
   hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(k_edges<true>, dim3(A.b.G, N_SETS), dim3(256), lds, st, A);
+  hipLaunchKernelGGL(k_edges<true>, dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -544,6 +544,92 @@ def golden_real_complex():
     np.savez_compressed(os.path.join(HERE, "real_3dbs.npz"), **out)
 
 
+
+def golden_real_trajectory():
+    """BASELINE config 1 end to end: the 3DBS pocket (866 atoms, reference-built templates / edges / features,
+    Decentration) + its crystal ligand, 2 poses initialised by the (pinned) LigInit / SCProtInit restatement, taken
+    through the reference's OWN `DiffBindFR.sample()` (scFlex.py:124-250 on tpscore.py) for all 20 steps.  Asserts the
+    oracle reproduces it and freezes batch + noise + trajectories as tests/golden/real_3dbs_traj.npz."""
+    print("[real complex 3DBS: 20-step reference trajectory]")
+    import time
+    from oracle import pose_init as opi
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    z = np.load(os.path.join(HERE, "real_3dbs.npz"))
+    if "druglib.datasets.builder" not in sys.modules or not hasattr(sys.modules["druglib.datasets.builder"], "PIPELINES"):
+        dsb = types.ModuleType("druglib.datasets.builder")
+        dsb.PIPELINES = ns.builder.INTERACTION.__class__("pipeline")
+        sys.modules["druglib.datasets.builder"] = dsb
+    obj = sys.modules["druglib.utils.obj"]
+    obj.Ligand3D = object
+    obj.make_torsion_mask = ns.prot_math.make_torsion_mask
+    ref_shims._load("druglib.datasets.Docking.utils", "datasets/Docking/utils.py")
+    pp = ref_shims._load("druglib.datasets.Docking.pocket_pipeline", "datasets/Docking/pocket_pipeline.py")
+    seq, pos, msk = z["aatype"], z["atom14_position"], z["atom14_mask"]
+    N = len(seq)
+    seq_t, msk_t = torch.from_numpy(seq), torch.from_numpy(msk)
+    fake = types.SimpleNamespace(num_res=lambda: N, atom_mask=np.zeros((N, 37)), residue_prop={})
+    feat = pp.PocketFeaturizer()(dict(atom14_mask=msk_t, sequence=seq_t, pocket=fake))["pocket_node_feature"]
+    data = dict(atom14_position=torch.from_numpy(pos).float(), atom14_mask=msk_t, sequence=seq_t,
+                backbone_transl=torch.from_numpy(z["ref_backbone_transl"]).float(), lig_pos=torch.from_numpy(z["lig_pos"]).float())
+    data = pp.Decentration()(data)
+    import tests.test_real_complex as trc
+    lig_half = trc._ligand_half(z)
+    rec = dict(lig_half, lig_pos=data["lig_pos"], sequence=seq_t, atom14_mask=msk_t,
+               backbone_transl=data["backbone_transl"], backbone_rots=torch.from_numpy(z["ref_backbone_rots"]).float(),
+               default_frame=torch.from_numpy(z["ref_default_frame"]).float(),
+               rigid_group_positions=torch.from_numpy(z["ref_rigid_group_positions"]).float(),
+               torsion_angle=torch.from_numpy(z["ref_torsion_angle"]).float(),
+               torsion_edge_index=torch.from_numpy(z["ref_torsion_edge_index"]),
+               sc_torsion_edge_mask=torch.from_numpy(z["ref_sc_torsion_edge_mask"]), pocket_node_feature=feat)
+    Tt = {k: (torch.from_numpy(np.asarray(v)) if k == "atom14_to_group" else v) for k, v in T.items()}
+    fixed = opi.sc_fixer(copy.deepcopy(rec), T)
+    rng = np.random.default_rng(31)
+    n_tor = int(rec["tor_edge_mask"].sum())
+    poses = []
+    for _ in range(2):
+        tape = dict(tor=rng.uniform(-np.pi, np.pi, n_tor), rot=synthetic._rand_rot(rng),
+                    tr=torch.from_numpy(rng.normal(0, 3.0, (1, 3))).float(),           # near the pocket: cross edges on every step
+                    sc=rng.uniform(-np.pi, np.pi, (N, 4)))
+        poses.append(opi.init_pose(fixed, tape, Tt))
+    coll = opi.collate(poses)
+    d = types.SimpleNamespace(**coll)
+    d.batch = d.lig_node_batch
+    G = 2
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=1)
+    model = ns.tpscore.TensorProductModel(ref_model_cfg()).eval()
+    model.load_state_dict(params, strict=True)
+    scfg = schedule.default_sample_cfg()
+    go = sys.modules["druglib.utils.geometry_utils"]
+    go.so3 = types.SimpleNamespace(score_norm=schedule.so3_score_norm)
+    go.torus = types.SimpleNamespace(score_norm=lambda s: schedule.torus_score_norm(s, 0))
+    ref_sampler = ns.scflex.DiffBindFR(diffusion_model=None, test_cfg=ED(sample_cfg=ED(vars(scfg))))
+    ref_sampler.diffusion_model_cfg = ED(no_sc_torsion=False)
+    ref_sampler.diffusion_model = model
+    rd = ED({k: (v.clone() if torch.is_tensor(v) else v) for k, v in vars(d).items() if k != "rot_node_mask"})
+    rd.metastore = {"rot_node_mask": [m.clone() for m in d.rot_node_mask]}
+    torch.manual_seed(1234)
+    t0 = time.time()
+    res = ref_sampler.sample(rd, visualize=True)
+    print(f"  reference sample(): 2 poses x {scfg.actual_steps} steps of the 866-atom pocket in {time.time() - t0:.0f}s")
+    lig_ref = torch.cat([r[0] for r in res], dim=1)
+    a14_ref = torch.cat([r[1] for r in res], dim=1)
+    n_sc = int(d.sc_torsion_edge_mask.sum())
+    noise = sampler.draw_noise(scfg.actual_steps, G, G * n_tor, n_sc, seed=1234)
+    lig_o, a14_o = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise,
+                                  torch.from_numpy(T["atom14_to_group"]).long(), torus_seed=0, visualize=True)
+    close(lig_o, lig_ref, 1e-4, "3dbs sample(): ligand trajectory (20 steps)")
+    close(a14_o, a14_ref, 1e-4, "3dbs sample(): atom14 trajectory (20 steps)")
+    out = batch_to_npz(d)
+    out.update(params_seed=np.asarray(1), params_sha256=np.asarray(params_digest(params)), noise_tr=npy(noise.tr),
+               noise_rot=npy(noise.rot), noise_tor=npy(noise.tor), noise_sc=npy(noise.sc), traj_lig=npy(lig_ref),
+               final_atom14=npy(a14_ref[-1]), atom14_step0=npy(a14_ref[0]))
+    for k in ("default_frame", "rigid_group_positions"):      # float32 exactly; compressed well
+        out[k] = out[k].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "real_3dbs_traj.npz"), **out)
+    print("  real_3dbs_traj.npz:", os.path.getsize(os.path.join(HERE, "real_3dbs_traj.npz")) // 1024, "KiB")
+
+
 # --------------------------------------------------------------------------- 8. output side (SURVEY 8(f) row f3)
 def _parse_sdf_elements(path):
     L = open(path).read().split("\n")
@@ -879,6 +965,7 @@ if __name__ == "__main__":
     golden_pose_init()
     golden_pocket()
     golden_real_complex()
+    golden_real_trajectory()
     golden_export()
     golden_pocket_select()
     golden_boundary()           # last: swaps the stand-in registry for the reference's real one

@@ -1,0 +1,31 @@
+"""Developer run for profiling the small-batch path: BASELINE configs[0] literally (1 complex of the 3DBS shape x 4 poses
+x 20 steps) or predict.py's -bs 16 of the cfg-2 shape, a few repetitions, wall time printed.
+    rocprofv3 --kernel-trace --stats -d gpurun_out/lat -- python tools/latency_run.py --case cfg1"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import diffbindfr_amd as dba  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--case", default="cfg1")
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+cfg_id, n_c, ppc = {"cfg1": (1, 1, 4), "bs16": (2, 4, 4), "bs40": (2, 1, 40)}[a.case]
+model = bench.seeded_params().to(dev)
+samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
+jobs = bench.make_jobs(cfg_id, n_c, seed=77)
+samp.run_complexes(jobs, ppc, dev, seed=1)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for r in range(a.reps):
+    samp.run_complexes(jobs, ppc, dev, seed=2 + r)
+torch.cuda.synchronize()
+print(f"{a.case}: {(time.perf_counter() - t0) / a.reps:.4f} s per run of {n_c * ppc} poses")
