@@ -9,8 +9,15 @@
 
 // ---- kernel launchers (conv.hip / graph.hip / heads.hip)
 void launch_conv(const ConvArgs& a, hipStream_t st);
+void launch_conv2(const Conv2Args& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
                       const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
+struct ReduceLayerArgs {
+  const float* msg[4]; const int* row_start[4]; const int* row_cnt[4]; LNDesc ln[4];
+  int NL, NA, D, D_old;
+  const float* old_l; const float* old_a; float* out_l; float* out_a;
+};
+void launch_reduce_ln_layer(const ReduceLayerArgs& a, hipStream_t st);
 enum SetKind { SET_LL = 0, SET_AA = 1, SET_AL = 2, SET_LA = 3, SET_TOR = 4, SET_SC = 5, N_SETS = 6 };
 struct GraphArgs {
   dbfr_batch b;
@@ -78,6 +85,9 @@ struct dbfr_model {
   std::vector<void*> allocs;
   ConvW layer[8][4];   // [l][family]: 0 lig, 1 cross_al, 2 atom, 3 cross_la
   ConvW final_conv, tor_conv, sc_conv;
+  ConvW2 layer2[8][4], tor_conv2, sc_conv2;   // k_conv2 layouts of the K=144 convs
+  int use_conv2;
+  int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
   Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
   Mlp2 tr_final, rot_final, tor_final, sc_final;
   const float* atom_emb[5]; int atom_dims[5];
@@ -330,6 +340,139 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
   return rc;
 }
 
+// k_conv2 layout (conv2.hip): same channel-owner row order as pack_conv, but ONE tile sequence for all waves.
+static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, int kind, const ConvW& base, ConvW2* o) {
+  ConvSpec sp = make_conv_spec(kind);
+  const int K = sp.K;
+  if (K != 144) return fail(DBFR_ERR_ARG, "k_conv2 layout is for the K=144 convs");
+  int rc = 0;
+  const float* W2 = need(tm, name + ".fc.lin.3.weight", (int64_t)sp.W * K, &rc);
+  const float* B2 = need(tm, name + ".fc.lin.3.bias", sp.W, &rc);
+  if (rc) return rc;
+  const int KT = K / 16;
+  struct Pair { int io, w; std::vector<const PathDesc*> paths; };
+  std::vector<Pair> pairs;
+  for (int io = 0; io < (int)sp.out.size(); ++io)
+    for (int w = 0; w < sp.out[io].mul; ++w) {
+      Pair pr{io, w, {}};
+      for (auto& p : sp.paths) if (p.io == io) pr.paths.push_back(&p);
+      std::stable_sort(pr.paths.begin(), pr.paths.end(),
+                       [](const PathDesc* a, const PathDesc* b) { return a->type != b->type ? a->type < b->type : a->mul1 > b->mul1; });
+      pairs.push_back(pr);
+    }
+  auto sig = [](const Pair& a) {
+    std::string k;
+    for (auto* p : a.paths) k += std::to_string(p->type) + ":" + std::to_string(p->mul1) + ":" + std::to_string(p->in_off) + ",";
+    return k;
+  };
+  struct Group { std::vector<int> pair_idx; int tiles; int xph; };
+  std::vector<Group> groups;
+  {
+    std::map<std::string, std::vector<int>> cls;
+    std::vector<std::string> order;
+    for (int i = 0; i < (int)pairs.size(); ++i) {
+      std::string k = sig(pairs[i]);
+      if (!cls.count(k)) order.push_back(k);
+      cls[k].push_back(i);
+    }
+    for (auto& k : order) {
+      auto& v = cls[k];
+      for (size_t i = 0; i < v.size(); i += 4) {
+        Group g;
+        for (size_t j = i; j < i + 4; ++j) g.pair_idx.push_back(j < v.size() ? v[j] : -1);
+        g.tiles = 0;
+        bool hi = false, lo = false;
+        for (auto* p : pairs[v[i]].paths) {
+          if (p->mul1 % 4) return fail(DBFR_ERR_ARG, "input multiplicity not a multiple of 4 in " + name);
+          g.tiles += p->mul1 / 4;
+          if (p->in_off >= 120) hi = true;
+          if (p->in_off < 48) lo = true;
+        }
+        // the LDS x row holds 120 floats: [0e|1o|1e] for the groups that read the 48x0e inputs, [0o|1o|1e] for those
+        // that read the 48x0o inputs (x[120:168]); no output irrep of this model family reads both
+        if (hi && lo) return fail(DBFR_ERR_ARG, "channel group reads both scalar input blocks in " + name);
+        g.xph = hi ? 1 : 0;
+        groups.push_back(g);
+      }
+    }
+  }
+  std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.xph < b.xph; });
+  std::vector<int> rows_orig; std::vector<float> rows_scale;
+  std::vector<RunDesc> runs;
+  std::vector<int> group_run0, group_tiles;
+  for (const Group& G : groups) {
+    group_run0.push_back((int)runs.size());
+    group_tiles.push_back(G.tiles);
+    const Pair& lead = pairs[G.pair_idx[0]];
+    for (size_t pi = 0; pi < lead.paths.size(); ++pi) {
+      const PathDesc* lp = lead.paths[pi];
+      RunDesc rd;
+      const uint32_t flags = (pi == 0 ? 1u : 0u) | (pi + 1 == lead.paths.size() ? 2u : 0u);
+      const uint32_t tile0 = (uint32_t)rows_orig.size() / 16, nt = (uint32_t)lp->mul1 / 4, x_step = 4u * (2 * lp->l1 + 1);
+      if (tile0 >= (1u << 20) || nt >= (1u << 12)) return fail(DBFR_ERR_ARG, "conv too large for the run descriptor");
+      rd.tile0_n = tile0 | (nt << 20);
+      rd.meta = (uint32_t)lp->type | (flags << 4) | ((uint32_t)lp->sh_off << 8) | (x_step << 12) | ((uint32_t)G.xph << 20);
+      rd.x_off4 = rd.o_off4 = 0;
+      for (int g = 0; g < 4; ++g) {
+        const int pidx = G.pair_idx[g];
+        const PathDesc* p = pidx >= 0 ? pairs[pidx].paths[pi] : lp;
+        if (p->type != lp->type || p->sh_off != lp->sh_off || p->mul1 != lp->mul1 || p->in_off != lp->in_off)
+          return fail(DBFR_ERR_ARG, "channel group with non-uniform paths in " + name);
+        const int d_o = 2 * p->lo + 1;
+        const uint32_t xo = p->in_off >= 120 ? p->in_off - 120 : p->in_off;     // position inside the 120-float LDS row
+        const uint32_t oo = pidx >= 0 ? p->out_off + pairs[pidx].w * d_o : 255u;  // 255 >= D_out: padded channel, never stored
+        if (xo + 4 * (2 * p->l1 + 1) * (p->mul1 / 4) > 120 || (oo != 255u && (int)oo >= sp.D_out))
+          return fail(DBFR_ERR_ARG, "irreps do not fit the k_conv2 row layout in " + name);
+        rd.x_off4 |= xo << (8 * g);
+        rd.o_off4 |= oo << (8 * g);
+      }
+      runs.push_back(rd);
+      for (int u0 = 0; u0 < lp->mul1; u0 += 4)
+        for (int g = 0; g < 4; ++g) {
+          const int pidx = G.pair_idx[g];
+          const PathDesc* p = pidx >= 0 ? pairs[pidx].paths[pi] : lp;
+          for (int r = 0; r < 4; ++r) {
+            rows_orig.push_back(pidx >= 0 ? p->w_off + (u0 + r) * p->mulo + pairs[pidx].w : -1);
+            rows_scale.push_back(pidx >= 0 ? p->fold : 0.f);
+          }
+        }
+    }
+  }
+  const int n_tiles = (int)rows_orig.size() / 16;
+  std::vector<float> w2q((size_t)n_tiles * KT * 64 * 4), b2q((size_t)n_tiles * 16);
+  for (int t = 0; t < n_tiles; ++t) {
+    for (int i = 0; i < 16; ++i) { const int ro = rows_orig[16 * t + i]; b2q[16 * t + i] = ro >= 0 ? rows_scale[16 * t + i] * B2[ro] : 0.f; }
+    for (int s4 = 0; s4 < KT; ++s4)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int ro = rows_orig[16 * t + (lane & 15)];
+        const float sc = rows_scale[16 * t + (lane & 15)];
+        for (int q = 0; q < 4; ++q)
+          w2q[(((size_t)t * KT + s4) * 64 + lane) * 4 + q] = ro >= 0 ? sc * W2[(size_t)ro * K + 16 * s4 + 4 * (lane >> 4) + q] : 0.f;
+      }
+  }
+  memset(o, 0, sizeof *o);
+  o->D_in = sp.D_in; o->D_out = sp.D_out; o->n_tiles = n_tiles; o->n_runs = (int)runs.size();
+  o->W1p = base.W1p; o->b1 = base.b1;
+  o->W2q = upload(m, w2q, &rc);
+  o->b2q = upload(m, b2q, &rc);
+  o->runs = upload(m, runs, &rc);
+  // contiguous group ranges of near-equal tile count for S = 1, 2, 4, 8
+  const int n_g = (int)groups.size();
+  int total_tiles = 0;
+  for (int t : group_tiles) total_tiles += t;
+  for (int si = 0; si < 4; ++si) {
+    const int S = 1 << si;
+    int gi = 0, acc = 0;
+    for (int p = 0; p < S; ++p) {
+      o->part_run[si][p] = gi < n_g ? group_run0[gi] : (int)runs.size();
+      const long target = (long)total_tiles * (p + 1) / S;
+      while (gi < n_g && (acc + group_tiles[gi] / 2 < target || p == S - 1)) { acc += group_tiles[gi]; ++gi; }
+    }
+    for (int p = S; p <= 8; ++p) o->part_run[si][p] = (int)runs.size();
+  }
+  return rc;
+}
+
 extern "C" int dbfr_abi_version(void) { return DBFR_ABI_VERSION; }
 extern "C" const char* dbfr_last_error(void) { return g_err.c_str(); }
 
@@ -382,13 +525,22 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   m->cfg = *cfg;
   m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
   m->streams_ready = false;
+  // which fused-conv kernel the K=144 convs use: k_conv2 (persistent, one launch per layer, tail split) wins while a layer
+  // is only a few rounds of workgroups (predict.py-sized batches), k_conv (conv.hip) at bench-sized batches.
+  // DBFR_CONV2 = 0 / 1 forces one of them, default -1 = by batch size
+  m->use_conv2 = getenv("DBFR_CONV2") ? atoi(getenv("DBFR_CONV2")) : -1;
   const char* fam[4] = {"lig_conv_layers", "cross_al_conv_layers", "atom_conv_layers", "cross_la_conv_layers"};
   for (int l = 0; l < cfg->num_conv_layers && !rc; ++l)
     for (int f = 0; f < 4 && !rc; ++f)
+    {
       rc = pack_conv(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), &m->layer[l][f]);
+      if (!rc) rc = pack_conv2(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer[l][f], &m->layer2[l][f]);
+    }
   if (!rc) rc = pack_conv(m, tm, "final_conv", 4, &m->final_conv);
   if (!rc) rc = pack_conv(m, tm, "tor_bond_conv", 5, &m->tor_conv);
+  if (!rc) rc = pack_conv2(m, tm, "tor_bond_conv", 5, m->tor_conv, &m->tor_conv2);
   if (!rc && !cfg->no_sc_torsion) rc = pack_conv(m, tm, "sc_tor_bond_conv", 5, &m->sc_conv);
+  if (!rc && !cfg->no_sc_torsion) rc = pack_conv2(m, tm, "sc_tor_bond_conv", 5, m->sc_conv, &m->sc_conv2);
   if (!rc) rc = pack_mlp(m, tm, "lig_node_embedding", cfg->lig_node_features + EMB, NS, NS, true, &m->lig_node_emb);
   if (!rc) rc = pack_mlp(m, tm, "lig_edge_embedding", cfg->lig_edge_features + 2 * EMB, NS, NS, true, &m->lig_edge_emb);
   if (!rc) rc = pack_mlp(m, tm, "atom_edge_embedding", 2 * EMB, NS, NS, true, &m->atom_edge_emb);
@@ -425,6 +577,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   }
   if (!rc) m->a14_group = upload(m, std::vector<int>(kAtom14ToGroup, kAtom14ToGroup + 21 * 14), &rc);
   if (!rc) { m->flops_dev = upload(m, std::vector<double>(2, 0.0), &rc); }
+  if (!rc) { m->queue = upload(m, std::vector<int>(4, 0), &rc); }
   if (rc) { dbfr_model_destroy(m); return rc; }
   *out = m;
   return DBFR_OK;
@@ -465,7 +618,7 @@ struct Ws {
   EdgeSet set[N_SETS];
   // centre set
   int *c_tgt, *c_gth, *c_row_start, *c_row_cnt, *c_n; float *c_dist, *c_sh, *c_emb;
-  float* msg[4]; int multi; float* gp; float *tor_attr, *sc_attr, *tor_feat, *sc_feat;
+  float* msg[4]; int multi; int conv2; float* gp; float *tor_attr, *sc_attr, *tor_feat, *sc_feat;
   int* n_edges6;  // [8] device counters
 };
 
@@ -515,6 +668,12 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   // launches of a few hundred workgroups still fill 256 CUs); large batches: one buffer, one stream
   static const long multi_edges = getenv("DBFR_MULTI_EDGES") ? atol(getenv("DBFR_MULTI_EDGES")) : 512 * 1024;
   w->multi = maxcap <= multi_edges;
+  w->conv2 = m->use_conv2 > 0 || (m->use_conv2 < 0 && w->multi);
+  if (w->conv2) {   // fused launches: every conv of a launch writes its own message buffer, sized by its own edge set
+    const long mc[4] = {std::max({caps[SET_LL], (long)NL, cap_t}), std::max(caps[SET_AL], cap_s), caps[SET_AA], caps[SET_LA]};
+    for (int i = 0; i < 4; ++i) w->msg[i] = b.take<float>((size_t)std::max(mc[i], 1L) * MAXD, i == 0 ? "msg" : nullptr);
+    w->multi = 0;
+  } else
   for (int i = 0; i < 4; ++i) w->msg[i] = (i == 0 || w->multi) ? b.take<float>((size_t)maxcap * MAXD, i == 0 ? "msg" : nullptr) : nullptr;
   w->gp = b.take<float>((size_t)G * 12, "gp");
   w->tor_attr = b.take<float>((size_t)(B->NTOR + 1) * NS, "tor_attr"); w->sc_attr = b.take<float>((size_t)(B->NSC + 1) * NS);
@@ -572,6 +731,38 @@ static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int ma
   }
 }
 
+static Conv2Desc conv2_desc(const ConvW2& cw, const int* n_edges, int max_edges, const int* gth, const float* emb, const float* sh,
+                            const float* tab1, int ld1, const int* idx1, const float* tab2, int ld2, const int* idx2, const float* x,
+                            int ldx, float* msg) {
+  Conv2Desc d;
+  d.n_edges = n_edges; d.max_edges = max_edges; d.gth = gth; d.emb = emb; d.sh = sh; d.tab1 = tab1; d.ld1 = ld1; d.idx1 = idx1;
+  d.tab2 = tab2; d.ld2 = ld2; d.idx2 = idx2; d.x = x; d.ldx = ldx; d.w = cw; d.msg = msg;
+  return d;
+}
+
+// one fused k_conv2 launch over up to four K=144 convs (an interaction layer, or the two torsion heads)
+static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int n, hipStream_t st) {
+  Conv2Args a;
+  memset(&a, 0, sizeof a);
+  for (int i = 0; i < n; ++i) a.c[i] = descs[i];
+  a.n_conv = n; a.queue = m->queue;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (m->profile == 1) {
+    if (m->ev_used + 2 > m->ev.size()) {
+      size_t old = m->ev.size();
+      m->ev.resize(old + 512);
+      for (size_t i = old; i < m->ev.size(); ++i) (void)hipEventCreate(&m->ev[i]);
+    }
+    e0 = m->ev[m->ev_used++]; e1 = m->ev[m->ev_used++];
+    (void)hipEventRecord(e0, st);
+  }
+  launch_conv2(a, st);
+  if (m->profile == 1) (void)hipEventRecord(e1, st);
+  if (m->profile)
+    for (int i = 0; i < n; ++i)
+      launch_acc_flops(descs[i].n_edges, 2.0 * 144 * (144.0 + Ws[i]), 4.0 * (Ws[i] + descs[i].w.D_in + 9) + 16.0, m->flops_dev, st);
+}
+
 static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, const dbfr_scores* out, Ws& w,
                      hipStream_t st, int step = 0) {
   const dbfr_model_cfg& cfg = m->cfg;
@@ -619,7 +810,20 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
     float *lnew = w.lig_x[cur ^ 1], *anew = w.atom_x[cur ^ 1];
     const EdgeSet &LL = w.set[SET_LL], &AA = w.set[SET_AA], &AL = w.set[SET_AL], &LA = w.set[SET_LA];
-    if (!w.multi || m->profile == 1) {   // profiling times each conv alone on the main stream
+    if (w.conv2) {   // all four convs of the layer in ONE persistent launch (conv2.hip)
+      const Conv2Desc ds[4] = {
+          conv2_desc(m->layer2[l][0], LL.n_edges, LL.cap, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0]),
+          conv2_desc(m->layer2[l][1], AL.n_edges, AL.cap, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[1]),
+          conv2_desc(m->layer2[l][2], AA.n_edges, AA.cap, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg[2]),
+          conv2_desc(m->layer2[l][3], LA.n_edges, LA.cap, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3])};
+      const int Ws[4] = {m->layer[l][0].W, m->layer[l][1].W, m->layer[l][2].W, m->layer[l][3].W};
+      conv2_call(m, ds, Ws, 4, st);
+      ReduceLayerArgs ra;
+      const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
+      for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
+      ra.NL = NL; ra.NA = NA; ra.D = Do; ra.D_old = Di; ra.old_l = lx; ra.old_a = ax; ra.out_l = lnew; ra.out_a = anew;
+      launch_reduce_ln_layer(ra, st);
+    } else if (!w.multi || m->profile == 1) {   // profiling times each conv alone on the main stream
       conv_call(m, m->layer[l][0], LL.n_edges, LL.cap, LL.tgt, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0], st);
       launch_reduce_ln(w.msg[0], LL.row_start, LL.row_cnt, NL, Do, m->layer[l][0].ln, lx, Di, lnew, Do, 0, st);
       conv_call(m, m->layer[l][1], AL.n_edges, AL.cap, AL.tgt, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[0], st);
@@ -656,7 +860,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   if (D != MAXD) return fail(DBFR_ERR_ARG, "heads need num_conv_layers >= 3");
   const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
   // ---- the three heads are independent: in the small-batch (multi-stream) regime the two torsion heads run on side streams
-  const bool fork_heads = w.multi && m->profile != 1;
+  const bool fork_heads = w.multi && m->profile != 1 && !w.conv2;
   hipStream_t s_tor = fork_heads ? m->side[0] : st, s_sc = fork_heads ? m->side[1] : st;
   float* msg_tor = fork_heads ? w.msg[1] : w.msg[0];
   float* msg_sc = fork_heads ? w.msg[2] : w.msg[0];
@@ -680,6 +884,40 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     a.tr = m->tr_final; a.rot = m->rot_final; a.G = G; a.scale_by_sigma = cfg.scale_by_sigma; a.tr_out = out->tr;
     a.rot_out = out->rot; a.err = w.err;
     launch_trrot(a, st);
+  }
+  if (w.conv2) {   // both torsion heads: embeddings, ONE fused k_conv2 launch, reductions, final MLPs
+    const EdgeSet& T = w.set[SET_TOR];
+    const EdgeSet& S = w.set[SET_SC];
+    const bool do_t = B->NTOR > 0, do_s = !cfg.no_sc_torsion && B->NSC > 0;
+    Conv2Desc ds[2]; int Ws[2]; int nd = 0;
+    if (do_t) {
+      launch_bond_attr(lx, D, B->bond_src, B->bond_dst, B->tor_bond, 0, B->NTOR, w.tor_attr, st);
+      MlpArgs a; memset(&a, 0, sizeof a);
+      a.w = m->tor_edge_emb; a.mode = IN_G; a.n_rows_dev = T.n_edges; a.n_rows_max = T.cap; a.dist = T.dist;
+      a.gs_offset = m->gs_lig_off; a.gs_coeff = m->gs_lig_c; a.out = T.emb;
+      launch_mlp(a, st);
+      ds[nd] = conv2_desc(m->tor_conv2, T.n_edges, T.cap, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg[0]);
+      Ws[nd++] = m->tor_conv.W;
+    }
+    if (do_s) {
+      launch_bond_attr(ax, D, B->sc_bond, nullptr, nullptr, 2, B->NSC, w.sc_attr, st);
+      MlpArgs a; memset(&a, 0, sizeof a);
+      a.w = m->sc_edge_emb; a.mode = IN_G; a.n_rows_dev = S.n_edges; a.n_rows_max = S.cap; a.dist = S.dist;
+      a.gs_offset = m->gs_atom_off; a.gs_coeff = m->gs_atom_c; a.out = S.emb;
+      launch_mlp(a, st);
+      ds[nd] = conv2_desc(m->sc_conv2, S.n_edges, S.cap, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg[1]);
+      Ws[nd++] = m->sc_conv.W;
+    }
+    if (nd) conv2_call(m, ds, Ws, nd, st);
+    if (do_t) {
+      launch_reduce_ln(w.msg[0], T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
+      launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, st);
+    }
+    if (do_s) {
+      launch_reduce_ln(w.msg[1], S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, st);
+      launch_tor_final(w.sc_feat, m->sc_final, c->sc_tor_score_norm2, cfg.scale_by_sigma, B->NSC, out->sc_tor, st);
+    }
+    return DBFR_OK;
   }
   // ---- ligand torsion head
   if (B->NTOR > 0) {
@@ -739,6 +977,7 @@ static int begin(dbfr_model* m, const dbfr_batch* B, void* workspace, size_t wby
     m->streams_ready = true;
   }
   HIPCHECK(hipMemsetAsync(workspace, 0, 1024, st));   // err @0, counters @256, n_edges6 @512
+  if (w->conv2) HIPCHECK(hipMemsetAsync(m->queue, 0, 16, st));   // the kernel re-arms it itself; this covers an aborted run
   launch_set_int(w->n_edges6 + 7, B->NL, st);           // the centre set has exactly one edge per ligand atom
   launch_batch_vectors(*B, w->lig_batch, w->atm_batch, w->is_cab, w->n_cab, w->tor_batch, w->sc_batch, st);
   return DBFR_OK;
@@ -933,17 +1172,40 @@ static const ConvW* pick_conv(const dbfr_model* m, int layer, int family) {
   return nullptr;
 }
 
+static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,
+                          const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh, const float* tab1, int32_t ld1,
+                          const int32_t* idx1, const float* tab2, int32_t ld2, const int32_t* idx2, const float* x, int32_t ldx,
+                          float* msg, void* hip_stream) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  const ConvW* cw = pick_conv(m, layer, family);
+  if (!cw) return fail(DBFR_ERR_ARG, "no such conv");
+  if (conv2) {
+    if (cw->K != 144) return fail(DBFR_ERR_ARG, "k_conv2 serves the K=144 convs");
+    const ConvW2* cw2 = layer >= 0 ? &m->layer2[layer][family] : layer == -2 ? &m->tor_conv2 : &m->sc_conv2;
+    const Conv2Desc d = conv2_desc(*cw2, n_edges_dev, n_edges, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg);
+    const int W = cw->W;
+    conv2_call(m, &d, &W, 1, (hipStream_t)hip_stream);
+  } else {
+    conv_call(m, *cw, n_edges_dev, n_edges, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg, (hipStream_t)hip_stream);
+  }
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
+}
+
 extern "C" int dbfr_test_conv(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,
                               const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh,
                               const float* tab1, int32_t ld1, const int32_t* idx1, const float* tab2, int32_t ld2,
                               const int32_t* idx2, const float* x, int32_t ldx, float* msg, void* hip_stream) {
-  if (!m) return fail(DBFR_ERR_ARG, "null model");
-  const ConvW* cw = pick_conv(m, layer, family);
-  if (!cw) return fail(DBFR_ERR_ARG, "no such conv");
-  conv_call(m, *cw, n_edges_dev, n_edges, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg,
-            (hipStream_t)hip_stream);
-  HIPCHECK(hipGetLastError());
-  return DBFR_OK;
+  return test_conv_impl(m, false, layer, family, n_edges, n_edges_dev, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx,
+                        msg, hip_stream);
+}
+
+extern "C" int dbfr_test_conv2(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,
+                               const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh,
+                               const float* tab1, int32_t ld1, const int32_t* idx1, const float* tab2, int32_t ld2,
+                               const int32_t* idx2, const float* x, int32_t ldx, float* msg, void* hip_stream) {
+  return test_conv_impl(m, true, layer, family, n_edges, n_edges_dev, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx,
+                        msg, hip_stream);
 }
 
 extern "C" int dbfr_test_reduce_ln(dbfr_model* m, int32_t layer, int32_t family, const float* msg,

@@ -70,6 +70,38 @@ struct ConvW {             // one TensorProductConvLayer, device resident
   LNDesc ln;
 };
 
+// Second-generation layout of the same conv for k_conv2 (conv2.hip): ONE tile sequence walked by every wave, channel
+// groups of the outputs 0e / 1o first, then those of 1e / 0o (they read the 48x0o inputs through the LDS slot the 48x0e
+// inputs occupied); contiguous group ranges = "parts" for the tail split.
+struct ConvW2 {
+  int D_in, D_out, n_tiles, n_runs;
+  const float* W1p;   // shared with ConvW
+  const float* b1;
+  const float* W2q;   // [n_tiles][K/16][64][4]
+  const float* b2q;   // [n_tiles*16]
+  const RunDesc* runs;    // meta bit 20: run reads the second x layout; x offsets already mapped to the LDS row
+  int part_run[4][9];     // part_run[si][p] = first run of part p when the conv is cut into 1 << si parts
+};
+
+struct Conv2Desc {         // one conv of a fused k_conv2 launch
+  const int* n_edges; int max_edges;
+  const int* gth;
+  const float* emb;       // [E][NS]
+  const float* sh;        // [E][SH_LD]
+  const float* tab1; int ld1; const int* idx1;
+  const float* tab2; int ld2; const int* idx2;
+  const float* x; int ldx;
+  ConvW2 w;
+  float* msg;             // [E][D_out]
+};
+
+struct Conv2Args {
+  Conv2Desc c[4];
+  int n_conv;
+  int* queue;             // [2] device ints, zero at launch: next unit, workgroups done (re-armed by the last one)
+  int run_barrier, no_split;   // developer knobs (launch_conv2)
+};
+
 struct Mlp2 {              // SimpleLinear: Linear(in,hid) -> act -> Linear(hid,out)
   int in, hid, out;
   const float* w0t;   // [in][hid]   (transposed for coalesced/bank-friendly reads)

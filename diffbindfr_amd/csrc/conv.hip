@@ -490,3 +490,91 @@ void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt
   hipLaunchKernelGGL(k_reduce_ln, dim3((N + 3) / 4), dim3(256), 0, st, msg, row_start, row_cnt, N, D, ln, old, D_old,
                      out, ldo, mode);
 }
+
+// ------------------------------------------------------------------------------------------------
+// The four reductions of an interaction layer in ONE launch (used behind the fused k_conv2 layer launch, where every
+// conv has its own message buffer): per ligand node  out = (pad(old) + LN_ll(mean ll)) + LN_al(mean al), per pocket atom
+// out = (pad(old) + LN_aa(mean aa)) + LN_la(mean la) -- the very operation order of the mode 0 / mode 1 launch pair.
+struct ReduceLayerArgs {
+  const float* msg[4]; const int* row_start[4]; const int* row_cnt[4]; LNDesc ln[4];   // ll, al, aa, la
+  int NL, NA, D, D_old;
+  const float* old_l; const float* old_a; float* out_l; float* out_a;
+};
+
+__device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, int rc, int D, const LNDesc& ln, float* bw, int lane) {
+  const int d4 = D >> 2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (lane < d4) {
+    const f32x4* r = reinterpret_cast<const f32x4*>(msg + (size_t)rs * D) + lane;
+    int e = 0;
+    for (; e + 4 <= rc; e += 4) {
+      const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; e < rc; ++e) acc += r[(size_t)e * d4];
+    const float cntf = (float)max(rc, 1);
+    bw[4 * lane] = acc[0] / cntf; bw[4 * lane + 1] = acc[1] / cntf; bw[4 * lane + 2] = acc[2] / cntf; bw[4 * lane + 3] = acc[3] / cntf;
+  }
+  __builtin_amdgcn_wave_barrier();
+  int iw = 0, ib = 0;
+  for (int bk = 0; bk < ln.nblk; ++bk) {
+    const int mul = ln.mul[bk], dim = ln.dim[bk], off = ln.off[bk];
+    const int nel = mul * dim;
+    float mean[3] = {0.f, 0.f, 0.f};
+    for (int i = lane; i < nel; i += 64) {
+      int comp = i % dim;
+      float v = bw[off + i];
+      if (comp == 0) mean[0] += v; else if (comp == 1) mean[1] += v; else mean[2] += v;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      for (int o = 32; o > 0; o >>= 1) mean[c] += __shfl_xor(mean[c], o);
+      mean[c] /= (float)mul;
+    }
+    float sq = 0.f;
+    for (int i = lane; i < nel; i += 64) {
+      int u = i / dim, comp = i - u * dim;
+      float v = bw[off + i] - (comp == 0 ? mean[0] : comp == 1 ? mean[1] : mean[2]) * ln.mean_shift[iw + u];
+      bw[off + i] = v;
+      sq += v * v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float inv = 1.0f / sqrtf(sq / (float)nel + 1e-5f);
+    for (int i = lane; i < nel; i += 64) {
+      int u = i / dim;
+      float v = bw[off + i] * (inv * ln.weight[iw + u]);
+      if (ln.is0e[bk]) v += ln.bias[ib + u];
+      bw[off + i] = v;
+    }
+    iw += mul;
+    if (ln.is0e[bk]) ib += mul;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void k_reduce_ln_layer(ReduceLayerArgs a) {
+  __shared__ float buf[4][2][MAXD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbl = (a.NL + 3) / 4;
+  const bool lig = (int)blockIdx.x < nbl;
+  const int node = (lig ? blockIdx.x : blockIdx.x - nbl) * 4 + wave;
+  const int N = lig ? a.NL : a.NA;
+  if (node >= N) return;                         // waves are independent here (wave-level barriers only)
+  const int s0 = lig ? 0 : 2;
+  mean_ln(a.msg[s0], a.row_start[s0][node], a.row_cnt[s0][node], a.D, a.ln[s0], buf[wave][0], lane);
+  mean_ln(a.msg[s0 + 1], a.row_start[s0 + 1][node], a.row_cnt[s0 + 1][node], a.D, a.ln[s0 + 1], buf[wave][1], lane);
+  const float* old = (lig ? a.old_l : a.old_a) + (size_t)node * a.D_old;
+  float* out = (lig ? a.out_l : a.out_a) + (size_t)node * a.D;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = lane + 64 * j;
+    if (c < a.D) out[c] = ((c < a.D_old ? old[c] : 0.f) + buf[wave][0][c]) + buf[wave][1][c];
+  }
+}
+
+void launch_reduce_ln_layer(const ReduceLayerArgs& a, hipStream_t st) {
+  const int nb = (a.NL + 3) / 4 + (a.NA + 3) / 4;
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(k_reduce_ln_layer, dim3(nb), dim3(256), 0, st, a);
+}

@@ -85,7 +85,7 @@ class PdbTopology(C.Structure):
 SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
            "dbfr_sample_range", "dbfr_capacity_report",
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
-           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_reduce_ln",
+           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
            "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket"]
 
 _lib = None
@@ -127,6 +127,7 @@ def load():
     lib.dbfr_workspace_layout.argtypes = [vp, C.POINTER(Batch), C.POINTER(Limits), C.c_char_p, C.c_size_t,
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i32]
     lib.dbfr_test_conv.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp]
+    lib.dbfr_test_conv2.argtypes = lib.dbfr_test_conv.argtypes
     lib.dbfr_test_reduce_ln.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp]
     lib.dbfr_select_pocket.argtypes = [i32, i32, vp, i32, vp, vp, vp, vp, C.c_double, i32, vp, vp, vp]
     lib.dbfr_pose_metrics.argtypes = [C.POINTER(PoseMetricsIn), C.POINTER(PoseMetricsOut), vp]

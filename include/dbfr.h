@@ -352,6 +352,11 @@ int dbfr_test_conv(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges
                    const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh, const float* tab1,
                    int32_t ld1, const int32_t* idx1, const float* tab2, int32_t ld2, const int32_t* idx2,
                    const float* x, int32_t ldx, float* msg, void* hip_stream);
+/* The same conv through the second-generation kernel k_conv2 (persistent, one W2 stream per CU; K=144 convs only).    */
+int dbfr_test_conv2(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,
+                    const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh, const float* tab1,
+                    int32_t ld1, const int32_t* idx1, const float* tab2, int32_t ld2, const int32_t* idx2,
+                    const float* x, int32_t ldx, float* msg, void* hip_stream);
 int dbfr_test_reduce_ln(dbfr_model* m, int32_t layer, int32_t family, const float* msg, const int32_t* row_start,
                         const int32_t* row_cnt, int32_t n_nodes, const float* old, int32_t d_old, float* out,
                         int32_t mode, void* hip_stream);

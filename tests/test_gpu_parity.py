@@ -252,7 +252,10 @@ def test_graph_permutation_invariance(setup, dev):
 @pytest.mark.parametrize("layer,fam,name", [(0, 0, "lig_conv_layers.0"), (1, 2, "atom_conv_layers.1"),
                                             (2, 1, "cross_al_conv_layers.2"), (5, 3, "cross_la_conv_layers.5"),
                                             (-1, 0, "final_conv"), (-2, 0, "tor_bond_conv"), (-3, 0, "sc_tor_bond_conv")])
-def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name):
+@pytest.mark.parametrize("kernel", ["k_conv", "k_conv2"])
+def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name, kernel):
+    if kernel == "k_conv2" and layer == -1:
+        pytest.skip("final_conv (K=96) runs on k_conv only")
     mcfg, p, model = setup
     lib, h = L.load(), model.handle(dev)
     g = torch.Generator().manual_seed(5 + abs(layer))
@@ -278,7 +281,7 @@ def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name):
     xd, xtd, embd, shd, tgtd, gthd, ned, msg = keep
     ptr = lambda t: C.c_void_p(t.data_ptr())
     if nef == 144:
-        rc = lib.dbfr_test_conv(h, layer, fam, E, ptr(ned), ptr(tgtd), ptr(gthd), ptr(embd), ptr(shd), ptr(xtd),
+        rc = (lib.dbfr_test_conv2 if kernel == "k_conv2" else lib.dbfr_test_conv)(h, layer, fam, E, ptr(ned), ptr(tgtd), ptr(gthd), ptr(embd), ptr(shd), ptr(xtd),
                                 xtd.shape[1], ptr(tgtd), ptr(xd), Din, ptr(gthd), ptr(xd), Din, ptr(msg), None)
     else:
         rc = lib.dbfr_test_conv(h, layer, fam, E, ptr(ned), ptr(tgtd), ptr(gthd), ptr(embd), ptr(shd), ptr(xd), Din,
@@ -429,3 +432,31 @@ def test_pocket_larger_than_the_old_2048_atom_limit(setup, dev):
     assert int(d.rec_atm_pos.shape[0]) > 2048
     errs = _oracle_vs_hip_scores(setup, dev, d)
     assert max(errs) < SCORE_RTOL, errs
+
+
+@pytest.mark.parametrize("layer,fam,E", [(3, 2, 70000), (0, 0, 5000), (4, 1, 1234), (-2, 0, 20000)])
+def test_k_conv2_equals_k_conv_bitwise(setup, dev, layer, fam, E):
+    """The two fused-conv kernels on the same random edges: k_conv2 (persistent, edge-owner waves, tail blocks split along
+    the output channels into 8 / 4 / 2 parts, whole blocks when there are more than 256) must give the very bits of k_conv:
+    both keep the channel-owner summation order."""
+    mcfg, p, model = setup
+    lib, h = L.load(), model.handle(dev)
+    Din = [48, 84, 120, 168][min(layer, 3)] if layer >= 0 else 168
+    Dout = [84, 120, 168, 168][min(layer, 3)] if layer >= 0 else 96
+    g = torch.Generator(device=dev).manual_seed(100 + E)
+    N = max(E // 9, 8)
+    x, xt = torch.randn(N, Din, device=dev, generator=g), torch.randn(N, max(Din, 48), device=dev, generator=g)
+    tgt = torch.sort(torch.randint(0, N, (E,), device=dev, generator=g)).values.to(torch.int32)
+    gth = torch.randint(0, N, (E,), device=dev, generator=g).to(torch.int32)
+    emb, sh = torch.randn(E, 48, device=dev, generator=g), torch.randn(E, 9, device=dev, generator=g)
+    ne = torch.tensor([E], dtype=torch.int32, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    outs = []
+    for fn in (lib.dbfr_test_conv, lib.dbfr_test_conv2):
+        msg = torch.full((E, Dout), float("nan"), device=dev)
+        L.check(fn(h, layer, fam, E, ptr(ne), ptr(tgt), ptr(gth), ptr(emb), ptr(sh), ptr(xt), xt.shape[1], ptr(tgt), ptr(x), Din,
+                   ptr(gth), ptr(x), Din, ptr(msg), None))
+        torch.cuda.synchronize()
+        outs.append(msg)
+    assert torch.isfinite(outs[1]).all()                     # every message element was written exactly by its owner
+    assert torch.equal(outs[0], outs[1])
