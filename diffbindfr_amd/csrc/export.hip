@@ -545,3 +545,85 @@ extern "C" int dbfr_pdb_write_files(const dbfr_pdb_topology* topo, int32_t n_row
     return DBFR_ERR_ARG;
   }
 }
+
+
+// ------------------------------------------------------------------------------------------------ ligand SD files
+// lig_final.sdf of every pose (DiffBindFR/evaluation/export.py:97-103,236-244: Ligand3D.pos_update + Chem.SDWriter): the
+// ligand's V2000 mol block with the pose's coordinates in the atom lines.  Everything that is not a coordinate (header,
+// the rest of each atom line, bond block, property block, data items) is text prepared once per ligand on the host
+// (diffbindfr_amd/ligand.py: SdfTemplate); here only the 30 coordinate columns are formatted.  Host code, all pointers host.
+static int check_sdf(const dbfr_sdf_template* t, const float* pos) {
+  if (!t || !pos || t->n_atoms < 0 || !t->header || !t->trailer || (t->n_atoms > 0 && !t->atom_tail)) {
+    dbfr_set_error("null argument (sdf template)");
+    return DBFR_ERR_ARG;
+  }
+  for (int i = 0; i < t->n_atoms; ++i)
+    if (!t->atom_tail[i]) { dbfr_set_error("null atom line (sdf template)"); return DBFR_ERR_ARG; }
+  return DBFR_OK;
+}
+
+static void format_sdf(const dbfr_sdf_template& t, const float* pos, std::string& s) {
+  s.clear();
+  s += t.header;
+  char buf[64];
+  for (int i = 0; i < t.n_atoms; ++i) {
+    // V2000 atom line: xxxxx.xxxxyyyyy.yyyyzzzzz.zzzz then " aaa dd ..." (CTfile spec; RDKit prints %10.4f as well)
+    snprintf(buf, sizeof buf, "%10.4f%10.4f%10.4f", (double)pos[3 * i], (double)pos[3 * i + 1], (double)pos[3 * i + 2]);
+    s += buf;
+    s += t.atom_tail[i];
+    s += '\n';
+  }
+  s += t.trailer;
+}
+
+extern "C" int64_t dbfr_sdf_format(const dbfr_sdf_template* t, const float* pos, char* out, int64_t cap) {
+  try {
+    if (check_sdf(t, pos)) return DBFR_ERR_ARG;
+    std::string s;
+    format_sdf(*t, pos, s);
+    if (out && cap >= (int64_t)s.size()) memcpy(out, s.data(), s.size());
+    return (int64_t)s.size();
+  } catch (const std::exception& e) {
+    dbfr_set_error(std::string("dbfr_sdf_format: ") + e.what());
+    return DBFR_ERR_ARG;
+  }
+}
+
+extern "C" int dbfr_sdf_write_files(const dbfr_sdf_template* t, const float* pos, int32_t n_pose, const char* const* paths,
+                                    int32_t n_threads) {
+  try {
+    if (check_sdf(t, pos)) return DBFR_ERR_ARG;
+    if (n_pose < 0 || (n_pose > 0 && !paths)) { dbfr_set_error("paths missing"); return DBFR_ERR_ARG; }
+    if (n_pose == 0) return DBFR_OK;
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    int nt = n_threads > 0 ? n_threads : std::min(hw, (int)n_pose);
+    nt = std::max(1, std::min(nt, (int)n_pose));
+    std::atomic<int> next(0), failed(-1);
+    auto work = [&]() noexcept {
+      try {
+        std::string s;
+        for (;;) {
+          int i = next.fetch_add(1);
+          if (i >= n_pose) break;
+          format_sdf(*t, pos + (size_t)i * t->n_atoms * 3, s);
+          FILE* f = fopen(paths[i], "wb");
+          bool ok = f && fwrite(s.data(), 1, s.size(), f) == s.size();
+          if (f) ok = (fclose(f) == 0) && ok;
+          if (!ok) { int e = -1; failed.compare_exchange_strong(e, i); }
+        }
+      } catch (...) { int e = -1; failed.compare_exchange_strong(e, 0); }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nt; ++k) {
+      try { th.emplace_back(work); } catch (...) { break; }
+    }
+    work();
+    for (auto& x : th) x.join();
+    if (failed.load() >= 0) { dbfr_set_error(std::string("cannot write ") + paths[failed.load()]); return DBFR_ERR_ARG; }
+    return DBFR_OK;
+  } catch (const std::exception& e) {
+    dbfr_set_error(std::string("dbfr_sdf_write_files: ") + e.what());
+    return DBFR_ERR_ARG;
+  }
+}

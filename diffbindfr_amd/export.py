@@ -157,6 +157,7 @@ class ComplexOutput:
     aatype: np.ndarray                        # proteinmeta.pocket.aatype
     row: Optional[dict] = None                # the pair_frame row copied onto every pose (export.py:143-148)
     heavy_mask: Optional[np.ndarray] = None
+    sdf_template: Optional[object] = None     # ligand.SdfTemplate of the input SD record -> lig_final.sdf per pose
 
 
 def rmsd_to_str(rmsd):
@@ -171,7 +172,8 @@ def complex_modeling(entries, export_dir=None, calc_metrics=False, lrmsd_naming=
     ``pkt_final.pdb``), same frame columns (``centroid``, ``chi1_15``, ``sc-rmsd``, ``l-rmsd``, ``sample_id``, ``docked_lig``,
     ``protein_pdb``) and the same ``arr_df`` dict.  Differences: the metrics of all poses come from one device launch per complex;
     ``l-rmsd`` is the heavy-atom RMSD minimised over the graph automorphisms (the reference asks RDKit for the symmetry
-    classes); ``lig_final.sdf`` is written by ``ligand_writer(entry, pose_index, final_pos[N_l,3], path)`` if given (RDKit's
+    classes); ``lig_final.sdf`` is written from the entry's ``sdf_template`` (``ligand.SdfTemplate``: the input mol block with
+    the pose's coordinates, library threads) or by ``ligand_writer(entry, pose_index, final_pos[N_l,3], path)`` if given (RDKit's
     SDWriter in the reference); the trajectory flags (``export_fullp_traj`` / ``export_pkt_traj``: ligand HETATM records + XTC)
     are not supported."""
     import pandas as pd
@@ -219,7 +221,10 @@ def complex_modeling(entries, export_dir=None, calc_metrics=False, lrmsd_naming=
             e.topology.write_poses(final_prot, [os.path.join(d, "prot_final.pdb") for d in dirs], threads=threads)
         if pkt:
             e.topology.pocket().write_poses(final_prot, [os.path.join(d, "pkt_final.pdb") for d in dirs], threads=threads)
-        final_lig = (e.ligand_traj[:, -1] + center.to(e.ligand_traj.device)).cpu().numpy() if ligand_writer is not None else None
+        want_lig = ligand_writer is not None or e.sdf_template is not None
+        final_lig = (e.ligand_traj[:, -1] + center.to(e.ligand_traj.device)).cpu().numpy() if want_lig else None
+        if ligand_writer is None and e.sdf_template is not None:      # all poses of the complex in one library call
+            e.sdf_template.write_poses(final_lig, [os.path.join(d, "lig_final.sdf") for d in dirs], threads=threads)
         for i, d in enumerate(dirs):
             pd_df["sample_id"].append(ids[i])
             sdf = os.path.join(d, "lig_final.sdf")

@@ -75,6 +75,10 @@ class PoseMetricsOut(C.Structure):
                 ("lig_rmsd", C.c_void_p)]
 
 
+class SdfTemplate(C.Structure):
+    _fields_ = [("n_atoms", C.c_int32), ("header", C.c_char_p), ("atom_tail", C.POINTER(C.c_char_p)), ("trailer", C.c_char_p)]
+
+
 class PdbTopology(C.Structure):
     _fields_ = [("n_res", C.c_int32), ("aatype", C.c_void_p), ("atom37_pos", C.c_void_p), ("atom37_mask", C.c_void_p),
                 ("residue_index", C.c_void_p), ("chain_index", C.c_void_p), ("b_factors", C.c_void_p),
@@ -86,7 +90,8 @@ SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "d
            "dbfr_sample_range", "dbfr_capacity_report",
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
            "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
-           "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket"]
+           "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket", "dbfr_sdf_format",
+           "dbfr_sdf_write_files"]
 
 _lib = None
 
@@ -134,6 +139,9 @@ def load():
     lib.dbfr_pdb_format.argtypes = [C.POINTER(PdbTopology), i32, vp, vp, i32, i32, vp, C.c_int64]
     lib.dbfr_pdb_format.restype = C.c_int64
     lib.dbfr_pdb_write_files.argtypes = [C.POINTER(PdbTopology), i32, vp, vp, i32, C.POINTER(C.c_char_p), i32]
+    lib.dbfr_sdf_format.argtypes = [C.POINTER(SdfTemplate), vp, vp, C.c_int64]
+    lib.dbfr_sdf_format.restype = C.c_int64
+    lib.dbfr_sdf_write_files.argtypes = [C.POINTER(SdfTemplate), vp, i32, C.POINTER(C.c_char_p), i32]
     if lib.dbfr_abi_version() != 1:
         raise DbfrError("libdbfr ABI version mismatch")
     _lib = lib

@@ -119,3 +119,88 @@ def automorphisms(node_labels, edge_index, edge_labels=None, limit=100000):
     finally:
         sys.setrecursionlimit(old)
     return np.asarray(out, np.int32).reshape(len(out), n)
+
+
+class SdfTemplate:
+    """The constant text of a ligand's V2000 mol block, prepared once per ligand so that every pose's ``lig_final.sdf``
+    (DiffBindFR/evaluation/export.py:236-244) is a coordinate substitution (``dbfr_sdf_write_files``, library threads).
+
+    ``from_molblock`` takes the ligand's input SD record and, like the reference's loader (RDKit ``RemoveHs``: the model
+    ligand holds heavy atoms only), drops explicit hydrogens: atoms renumbered, bonds to hydrogens removed, the atom lists
+    of ``M  CHG`` / ``M  ISO`` / ``M  RAD`` lines remapped.  Atom order = the order the sampler's poses use (heavy atoms in
+    file order).  Byte parity with RDKit's ``SDWriter`` is not pinned offline (RDKit absent)."""
+
+    def __init__(self, header, atom_tails, trailer):
+        self.header, self.atom_tails, self.trailer = header, list(atom_tails), trailer
+        self.n_atoms = len(self.atom_tails)
+
+    @classmethod
+    def from_molblock(cls, text, remove_hs=True, program="DBFR-HIP"):
+        lines = text.replace("\r\n", "\n").split("\n")
+        if len(lines) < 4 or "V2000" not in lines[3]:
+            raise ValueError("not a V2000 mol block")
+        na, nb = int(lines[3][0:3]), int(lines[3][3:6])
+        atoms, bonds = lines[4:4 + na], lines[4 + na:4 + na + nb]
+        rest = lines[4 + na + nb:]
+        sym = [a[31:34].strip() for a in atoms]
+        keep = [i for i in range(na) if not (remove_hs and sym[i] == "H")]
+        ren = {old: new + 1 for new, old in enumerate(keep)}                    # 0-based old -> 1-based new
+        out_bonds = []
+        for b in bonds:
+            i, j = int(b[0:3]) - 1, int(b[3:6]) - 1
+            if i in ren and j in ren:
+                out_bonds.append(f"{ren[i]:3d}{ren[j]:3d}{b[6:]}")
+        props = []
+        for l in rest:
+            if l[:6] in ("M  CHG", "M  ISO", "M  RAD"):
+                n = int(l[6:9])
+                ent = [(int(l[9 + 8 * k:13 + 8 * k]) - 1, l[13 + 8 * k:17 + 8 * k]) for k in range(n)]
+                ent = [(ren[a], v) for a, v in ent if a in ren]
+                if ent:
+                    props.append(f"{l[:6]}{len(ent):3d}" + "".join(f"{a:4d}{v}" for a, v in ent))
+            else:
+                props.append(l)
+        while props and props[-1] == "":
+            props.pop()
+        if "M  END" not in props:
+            props.insert(0, "M  END")
+        if not props or props[-1] != "$$$$":
+            props.append("$$$$")
+        counts = f"{len(keep):3d}{len(out_bonds):3d}{lines[3][6:]}"
+        header = "\n".join([lines[0], f"  {program:<8s}          3D", lines[2], counts]) + "\n"
+        trailer = "\n".join(out_bonds + props) + "\n"
+        return cls(header, [atoms[i][30:] for i in keep], trailer)
+
+    def _c(self):
+        from . import lib as L
+        import ctypes as C
+        self._keep = [t.encode() for t in self.atom_tails]
+        arr = (C.c_char_p * max(self.n_atoms, 1))(*self._keep)
+        self._arr = arr
+        return L.SdfTemplate(self.n_atoms, self.header.encode(), arr, self.trailer.encode())
+
+    def format(self, pos):
+        """Text of one pose (pos [n_atoms,3])."""
+        from . import lib as L
+        import ctypes as C
+        lib = L.load()
+        a = np.ascontiguousarray(np.asarray(pos, np.float32).reshape(self.n_atoms, 3))
+        t = self._c()
+        need = lib.dbfr_sdf_format(C.byref(t), a.ctypes.data_as(C.c_void_p), None, 0)
+        if need < 0:
+            L.check(int(need))
+        buf = C.create_string_buffer(int(need))
+        lib.dbfr_sdf_format(C.byref(t), a.ctypes.data_as(C.c_void_p), buf, need)
+        return buf.raw.decode()
+
+    def write_poses(self, pos, paths, threads=0):
+        """pos [n_pose, n_atoms, 3] -> paths[i], on library threads."""
+        from . import lib as L
+        import ctypes as C
+        lib = L.load()
+        a = np.ascontiguousarray(np.asarray(pos, np.float32))
+        if a.ndim != 3 or a.shape[1:] != (self.n_atoms, 3) or a.shape[0] != len(paths):
+            raise L.DbfrError(f"pose array {a.shape} for {len(paths)} paths of a {self.n_atoms}-atom ligand")
+        t = self._c()
+        arr = (C.c_char_p * len(paths))(*[str(x).encode() for x in paths])
+        L.check(lib.dbfr_sdf_write_files(C.byref(t), a.ctypes.data_as(C.c_void_p), len(paths), arr, int(threads)))

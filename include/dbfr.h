@@ -312,6 +312,24 @@ int64_t dbfr_pdb_format(const dbfr_pdb_topology* topo, int32_t n_rows, const int
 int dbfr_pdb_write_files(const dbfr_pdb_topology* topo, int32_t n_rows, const int32_t* rows, const float* pos14,
                          int32_t n_pose, const char* const* paths, int32_t n_threads);
 
+/* SD file of a ligand pose (host code, all pointers host): what the reference writes per pose as `lig_final.sdf`
+ * (DiffBindFR/evaluation/export.py:97-103,236-244: Ligand3D.pos_update(pose) -> Chem.SDWriter).  The V2000 mol block of
+ * the (hydrogen-free) ligand is prepared once as text; per pose only the coordinate columns change.
+ * Byte parity with RDKit's SDWriter is NOT pinned (RDKit is absent offline): the block follows the CTfile V2000 layout
+ * RDKit reads and writes (%10.4f coordinates), header program line "DBFR-HIP".                                        */
+typedef struct {
+  int32_t            n_atoms;    /* atoms of the block = rows of a pose                                             */
+  const char*        header;     /* 3 header lines + counts line, each newline-terminated                            */
+  const char* const* atom_tail;  /* [n_atoms] atom line after the 30 coordinate columns (" C   0  0 ...", no newline) */
+  const char*        trailer;    /* bond block, property block, "M  END", data items, "$$$$", newline-terminated      */
+} dbfr_sdf_template;
+
+/* Formats one pose (pos [n_atoms,3]) into out (capacity cap) and returns the byte count; too small a cap writes nothing. */
+int64_t dbfr_sdf_format(const dbfr_sdf_template* t, const float* pos, char* out, int64_t cap);
+/* paths[i] receives pose i of pos [n_pose, n_atoms, 3] on n_threads host threads (<= 0: one per pose up to the cores). */
+int dbfr_sdf_write_files(const dbfr_sdf_template* t, const float* pos, int32_t n_pose, const char* const* paths,
+                         int32_t n_threads);
+
 /* Synchronises the stream and returns the device-side status word of the last
  * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
  * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last

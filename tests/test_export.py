@@ -381,3 +381,67 @@ def test_gpu_complex_modeling_frame_and_files(tmp_path):
     assert arr2 is None and list(frame2.columns) == ["protein", "ligand"] and len(frame2) == 4
     frame3, arr3 = pex.complex_modeling([e], calc_metrics=True)          # metrics without export: no l-rmsd (export.py:198 precedes :215)
     assert list(frame3.columns) == ["protein", "ligand", "centroid", "chi1_15", "sc-rmsd"] and set(arr3) == {"centroid", "chi1_15", "sc-rmsd"}
+
+
+# ------------------------------------------------------------------------------------------------ lig_final.sdf
+_MOLBLOCK = """glycine zwitterion
+  toolkit           3D
+
+ 10  9  0  0  0  0  0  0  0  0999 V2000
+    0.0000    0.0000    0.0000 N   0  3  0  0  0  0  0  0  0  0  0  0
+    1.4500    0.0000    0.0000 C   0  0  0  0  0  0  0  0  0  0  0  0
+    0.3300    0.9400    0.0000 H   0  0  0  0  0  0  0  0  0  0  0  0
+    2.0000    1.4000    0.0000 C   0  0  0  0  0  0  0  0  0  0  0  0
+    1.3000    2.4000    0.0000 O   0  0  0  0  0  0  0  0  0  0  0  0
+    3.2500    1.5000    0.0000 O   0  5  0  0  0  0  0  0  0  0  0  0
+   -0.3300   -0.4700    0.8100 H   0  0  0  0  0  0  0  0  0  0  0  0
+   -0.3300   -0.4700   -0.8100 H   0  0  0  0  0  0  0  0  0  0  0  0
+    1.8100   -0.5200    0.8900 H   0  0  0  0  0  0  0  0  0  0  0  0
+    1.8100   -0.5200   -0.8900 H   0  0  0  0  0  0  0  0  0  0  0  0
+  1  2  1  0
+  1  3  1  0
+  2  4  1  0
+  4  5  2  0
+  4  6  1  0
+  1  7  1  0
+  1  8  1  0
+  2  9  1  0
+  2 10  1  0
+M  CHG  2   1   1   6  -1
+M  END
+>  <ID>
+gly
+
+$$$$
+"""
+
+
+def test_sdf_template_writes_heavy_atom_poses(tmp_path):
+    """lig_final.sdf (evaluation/export.py:236-244): the input mol block without its hydrogens (RemoveHs: what the model
+    ligand holds), atoms renumbered, charges remapped, the pose's coordinates in %10.4f columns.  Host code of the C ABI
+    (dbfr_sdf_format / dbfr_sdf_write_files) against a plain-Python formatting of the same block."""
+    t = ligand.SdfTemplate.from_molblock(_MOLBLOCK)
+    assert t.n_atoms == 5                                   # N, C, C, O, O
+    rng = np.random.default_rng(0)
+    poses = rng.normal(0, 30, (7, 5, 3)).astype(np.float32)
+    poses[0, 0] = [-123.45678, 0.00004, 9999.5]
+    text = t.format(poses[0])
+    L_ = text.split("\n")
+    assert L_[0] == "glycine zwitterion" and L_[1] == "  DBFR-HIP          3D" and L_[3].startswith("  5  4") and "V2000" in L_[3]
+    want_atoms = [f"{x:10.4f}{y:10.4f}{z:10.4f}" for x, y, z in poses[0].astype(np.float64)]
+    tails = [" N   0  3  0  0  0  0  0  0  0  0  0  0", " C   0  0  0  0  0  0  0  0  0  0  0  0", " C   0  0  0  0  0  0  0  0  0  0  0  0",
+             " O   0  0  0  0  0  0  0  0  0  0  0  0", " O   0  5  0  0  0  0  0  0  0  0  0  0"]
+    assert L_[4:9] == [a + b for a, b in zip(want_atoms, tails)]
+    assert L_[9:13] == ["  1  2  1  0", "  2  3  1  0", "  3  4  2  0", "  3  5  1  0"]     # bonds to H dropped, renumbered
+    assert L_[13] == "M  CHG  2   1   1   5  -1" and L_[14] == "M  END"
+    assert L_[15:19] == [">  <ID>", "gly", "", "$$$$"] and text.endswith("$$$$\n")
+    paths = [str(tmp_path / f"sample_{i}" / "lig_final.sdf") for i in range(7)]
+    for p in paths:
+        os.makedirs(os.path.dirname(p))
+    t.write_poses(poses, paths, threads=3)
+    for i, p in enumerate(paths):
+        assert open(p).read() == t.format(poses[i])
+    with pytest.raises(Exception):
+        t.write_poses(poses[:, :4], paths)
+    keep_h = ligand.SdfTemplate.from_molblock(_MOLBLOCK, remove_hs=False)
+    assert keep_h.n_atoms == 10 and "M  CHG  2   1   1   6  -1" in keep_h.trailer
