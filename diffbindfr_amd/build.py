@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdbfr.so")
-SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "conv2.hip", "graph.hip", "heads.hip", "export.hip"]
+SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "conv2.hip", "graph.hip", "heads.hip", "export.hip", "mdn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # conv: no SLP vectorisation -- it pairs the contraction FMAs of different edge blocks into v_pk_fma_f32 with a v_mov
 # shuffle per operand pair, which costs more vector-pipe slots next to the MFMAs than it saves and makes the kernel spill.
@@ -21,6 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # graph/heads: every fp op rounded separately (edge-in/out decisions and the SDE update mirror the oracle's
 # operation order); conv: contraction allowed (fewer VALU slots next to the MFMAs; results are tolerance-checked)
 FILE_FLAGS = {"conv.hip": ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-array-bounds"] + ([f"-DCONV_NB={os.environ['DBFR_BUILD_NB']}"] if "DBFR_BUILD_NB" in os.environ else [])}
+FILE_FLAGS["mdn.hip"] = ["-ffp-contract=off"]
 FILE_FLAGS["conv2.hip"] = ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-array-bounds"]
 DEFAULT_FP = ["-ffp-contract=off"]
 

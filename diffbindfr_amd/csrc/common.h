@@ -100,6 +100,7 @@ struct Conv2Args {
   int n_conv;
   int* queue;             // [2] device ints, zero at launch: next unit, workgroups done (re-armed by the last one)
   int run_barrier, no_split;   // developer knobs (launch_conv2)
+  int skew;                    // start delay of the second half of the waves, in 512-cycle sleeps
 };
 
 struct Mlp2 {              // SimpleLinear: Linear(in,hid) -> act -> Linear(hid,out)

@@ -180,6 +180,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2(Conv2Args a) {
     const float* xs_lane = xs + n * C2_XLD;          // + 16 b C2_XLD per edge block
     const float* sh_lane = shs + n * 10;
     if (RB == 3 && wave >= NW / 2) __builtin_amdgcn_s_barrier();   // second half: one barrier interval (half a tile) behind
+    // the two waves of a SIMD run the same code from the same start: left alone they stay IN phase (both in their MFMA
+    // burst, then both in their contraction, the matrix pipe idle).  The second-dispatched half starts its tiles a
+    // fraction of a tile late; the offset then persists (a wave that contracts lets its partner run at full rate)
+    if (RB == 0 && wave >= NW / 2) for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(8);
     for (int r = r_begin; r < r_end; ++r) {
       const RunDesc rd = d.w.runs[r];
       const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
@@ -319,7 +323,9 @@ void launch_conv2(const Conv2Args& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
+  static int skew = getenv("DBFR_CONV2_SKEW") ? atoi(getenv("DBFR_CONV2_SKEW")) : 0;
   Conv2Args b = a;
+  b.skew = skew;
   b.run_barrier = run_barrier;
   b.no_split = no_split;
   static int abl = getenv("DBFR_CONV2_ABL") ? atoi(getenv("DBFR_CONV2_ABL")) : 0;

@@ -75,6 +75,16 @@ class PoseMetricsOut(C.Structure):
                 ("lig_rmsd", C.c_void_p)]
 
 
+_MDN_PTRS = ("lig_ptr", "lig_node_s", "lig_edge_s", "lig_edge_src", "lig_edge_dst", "lig_in_ptr", "lig_in_edge", "lig_pos",
+             "lig_s_in", "res_ptr", "pro_node_s", "pro_node_v", "pro_edge_src", "pro_edge_dst", "pro_in_ptr", "pro_edge_s",
+             "pro_edge_v", "pro_seq", "pro_xyz_full")
+
+
+class MdnBatch(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "NL", "EL", "NR", "EP")] + [(n, C.c_void_p) for n in _MDN_PTRS] + \
+               [("dist_threshold", C.c_float)]
+
+
 class SdfTemplate(C.Structure):
     _fields_ = [("n_atoms", C.c_int32), ("header", C.c_char_p), ("atom_tail", C.POINTER(C.c_char_p)), ("trailer", C.c_char_p)]
 
@@ -91,7 +101,7 @@ SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "d
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
            "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
            "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket", "dbfr_sdf_format",
-           "dbfr_sdf_write_files"]
+           "dbfr_sdf_write_files", "dbfr_mdn_model_create", "dbfr_mdn_model_destroy", "dbfr_mdn_workspace_bytes", "dbfr_mdn_forward"]
 
 _lib = None
 
@@ -142,6 +152,11 @@ def load():
     lib.dbfr_sdf_format.argtypes = [C.POINTER(SdfTemplate), vp, vp, C.c_int64]
     lib.dbfr_sdf_format.restype = C.c_int64
     lib.dbfr_sdf_write_files.argtypes = [C.POINTER(SdfTemplate), vp, i32, C.POINTER(C.c_char_p), i32]
+    lib.dbfr_mdn_model_create.argtypes = [C.POINTER(Tensor), i32, C.POINTER(vp)]
+    lib.dbfr_mdn_model_destroy.argtypes = [vp]
+    lib.dbfr_mdn_model_destroy.restype = None
+    lib.dbfr_mdn_workspace_bytes.argtypes = [C.POINTER(MdnBatch), C.POINTER(C.c_size_t)]
+    lib.dbfr_mdn_forward.argtypes = [vp, C.POINTER(MdnBatch), vp, vp, vp, vp, C.c_size_t, vp]
     if lib.dbfr_abi_version() != 1:
         raise DbfrError("libdbfr ABI version mismatch")
     _lib = lib

@@ -1,0 +1,216 @@
+"""``KarmaDockHIP``: the MDN pose scorer's network forward on the device.
+
+Mirrors ``KarmaDock`` of DiffBindFR/scoring/architecture/KarmaDock_sc.py (constructed in
+DiffBindFR/common/engines.py:249, weights loaded with ``strict=False``, :263-268): same parameter names for everything
+the scoring forward reads (``lig_encoder.*``, ``pro_encoder.*``, ``mdn_layer.*``), ``forward(data) -> mdn_score [B]`` with
+``data`` the featurised HeteroData batch (or a plain dict of the same tensors).  The arithmetic runs in libdbfr.so
+(csrc/mdn.hip) through ``dbfr_mdn_forward``; there is no CPU path.  The RDKit / openfold featurisation that builds
+``data`` stays with the reference.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import lib as L
+
+GT_LAYERS, GVP_LAYERS = 6, 3
+
+
+def param_shapes():
+    """name -> shape of every tensor of KarmaDock's state_dict that its scoring forward reads."""
+    S = {}
+
+    def lin(k, o, i, bias=True):
+        S[k + ".weight"] = (o, i)
+        if bias:
+            S[k + ".bias"] = (o,)
+
+    def bn(k, n):
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            S[f"{k}.{s}"] = (n,)
+
+    def ln(k, n):
+        S[k + ".scalar_norm.weight"] = (n,)
+        S[k + ".scalar_norm.bias"] = (n,)
+
+    def gvp(k, si, vi, so, vo):
+        h = max(vi, vo)
+        lin(k + ".wh", h, vi, False)
+        lin(k + ".ws", so, h + si)
+        if vo:
+            lin(k + ".wv", vo, h, False)
+
+    lin("lig_encoder.node_encoder", 128, 89)
+    lin("lig_encoder.edge_encoder", 128, 20)
+    for l in range(GT_LAYERS):
+        k = f"lig_encoder.gt_block.{l}"
+        for w in ("node", "edge"):
+            bn(f"{k}.batch_norm1_{w}_feats", 128)
+        for w in ("Q", "K", "V", "edge_feats_projection"):
+            lin(f"{k}.mha_module.{w}", 128, 128, False)
+        lin(k + ".O_node_feats", 128, 128)
+        lin(k + ".node_feats_MLP.0", 256, 128, False)
+        lin(k + ".node_feats_MLP.3", 128, 256, False)
+        bn(k + ".batch_norm2_node_feats", 128)
+        if l < GT_LAYERS - 1:
+            lin(k + ".O_edge_feats", 128, 128)
+            bn(k + ".batch_norm2_edge_feats", 128)
+            lin(k + ".edge_feats_MLP.0", 256, 128, False)
+            lin(k + ".edge_feats_MLP.3", 128, 256, False)
+    S["pro_encoder.W_s.weight"] = (31, 31)
+    ln("pro_encoder.W_v.0", 40); gvp("pro_encoder.W_v.1", 40, 3, 128, 16)
+    ln("pro_encoder.W_e.0", 21); gvp("pro_encoder.W_e.1", 21, 1, 32, 1)
+    for l in range(GVP_LAYERS):
+        k = f"pro_encoder.layers.{l}"
+        gvp(k + ".conv.message_func.0", 288, 33, 128, 16)
+        gvp(k + ".conv.message_func.1", 128, 16, 128, 16)
+        gvp(k + ".conv.message_func.2", 128, 16, 128, 16)
+        ln(k + ".norm.0", 128); ln(k + ".norm.1", 128)
+        gvp(k + ".ff_func.0", 128, 16, 512, 32)
+        gvp(k + ".ff_func.1", 512, 32, 128, 16)
+    ln("pro_encoder.W_out.0", 128); gvp("pro_encoder.W_out.1", 128, 16, 128, 0)
+    lin("mdn_layer.MLP.0", 128, 256); bn("mdn_layer.MLP.1", 128)
+    for w in ("z_pi", "z_sigma", "z_mu"):
+        lin("mdn_layer." + w, 10, 128)
+    return S
+
+
+class _Store(nn.Module):
+    """Nested parameter container: attribute path == state_dict key."""
+
+
+def _put(root, name, tensor, buffer):
+    parts = name.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, _Store())
+        m = getattr(m, p)
+    if buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+def _get(data, *path):
+    cur = data
+    for p in path:
+        cur = cur[p] if isinstance(cur, dict) or not hasattr(cur, p if isinstance(p, str) else "") else getattr(cur, p)
+    return cur
+
+
+def batch_from_hetero(data):
+    """The tensors ``KarmaDock.forward`` reads from its HeteroData batch (KarmaDock_sc.py:58-96) as a flat dict."""
+    lig, pro = data["ligand"], data["protein"]
+    l2l, p2p = data[("ligand", "l2l", "ligand")], data[("protein", "p2p", "protein")]
+    g = lambda s, k: s[k] if isinstance(s, dict) else getattr(s, k)
+    cov = g(lig, "cov_edge_mask")
+    return dict(lig_node_s=g(lig, "node_s"), lig_edge_s=g(l2l, "edge_s")[cov], lig_edge_index=g(l2l, "edge_index")[:, cov],
+                lig_pos=g(lig, "xyz"), lig_batch=g(lig, "batch"), pro_node_s=g(pro, "node_s"), pro_node_v=g(pro, "node_v"),
+                pro_edge_index=g(p2p, "edge_index"), pro_edge_s=g(p2p, "edge_s"), pro_edge_v=g(p2p, "edge_v"),
+                pro_seq=g(pro, "seq"), pro_xyz_full=g(pro, "xyz_full"), pro_batch=g(pro, "batch"))
+
+
+class KarmaDockHIP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        for k, shp in param_shapes().items():
+            buf = k.endswith(("running_mean", "running_var"))
+            _put(self, k, torch.ones(shp) if k.endswith(("running_var", "norm.weight")) else torch.zeros(shp), buf)
+        self._handles = {}
+        self._ws = {}
+
+    def load_state_dict(self, state_dict, strict=False, **kw):
+        """The reference loads the scorer with strict=False (engines.py:263-268): its checkpoint carries the pose-prediction
+        modules (egnn_layers, gates, torsion head) that the scoring forward never calls."""
+        mine = set(self.state_dict().keys())
+        return super().load_state_dict({k: v for k, v in state_dict.items() if k in mine or strict}, strict=strict, **kw)
+
+    def release(self):
+        for _, h in self._handles.values():
+            L.load().dbfr_mdn_model_destroy(h)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def handle(self, device):
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        fp = tuple((v.data_ptr(), v._version) for v in self.state_dict(keep_vars=True).values())
+        cur = self._handles.get(idx)
+        if cur is not None and cur[0] == fp:
+            return cur[1]
+        lib = L.load()
+        if cur is not None:
+            lib.dbfr_mdn_model_destroy(cur[1])
+            del self._handles[idx]
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in self.state_dict().items()}
+        arr = (L.Tensor * len(sd))()
+        for i, (k, v) in enumerate(sd.items()):
+            arr[i].name, arr[i].data, arr[i].numel = k.encode(), C.c_void_p(v.data_ptr()), v.numel()
+        h = C.c_void_p()
+        with torch.cuda.device(idx):
+            L.check(lib.dbfr_mdn_model_create(arr, len(sd), C.byref(h)))
+        self._handles[idx] = (fp, h)
+        return h
+
+    @torch.no_grad()
+    def score(self, d, lig_s=None, return_embeddings=False, dist_threshold=5.0):
+        """``d``: flat dict (``batch_from_hetero``) of DEVICE tensors.  Returns mdn_score [B] (and the embeddings)."""
+        lib = L.load()
+        dev = d["lig_pos"].device
+        if dev.type != "cuda":
+            raise L.DbfrError("KarmaDockHIP needs a ROCm device (no CPU path)")
+        i32 = lambda x: x.to(device=dev, dtype=torch.int32).contiguous()
+        f32 = lambda x: x.to(device=dev, dtype=torch.float32).contiguous()
+        lb, pb = d["lig_batch"].to(dev).long(), d["pro_batch"].to(dev).long()
+        B = int(lb.max().item()) + 1
+        ptr = lambda b: torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(torch.bincount(b, minlength=B), 0)])
+        assert bool((lb[1:] >= lb[:-1]).all()) and bool((pb[1:] >= pb[:-1]).all()), "graphs must be contiguous node ranges"
+        NL, NR = int(lb.numel()), int(pb.numel())
+        lei = d["lig_edge_index"].to(dev).long()
+        EL = int(lei.shape[1])
+        order = torch.argsort(lei[1], stable=True)                   # edge ids grouped by col, ascending inside a group
+        lin_ptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(torch.bincount(lei[1], minlength=NL), 0)])
+        pei = d["pro_edge_index"].to(dev).long()
+        EP = int(pei.shape[1])
+        perm = torch.argsort(pei[1], stable=True)                    # pocket edges grouped by target (no-op for knn_graph output)
+        pei = pei[:, perm]
+        pin_ptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(torch.bincount(pei[1], minlength=NR), 0)])
+        one = lambda *s: torch.zeros(*s, device=dev)
+        T = dict(lig_ptr=i32(ptr(lb)), lig_node_s=f32(d["lig_node_s"]), lig_edge_s=f32(d["lig_edge_s"]) if EL else one(1, 20),
+                 lig_edge_src=i32(lei[0]) if EL else i32(torch.zeros(1)), lig_edge_dst=i32(lei[1]) if EL else i32(torch.zeros(1)),
+                 lig_in_ptr=i32(lin_ptr), lig_in_edge=i32(order) if EL else i32(torch.zeros(1)), lig_pos=f32(d["lig_pos"]),
+                 lig_s_in=None if lig_s is None else f32(lig_s), res_ptr=i32(ptr(pb)), pro_node_s=f32(d["pro_node_s"]),
+                 pro_node_v=f32(d["pro_node_v"]), pro_edge_src=i32(pei[0]) if EP else i32(torch.zeros(1)),
+                 pro_edge_dst=i32(pei[1]) if EP else i32(torch.zeros(1)), pro_in_ptr=i32(pin_ptr),
+                 pro_edge_s=f32(d["pro_edge_s"].to(dev)[perm]) if EP else one(1, 21),
+                 pro_edge_v=f32(d["pro_edge_v"].to(dev)[perm]) if EP else one(1, 3), pro_seq=i32(d["pro_seq"]),
+                 pro_xyz_full=f32(d["pro_xyz_full"]))
+        b = L.MdnBatch(B=B, NL=NL, EL=EL, NR=NR, EP=EP, dist_threshold=float(dist_threshold))
+        for k in L._MDN_PTRS:
+            setattr(b, k, None if T[k] is None else C.c_void_p(T[k].data_ptr()))
+        nbytes = C.c_size_t()
+        L.check(lib.dbfr_mdn_workspace_bytes(C.byref(b), C.byref(nbytes)))
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        ws = self._ws.get(idx)
+        if ws is None or ws.numel() < nbytes.value:
+            ws = self._ws[idx] = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        score = torch.empty(B, device=dev)
+        ls = torch.empty(NL, 128, device=dev) if return_embeddings else None
+        ps = torch.empty(NR, 128, device=dev) if return_embeddings else None
+        p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            L.check(lib.dbfr_mdn_forward(self.handle(dev), C.byref(b), p(score), p(ls), p(ps), C.c_void_p(ws.data_ptr()), ws.numel(), stream))
+        self._keep = T                      # inputs stay alive until the stream has consumed them
+        return (score, ls, ps) if return_embeddings else score
+
+    def forward(self, data):
+        """KarmaDock.forward (KarmaDock_sc.py:58-70)."""
+        return self.score(batch_from_hetero(data) if not isinstance(data, dict) or "ligand" in data else data)

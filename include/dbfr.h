@@ -330,6 +330,47 @@ int64_t dbfr_sdf_format(const dbfr_sdf_template* t, const float* pos, char* out,
 int dbfr_sdf_write_files(const dbfr_sdf_template* t, const float* pos, int32_t n_pose, const char* const* paths,
                          int32_t n_threads);
 
+/* ---- MDN pose scorer: the network forward of the KarmaDock scorer the reference runs on the
+ * sampled poses (DiffBindFR/scoring/architecture/KarmaDock_sc.py:58-101, called from DiffBindFR/common/engines.py:230-302):
+ * graph-transformer ligand encoder, GVP pocket encoder, mixture-density head, score = sum over (ligand atom, residue)
+ * pairs within 5 A of the 10-component mixture density at their distance.  Inputs are the featurised tensors the
+ * reference's HeteroData batch holds (the RDKit / openfold featurisation stays on the host, outside this path).       */
+typedef struct dbfr_mdn_model dbfr_mdn_model;
+/* tensors: the reference module's state_dict entries (names relative to KarmaDock: "lig_encoder...", "pro_encoder...",
+ * "mdn_layer..."); tensors of modules the scoring forward never calls (egnn_layers, gates, ...) may be present.        */
+int  dbfr_mdn_model_create(const dbfr_tensor* tensors, int32_t n_tensors, dbfr_mdn_model** out);
+void dbfr_mdn_model_destroy(dbfr_mdn_model* m);
+
+typedef struct {                      /* device pointers; graphs are contiguous node ranges                              */
+  int32_t B, NL, EL, NR, EP;          /* graphs, ligand atoms, directed covalent ligand edges, residues, pocket edges     */
+  const int32_t* lig_ptr;             /* [B+1]                                                                            */
+  const float*   lig_node_s;          /* [NL,89]   data['ligand'].node_s                                                  */
+  const float*   lig_edge_s;          /* [EL,20]   edge_s[cov_edge_mask]                                                  */
+  const int32_t* lig_edge_src;        /* [EL]      edge_index[0] (row)                                                    */
+  const int32_t* lig_edge_dst;        /* [EL]      edge_index[1] (col): attention is normalised over the edges into col   */
+  const int32_t* lig_in_ptr;          /* [NL+1]    CSR over lig_in_edge by col                                            */
+  const int32_t* lig_in_edge;         /* [EL]      edge ids grouped by col, ascending inside a group                      */
+  const float*   lig_pos;             /* [NL,3]    data['ligand'].xyz (the pose)                                          */
+  const float*   lig_s_in;            /* [NL,128]  optional: ligand embeddings computed before (they do not depend on the
+                                                   pose), NULL = run the ligand encoder                                   */
+  const int32_t* res_ptr;             /* [B+1]                                                                            */
+  const float*   pro_node_s;          /* [NR,9]                                                                           */
+  const float*   pro_node_v;          /* [NR,3,3]                                                                         */
+  const int32_t* pro_edge_src;        /* [EP]      edge_index[0] (message source j)                                       */
+  const int32_t* pro_edge_dst;        /* [EP]      edge_index[1] (target i); edges GROUPED BY TARGET (knn_graph order)    */
+  const int32_t* pro_in_ptr;          /* [NR+1]    CSR over the edge array by target                                      */
+  const float*   pro_edge_s;          /* [EP,21]                                                                          */
+  const float*   pro_edge_v;          /* [EP,1,3]                                                                         */
+  const int32_t* pro_seq;             /* [NR]      residue type ids (< 31)                                                */
+  const float*   pro_xyz_full;        /* [NR,14,3] atom14 coordinates of the pose (unused slots as the featuriser leaves them) */
+  float          dist_threshold;      /* pairs farther apart contribute 0 (KarmaDock.forward passes 5.0); <= 0 = 5.0       */
+} dbfr_mdn_batch;
+
+int dbfr_mdn_workspace_bytes(const dbfr_mdn_batch* b, size_t* bytes);
+/* score [B]; lig_s_out [NL,128] / pro_s_out [NR,128] optional (embeddings, e.g. to reuse lig_s for the other poses).      */
+int dbfr_mdn_forward(dbfr_mdn_model* m, const dbfr_mdn_batch* b, float* score, float* lig_s_out, float* pro_s_out,
+                     void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Synchronises the stream and returns the device-side status word of the last
  * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
  * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last

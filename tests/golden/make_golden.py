@@ -834,6 +834,166 @@ def golden_pocket_select():
 
 
 
+
+# --------------------------------------------------------------------------- f4: MDN pose scorer (KarmaDock) network forward
+def _pyg_standins():
+    """torch_geometric / torch_scatter are absent offline: the few entry points the scorer's architecture files import,
+    restated from their documented semantics (parity UNPINNED at this boundary, like e3nn)."""
+    from oracle import cluster
+    import torch.nn as nn
+
+    class MessagePassing(nn.Module):
+        """flow='source_to_target': x_j = x[edge_index[0]], x_i = x[edge_index[1]], aggregation over i."""
+        def __init__(self, aggr="add", **kw):
+            super().__init__()
+            self.aggr = aggr
+
+        def propagate(self, edge_index, **kw):
+            import inspect
+            j, i = edge_index[0], edge_index[1]
+            args = {}
+            for name in inspect.signature(self.message).parameters:
+                if name.endswith("_i"):
+                    args[name] = kw[name[:-2]][i]
+                elif name.endswith("_j"):
+                    args[name] = kw[name[:-2]][j]
+                else:
+                    args[name] = kw[name]
+            msg = self.message(**args)
+            n = next(v for k, v in kw.items() if torch.is_tensor(v) and k != "edge_attr").shape[0]
+            out = torch.zeros((n,) + tuple(msg.shape[1:]), dtype=msg.dtype).index_add_(0, i, msg)
+            if self.aggr == "mean":
+                cnt = torch.zeros(n, dtype=msg.dtype).index_add_(0, i, torch.ones(i.shape[0], dtype=msg.dtype)).clamp(min=1)
+                out = out / cnt.view(-1, *([1] * (msg.dim() - 1)))
+            return out
+
+    class GraphNorm(nn.Module):                       # constructed by KarmaDock.__init__, never called by forward()
+        def __init__(self, n):
+            super().__init__()
+            self.weight, self.bias, self.mean_scale = (nn.Parameter(torch.ones(n)), nn.Parameter(torch.zeros(n)), nn.Parameter(torch.ones(n)))
+
+    def to_dense_batch(x, batch, fill_value=0):
+        B = int(batch.max()) + 1
+        cnt = torch.bincount(batch, minlength=B)
+        N = int(cnt.max())
+        ptr = torch.cumsum(cnt, 0) - cnt
+        pos = torch.arange(batch.shape[0]) - ptr[batch]
+        out = x.new_full((B, N) + tuple(x.shape[1:]), fill_value)
+        mask = torch.zeros(B, N, dtype=torch.bool)
+        out[batch, pos] = x
+        mask[batch, pos] = True
+        return out, mask
+
+    tg = types.ModuleType("torch_geometric")
+    tgn, tgu = types.ModuleType("torch_geometric.nn"), types.ModuleType("torch_geometric.utils")
+    tgn.MessagePassing, tgn.GraphNorm = MessagePassing, GraphNorm
+    tgu.to_dense_batch = to_dense_batch
+    tgu.softmax = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("EGNN is not on the scoring path"))
+    tg.nn, tg.utils = tgn, tgu
+    sys.modules.update({"torch_geometric": tg, "torch_geometric.nn": tgn, "torch_geometric.utils": tgu})
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter, ts.scatter_add, ts.scatter_mean = cluster.scatter, cluster.scatter_add, cluster.scatter_mean
+    sys.modules["torch_scatter"] = ts
+
+
+def mdn_inputs(rng, sizes):
+    """Featurised synthetic inputs of the scorer: per graph (n_lig, n_res) with the reference's feature widths
+    (ligand_feature.py / protein_feature.py: 89 + 20, 9 + 3x3, 21 + 1x3, topk = 30 nearest CA)."""
+    d = {k: [] for k in ("lig_node_s", "lig_edge_s", "lig_edge_index", "lig_pos", "lig_batch", "pro_node_s", "pro_node_v",
+                         "pro_edge_index", "pro_edge_s", "pro_edge_v", "pro_seq", "pro_xyz_full", "pro_batch")}
+    lo = po = 0
+    for b, (nl, nr) in enumerate(sizes):
+        lig = synthetic.make_ligand(rng, nl)
+        ei = lig["lig_edge_index"]
+        ca = rng.normal(0, 6.0, (nr, 3))
+        xyz = ca[:, None, :] + rng.normal(0, 1.5, (nr, 14, 3))
+        xyz[:, 1] = ca
+        absent = rng.random((nr, 14)) < 0.25
+        absent[:, :5] = False
+        xyz[absent] = 0.0                                             # unused atom14 slots sit at the origin (not masked by the head)
+        lig_pos = ca[rng.integers(0, nr, nl)] + rng.normal(0, 2.5, (nl, 3))
+        lig_pos[0] = xyz[0, 2]                                         # one coincident pair: d^2 rounds to <= 0
+        k = min(30, nr - 1)
+        D = np.linalg.norm(ca[:, None] - ca[None], axis=-1) + np.eye(nr) * 1e9
+        nbr = np.argsort(D, axis=1)[:, :k]
+        pei = np.stack([nbr.reshape(-1), np.repeat(np.arange(nr), k)])   # knn_graph: source = neighbour, target = centre
+        ev = ca[pei[0]] - ca[pei[1]]
+        ev = ev / np.linalg.norm(ev, axis=-1, keepdims=True)
+        d["lig_node_s"].append(rng.normal(0, 1, (nl, 89))); d["lig_edge_s"].append(rng.normal(0, 1, (ei.shape[1], 20)))
+        d["lig_edge_index"].append(ei + lo); d["lig_pos"].append(lig_pos); d["lig_batch"].append(np.full(nl, b))
+        d["pro_node_s"].append(rng.normal(0, 1, (nr, 9))); d["pro_node_v"].append(rng.normal(0, 1, (nr, 3, 3)))
+        d["pro_edge_index"].append(pei + po); d["pro_edge_s"].append(rng.normal(0, 1, (pei.shape[1], 21)))
+        d["pro_edge_v"].append(ev[:, None, :]); d["pro_seq"].append(rng.integers(0, 21, nr)); d["pro_xyz_full"].append(xyz)
+        d["pro_batch"].append(np.full(nr, b))
+        lo += nl; po += nr
+    out = {}
+    for k, v in d.items():
+        a = np.concatenate(v, axis=1 if k.endswith("edge_index") else 0)
+        out[k] = torch.from_numpy(a).long() if a.dtype.kind == "i" else torch.from_numpy(a).float()
+    return out
+
+
+def golden_mdn():
+    """f4: the reference's OWN KarmaDock.forward (DiffBindFR/scoring/architecture/*.py executed from source, eval mode)
+    on featurised synthetic inputs with seeded weights; asserts the oracle reproduces score and both embeddings; freezes
+    inputs + outputs as tests/golden/mdn.npz."""
+    print("[f4: MDN scorer network forward]")
+    from oracle import mdn_scorer as oms
+    import importlib.util
+    _pyg_standins()
+    base = os.path.join(ref_shims.COPY, "DiffBindFR", "scoring", "architecture")
+    pkg = types.ModuleType("dbfr_ref_scoring_arch")
+    pkg.__path__ = [base]
+    sys.modules["dbfr_ref_scoring_arch"] = pkg
+    spec = importlib.util.spec_from_file_location("dbfr_ref_scoring_arch.KarmaDock_sc", os.path.join(base, "KarmaDock_sc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    torch.manual_seed(0)
+    model = mod.KarmaDock().eval()
+    P = oms.init_params(seed=3)
+    sd = model.state_dict()
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing
+    for k, v in P.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+    used = set(P)
+    on_path = [k for k in sd if k.split(".")[0] in ("lig_encoder", "pro_encoder", "mdn_layer") and k not in used
+               and not k.endswith("num_batches_tracked") and not k.endswith("dummy_param")
+               and not k.startswith(("mdn_layer.atom_types", "mdn_layer.bond_types"))]
+    assert not on_path, f"oracle.param_shapes misses tensors of the scoring path: {on_path}"
+    model.load_state_dict(P, strict=False)
+    rng = np.random.default_rng(12)
+    d = mdn_inputs(rng, [(9, 34), (14, 41), (5, 31)])
+
+    class Store(dict):
+        __getattr__ = dict.__getitem__
+
+    cov = torch.ones(d["lig_edge_index"].shape[1], dtype=torch.bool)
+    data = {"ligand": Store(batch=d["lig_batch"], xyz=d["lig_pos"], node_s=d["lig_node_s"], cov_edge_mask=cov),
+            ("ligand", "l2l", "ligand"): Store(edge_s=d["lig_edge_s"], edge_index=d["lig_edge_index"]),
+            "protein": Store(node_s=d["pro_node_s"], node_v=d["pro_node_v"], seq=d["pro_seq"], xyz_full=d["pro_xyz_full"], batch=d["pro_batch"]),
+            ("protein", "p2p", "protein"): Store(edge_index=d["pro_edge_index"], edge_s=d["pro_edge_s"], edge_v=d["pro_edge_v"])}
+
+    class Hetero(dict):
+        def __getitem__(self, k):
+            return dict.__getitem__(self, k)
+    H = Hetero(data)
+    H_get = H.__getitem__
+    # HeteroData indexes edge stores by a tuple key: data['ligand', 'l2l', 'ligand'] == data[('ligand','l2l','ligand')]
+    with torch.no_grad():
+        pro_ref, lig_ref = model.encoding(H)
+        score_ref = model(H)
+    score, lig_s, pro_s = oms.forward(P, d)
+    close(lig_s, lig_ref, 2e-5, "f4/ligand graph-transformer embedding")
+    close(pro_s, pro_ref, 2e-5, "f4/pocket GVP embedding")
+    close(score, score_ref, 1e-5 * float(score_ref.abs().max()), "f4/MDN score per graph")
+    out = {k: npy(v) for k, v in d.items()}
+    out.update(params_seed=np.asarray(3), ref_score=npy(score_ref), ref_lig_s=npy(lig_ref), ref_pro_s=npy(pro_ref))
+    np.savez_compressed(os.path.join(HERE, "mdn.npz"), **out)
+    print("  mdn.npz:", os.path.getsize(os.path.join(HERE, "mdn.npz")) // 1024, "KiB; scores", npy(score_ref))
+
+
 # --------------------------------------------------------------------------- boundary: the reference's REAL registry + checkpoint loader
 def _ref_function_source(path, start_marker, stop_marker):
     """Source text of one top-level function of a reference file, read at run time (never stored)."""
@@ -968,5 +1128,6 @@ if __name__ == "__main__":
     golden_real_trajectory()
     golden_export()
     golden_pocket_select()
+    golden_mdn()
     golden_boundary()           # last: swaps the stand-in registry for the reference's real one
     print("golden fixtures written to", HERE)
