@@ -45,3 +45,65 @@ def test_pair_distance_quirks():
 def test_product_parameter_names_match_the_oracle():
     from diffbindfr_amd import mdn
     assert mdn.param_shapes() == {k: tuple(v) for k, v in oms.param_shapes().items()}
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _hip_model(dev, seed):
+    from diffbindfr_amd import mdn
+    P = oms.init_params(seed=seed)
+    m = mdn.KarmaDockHIP().to(dev)
+    m.load_state_dict(P, strict=True)
+    return P, m
+
+
+def _to(d, dev):
+    return {k: v.to(dev) for k, v in d.items()}
+
+
+@pytest.mark.gpu
+def test_gpu_scorer_matches_reference_fixture():
+    """Scores and both embeddings of the HIP forward against what the reference's KarmaDock computed (mdn.npz).
+    Tolerance: embeddings 1e-4 absolute (fp32 sums in another order), scores 1e-4 relative."""
+    dev = torch.device("cuda:0")
+    d, z = fixture()
+    P, m = _hip_model(dev, int(z["params_seed"]))
+    score, lig_s, pro_s = m.score(_to(d, dev), return_embeddings=True)
+    torch.cuda.synchronize()
+    assert (lig_s.cpu() - torch.from_numpy(z["ref_lig_s"])).abs().max() < 1e-4
+    assert (pro_s.cpu() - torch.from_numpy(z["ref_pro_s"])).abs().max() < 1e-4
+    assert rel_err(score, torch.from_numpy(z["ref_score"])) < 1e-4, (score.cpu(), z["ref_score"])
+
+
+@pytest.mark.gpu
+def test_gpu_scorer_ragged_batches_vs_oracle_and_reuse_of_ligand_embeddings():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    dev = torch.device("cuda:0")
+    P, m = _hip_model(dev, 7)
+    rng = np.random.default_rng(5)
+    from tests.test_mdn_inputs import mdn_inputs
+    for sizes in ([(4, 31)], [(30, 140), (6, 33), (21, 75), (12, 90)], [(35, 105)] * 3):
+        d = mdn_inputs(rng, sizes, coincident=False)
+        ref, lig_ref, pro_ref = oms.forward(P, d)
+        score, lig_s, pro_s = m.score(_to(d, dev), return_embeddings=True)
+        assert (lig_s.cpu() - lig_ref).abs().max() < 1e-4 and (pro_s.cpu() - pro_ref).abs().max() < 1e-4
+        assert rel_err(score, ref) < 1e-4, (sizes, score.cpu(), ref)
+        # pose-independent ligand embeddings handed back in: same scores, bit for bit
+        again = m.score(_to(d, dev), lig_s=lig_s)
+        assert torch.equal(again, score)
+        assert torch.equal(m.score(_to(d, dev)), score)            # reproducible
+    # graph order does not matter
+    d = mdn_inputs(rng, [(9, 40), (15, 52)], coincident=False)
+    a = m.score(_to(d, dev)).cpu()
+    sw = mdn_inputs(np.random.default_rng(99), [(15, 52)], coincident=False)   # unrelated batch in between
+    m.score(_to(sw, dev))
+    assert torch.equal(m.score(_to(d, dev)).cpu(), a)
+
+
+@pytest.mark.gpu
+def test_gpu_scorer_refuses_cpu_tensors_and_bad_state():
+    from diffbindfr_amd import lib as L, mdn
+    d, z = fixture()
+    m = mdn.KarmaDockHIP()
+    with pytest.raises(L.DbfrError):
+        m.score(d)
