@@ -835,6 +835,51 @@ def golden_pocket_select():
 
 
 
+
+def golden_chi_differ():
+    """f3: `chi_differ` (DiffBindFR/metrics/angbin.py:48-103) calls `atom37_to_torsion_angles` of the openfold package the
+    reference VENDORS (openfold/data/data_transforms.py:943-): it imports here once `openfold.config` (needs ml_collections,
+    absent; only four placeholder names are read) and `tree` are stood in.  Runs the reference's chi_differ on the 3DBS poses
+    of export.npz, asserts the oracle's restatement, freezes the result (tests/golden/chi_differ.npz)."""
+    print("[chi_differ through the vendored openfold transforms]")
+    import importlib.util
+    from oracle import export as oex
+    cfgm = types.ModuleType("openfold.config")
+    cfgm.NUM_RES, cfgm.NUM_EXTRA_SEQ, cfgm.NUM_TEMPLATES, cfgm.NUM_MSA_SEQ = "num residues placeholder", "extra", "templates", "msa"
+    root = os.path.join(ref_shims.COPY, "openfold")
+    of = types.ModuleType("openfold"); of.__path__ = [root]
+    sys.modules["openfold"] = of
+    sys.modules["openfold.config"] = cfgm
+    for sub in ("np", "utils", "data", "resources"):
+        m = types.ModuleType("openfold." + sub); m.__path__ = [os.path.join(root, sub)]
+        sys.modules["openfold." + sub] = m
+    import importlib
+    dt = importlib.import_module("openfold.data.data_transforms")
+    assert hasattr(dt, "atom37_to_torsion_angles")
+    tu = sys.modules["druglib.utils.torch_utils"]
+    assert hasattr(tu, "batched_gather")
+    sys.modules["druglib.utils.obj"].prot_math = ns.prot_math
+    spec = importlib.util.spec_from_file_location("ref_metrics_angbin", os.path.join(ref_shims.COPY, "DiffBindFR", "metrics", "angbin.py"))
+    ang = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ang)
+    z = np.load(os.path.join(HERE, "export.npz"))
+    seq = torch.from_numpy(z["aatype"][z["pocket_mask"]])
+    center = torch.from_numpy(z["center"])
+    pred = torch.from_numpy(z["prot_traj"]) + center
+    tgt = torch.from_numpy(z["target_atom14"]) + center
+    tmask = torch.from_numpy(z["target_atom14_mask"])
+    ref_d, ref_m = ang.chi_differ(pred, tgt, tmask, seq)
+    d, m = oex.chi_differ(pred, tgt, tmask, seq, T)
+    close(m.float().expand_as(ref_m), ref_m.float(), 0.0, "chi_differ/torsion mask")
+    # fp32 coordinates ~50 A from the origin: the reference's Rigid algebra and the restatement's direct projection round
+    # differently (openfold's own docstring: "extremely sensitive to floating point imprecisions"); 1e-4 rad = 0.006 degrees
+    close(d, ref_d, 1e-4, "chi_differ/delta chi (radians)")
+    rate_ref = ((ref_d < 15 / 180 * torch.pi) * ref_m.bool()).sum(dim=-2) / ref_m.sum(dim=-2)
+    close(oex.chi_success_rate(d, m), rate_ref, 1e-7, "chi_differ/chi success rates (export.py:176-179)")
+    # a second case: random rigid-group rotations about chi on the synthetic strip of all residue types
+    np.savez_compressed(os.path.join(HERE, "chi_differ.npz"), ref_delta_chi=npy(ref_d), ref_mask=npy(ref_m[0, 0]), ref_chi_rate=npy(rate_ref))
+
+
 # --------------------------------------------------------------------------- f4: MDN pose scorer (KarmaDock) network forward
 def _pyg_standins():
     """torch_geometric / torch_scatter are absent offline: the few entry points the scorer's architecture files import,
@@ -1094,6 +1139,7 @@ if __name__ == "__main__":
     golden_real_trajectory()
     golden_export()
     golden_pocket_select()
+    golden_chi_differ()
     golden_mdn()
     golden_boundary()           # last: swaps the stand-in registry for the reference's real one
     print("golden fixtures written to", HERE)

@@ -445,3 +445,30 @@ def test_sdf_template_writes_heavy_atom_poses(tmp_path):
         t.write_poses(poses[:, :4], paths)
     keep_h = ligand.SdfTemplate.from_molblock(_MOLBLOCK, remove_hs=False)
     assert keep_h.n_atoms == 10 and "M  CHG  2   1   1   6  -1" in keep_h.trailer
+
+
+def test_chi_differ_matches_the_reference_fixture():
+    """tests/golden/chi_differ.npz: what the reference's own `chi_differ` (metrics/angbin.py:48-103) returned for the 3DBS
+    poses of export.npz, its `atom37_to_torsion_angles` being the openfold copy the reference vendors
+    (make_golden.py::golden_chi_differ).  Pins the restatement to 1e-4 rad (fp32 noise of the two formulations)."""
+    z, c = fixture(), np.load(os.path.join(GOLDEN, "chi_differ.npz"))
+    seq = torch.from_numpy(z["aatype"][z["pocket_mask"]])
+    center = torch.from_numpy(z["center"])
+    d, m = oex.chi_differ(torch.from_numpy(z["prot_traj"]) + center, torch.from_numpy(z["target_atom14"]) + center,
+                          torch.from_numpy(z["target_atom14_mask"]), seq, T)
+    assert torch.equal(m.reshape(-1, 4).bool(), torch.from_numpy(c["ref_mask"]).bool())
+    assert (d - torch.from_numpy(c["ref_delta_chi"])).abs().max() < 1e-4
+    assert (oex.chi_success_rate(d, m) - torch.from_numpy(c["ref_chi_rate"])).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_delta_chi_matches_the_reference_chi_differ():
+    """k_pose_metrics' per-residue |delta chi| and chi_1..4 success rates against the REFERENCE's chi_differ output
+    (chi_differ.npz, openfold transforms vendored by the reference): 2e-4 rad."""
+    z, c = fixture(), np.load(os.path.join(GOLDEN, "chi_differ.npz"))
+    dev = torch.device("cuda:0")
+    seq = z["aatype"][z["pocket_mask"]]
+    out = pex.pose_metrics(torch.from_numpy(z["lig_traj"]).to(dev), torch.from_numpy(z["prot_traj"]).to(dev), z["center"], z["lig_pos"],
+                           z["target_atom14"], z["target_atom14_mask"], seq, with_delta_chi=True)
+    assert np.abs(out["delta_chi"].cpu().numpy() - c["ref_delta_chi"]).max() < 2e-4
+    assert np.abs(out["chi_rate"].cpu().numpy() - c["ref_chi_rate"]).max() < 1e-6
