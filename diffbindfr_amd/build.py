@@ -26,6 +26,19 @@ FILE_FLAGS["conv2.hip"] = ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-arr
 DEFAULT_FP = ["-ffp-contract=off"]
 
 
+def source_hash():
+    """sha256 over every file the library is built from (sorted names + contents): compiled into api.cpp as
+    DBFR_BUILD_ID and returned by dbfr_build_id(), so that a test can tell a stale prebuilt .so from the tree it sits in."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip", ".h", ".inc"))])
+    files.append(os.path.join(HERE, "..", "include", "dbfr.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -37,12 +50,18 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "residue_tables.inc"), os.path.join(HERE, "..", "include", "dbfr.h")]
     objs, jobs = [], []
+    bid = source_hash()
+    stamp = os.path.join(CSRC, ".build_id")
+    if not os.path.exists(stamp) or open(stamp).read() != bid:      # any source changed: api.cpp carries the id
+        open(stamp, "w").write(bid)
+    headers.append(stamp)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc, "-x", "hip", "-c", src, "-o", obj] + FLAGS + FILE_FLAGS.get(s, DEFAULT_FP))
+            jobs.append([hipcc, "-x", "hip", "-c", src, "-o", obj] + FLAGS + FILE_FLAGS.get(s, DEFAULT_FP) +
+                        ([f'-DDBFR_BUILD_ID="{bid}"'] if s == "api.cpp" else []))
 
     def run(cmd):
         if verbose:

@@ -474,6 +474,10 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
 }
 
 extern "C" int dbfr_abi_version(void) { return DBFR_ABI_VERSION; }
+#ifndef DBFR_BUILD_ID
+#define DBFR_BUILD_ID "unknown"
+#endif
+extern "C" const char* dbfr_build_id(void) { return DBFR_BUILD_ID; }
 extern "C" const char* dbfr_last_error(void) { return g_err.c_str(); }
 
 extern "C" int dbfr_wigner3j(int32_t l1, int32_t l2, int32_t l3, double* out) {

@@ -98,7 +98,7 @@ class PdbTopology(C.Structure):
 # every symbol include/dbfr.h declares (tests check that the library exports all of them)
 SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
            "dbfr_sample_range", "dbfr_capacity_report",
-           "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
+           "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_build_id", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
            "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
            "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket", "dbfr_sdf_format",
            "dbfr_sdf_write_files", "dbfr_mdn_model_create", "dbfr_mdn_model_destroy", "dbfr_mdn_workspace_bytes", "dbfr_mdn_forward"]
@@ -120,6 +120,7 @@ def load():
                         f"(python -m diffbindfr_amd.build). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     lib.dbfr_last_error.restype = C.c_char_p
+    lib.dbfr_build_id.restype = C.c_char_p
     lib.dbfr_model_create.argtypes = [C.POINTER(ModelCfg), C.POINTER(Tensor), i32, C.POINTER(vp)]
     lib.dbfr_model_destroy.argtypes = [vp]
     lib.dbfr_model_destroy.restype = None

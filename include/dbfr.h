@@ -379,6 +379,9 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 
 /* ---- introspection / test hooks */
 int         dbfr_abi_version(void);
+/* First 16 hex digits of the sha256 over the library's source files at build time (diffbindfr_amd/build.py:
+ * source_hash): lets a caller check that a prebuilt libdbfr.so belongs to the source tree next to it.               */
+const char* dbfr_build_id(void);
 const char* dbfr_last_error(void);
 /* Real-basis Wigner-3j tensor the library derives (Racah formula) to self-check
  * the closed forms baked into the kernels; out has (2l1+1)(2l2+1)(2l3+1) doubles. */

@@ -11,10 +11,10 @@ Follows
   druglib/utils/obj/prot_math.py:18-43,294-316   to_pos14, atom14_to_atom37
   druglib/utils/obj/protein.py:478-537,658-800   Protein.pos_update (atom14 -> atom37), int_id_to_str_id, to_pdb
 Pinned against the reference's own functions by tests/golden/make_golden.py -> tests/golden/export.npz, EXCEPT the
-dihedral extraction inside chi_differ: the reference calls openfold.data.data_transforms.atom37_to_torsion_angles
-(openfold is an un-vendored dependency absent offline, env.yaml) => PARITY UNPINNED at that call; it is restated
-below from the published AlphaFold-2 / OpenFold algorithm and cross-checked against the chi angles the reference's own
-extract_chi_and_template recovers (tests/test_export.py).
+dihedral extraction inside chi_differ: the reference calls atom37_to_torsion_angles of the openfold copy it vendors
+(/root/reference/openfold/data/data_transforms.py:943-); restated below (chi part only, on the atom14 layout) and PINNED since
+round 2: tests/golden/make_golden.py::golden_chi_differ runs the reference's own chi_differ on the 3DBS poses (mask equal,
+|delta chi| within 4.8e-5 rad = the fp32 noise of the two formulations, success rates equal) -> tests/golden/chi_differ.npz.
 """
 import numpy as np
 import torch
@@ -59,7 +59,7 @@ def sidechain_rmsd(pred_atom14, target_atom14, target_atom14_mask, sequence, tab
 
 
 def chi_sin_cos(atom14_pos, atom14_mask, sequence, tables):
-    """The chi part of atom37_to_torsion_angles (published AF2 / OpenFold algorithm, UNPINNED here), evaluated on the
+    """The chi part of atom37_to_torsion_angles (openfold/data/data_transforms.py:943-1090, vendored by the reference), evaluated on the
     atom14 layout: for every chi_k with dihedral atoms (a0,a1,a2,a3) build the frame with origin a2, x along a2-a1 and
     a0 in the xy plane (eps 1e-8 under both square roots), express a3 in it and return (sin, cos) = (z, y) / sqrt(z^2 +
     y^2 + 1e-8).  Returns (sin_cos [..., N, 4, 2], alt_sin_cos, mask [..., N, 4]); alt flips the pi-periodic chis."""

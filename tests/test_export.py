@@ -2,7 +2,7 @@
 
 CPU: the oracle (oracle/export.py) against the fixture frozen from the reference's own calc_lig_centroid /
 sidechain_rmsd / symm_rmsd / Protein.pos_update + to_pdb (tests/golden/export.npz, 3DBS example); the chi part, whose
-dihedral extraction the reference delegates to the absent openfold (UNPINNED), cross-checked against the chi angles of
+dihedral extraction the reference delegates to its vendored openfold transforms (pinned by chi_differ.npz), cross-checked against the chi angles of
 the reference-pinned extract_chi_and_template; the library's host-side PDB writer byte-for-byte against the reference
 text; the product's automorphism search against the reference's networkx matcher.
 GPU: dbfr_pose_metrics against the reference fixture and the oracle.
@@ -55,7 +55,7 @@ def test_oracle_metrics_match_reference_fixture():
 
 
 def test_oracle_chi_matches_reference_pinned_chi_extraction():
-    """UNPINNED call (openfold's atom37_to_torsion_angles) restated in oracle/export.chi_sin_cos: its angles must be the
+    """openfold's atom37_to_torsion_angles restated in oracle/export.chi_sin_cos (pinned by chi_differ.npz): its angles must be the
     chi angles the reference's own extract_chi_and_template recovers from the same coordinates, and the difference of
     two structures built from known torsions must be the applied rotation (wrapped; pi-periodic chis modulo pi)."""
     z = fixture()

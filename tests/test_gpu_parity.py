@@ -47,6 +47,9 @@ def test_native_library_is_loaded(setup):
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
     assert "libdbfr.so" in maps
+    # ... and it is the library of THIS source tree, not a stale prebuilt one
+    from diffbindfr_amd import build
+    assert L.load().dbfr_build_id().decode() == build.source_hash()
 
 
 @pytest.mark.parametrize("step", [0, 10, 19])

@@ -280,3 +280,9 @@ def test_f1_f2_entry_points_have_no_cpu_path():
     with pytest.raises(L.DbfrError):
         assemble.init_poses(None, pb, dict(tor=torch.zeros(1), rot=torch.eye(3).repeat(2, 1, 1), tr=torch.zeros(2, 3),
                                            sc=torch.zeros(pb.dims["NR"], 4)))
+
+
+def test_library_build_id_matches_the_sources():
+    """The in-tree libdbfr.so carries the hash of the sources it was built from (diffbindfr_amd/build.py)."""
+    from diffbindfr_amd import build
+    assert L.load().dbfr_build_id().decode() == build.source_hash()
