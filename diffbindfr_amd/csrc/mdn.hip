@@ -616,3 +616,125 @@ extern "C" int dbfr_mdn_forward(dbfr_mdn_model* m, const dbfr_mdn_batch* B, floa
   MCHECK(hipGetLastError());
   return DBFR_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ pocket featurisation
+// The pocket half of the scorer's input from residue types + atom14 coordinates (absent atoms at the origin), for any number
+// of pockets / poses at once: `get_protein_feature` of DiffBindFR/scoring/dataset/protein_feature.py:137-216 behind its PDB
+// parser (intra-residue distances, backbone dihedral sin/cos as openfold's atom37_to_torsion_angles computes them, CA
+// orientations + side-chain direction, the k nearest CA neighbours of every residue, 21 edge scalars, unit CA-CA vector).
+// Quirks kept as listed in oracle/mdn_features.py.  One workgroup per pocket, thread per residue.
+#define PF_MAXR 1024
+#define PF_MAXK 32
+__constant__ int kIdealAtoms[21] = {5, 11, 8, 8, 6, 9, 9, 4, 10, 8, 8, 9, 8, 11, 7, 6, 7, 14, 12, 7, 0};
+
+struct PocketFeatArgs {
+  const int* res_ptr; const int* edge_ptr; const int* aatype; const float* x14; int topk; int n_res;
+  float* node_s; float* node_v; int* edge_src; int* edge_dst; int* in_ptr; float* edge_s; float* edge_v;
+};
+
+__device__ __forceinline__ void dihedral_sc(const float* a0, const float* a1, const float* a2, const float* a3, float sign, float* out) {
+  float e0[3], e1[3], e2[3], d[3];
+  for (int c = 0; c < 3; ++c) { e0[c] = a2[c] - a1[c]; e1[c] = a0[c] - a2[c]; d[c] = a3[c] - a2[c]; }
+  float den = sqrtf((e0[0] * e0[0] + e0[1] * e0[1]) + e0[2] * e0[2] + 1e-8f);
+  for (int c = 0; c < 3; ++c) e0[c] = e0[c] / den;
+  const float dot = (e0[0] * e1[0] + e0[1] * e1[1]) + e0[2] * e1[2];
+  for (int c = 0; c < 3; ++c) e1[c] = e1[c] - e0[c] * dot;
+  den = sqrtf((e1[0] * e1[0] + e1[1] * e1[1]) + e1[2] * e1[2] + 1e-8f);
+  for (int c = 0; c < 3; ++c) e1[c] = e1[c] / den;
+  e2[0] = e0[1] * e1[2] - e0[2] * e1[1]; e2[1] = e0[2] * e1[0] - e0[0] * e1[2]; e2[2] = e0[0] * e1[1] - e0[1] * e1[0];
+  const float z = (e2[0] * d[0] + e2[1] * d[1]) + e2[2] * d[2], y = (e1[0] * d[0] + e1[1] * d[1]) + e1[2] * d[2];
+  const float nn = sqrtf((z * z + y * y) + 1e-8f);
+  out[0] = sign * (z / nn); out[1] = sign * (y / nn);
+}
+__device__ __forceinline__ void unit3(float x, float y, float z, float* o) {   // nan_to_num(v / |v|)
+  const float n = sqrtf((x * x + y * y) + z * z);
+  o[0] = n > 0.f ? x / n : 0.f; o[1] = n > 0.f ? y / n : 0.f; o[2] = n > 0.f ? z / n : 0.f;
+}
+__device__ __forceinline__ float norm_eps(float x, float y, float z) {          // |v + 1e-6|
+  x += 1e-6f; y += 1e-6f; z += 1e-6f;
+  return sqrtf((x * x + y * y) + z * z);
+}
+
+__global__ __launch_bounds__(128) void k_pocket_features(PocketFeatArgs a) {
+  __shared__ float ca[PF_MAXR][3], cb[PF_MAXR][3], com[PF_MAXR][3];
+  const int g = blockIdx.x, r0 = a.res_ptr[g], n = min(a.res_ptr[g + 1] - r0, PF_MAXR);
+  const int k_eff = min(a.topk, n - 1);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float* X = a.x14 + (size_t)(r0 + i) * 42;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int s = 0; s < 14; ++s) { sx += X[3 * s]; sy += X[3 * s + 1]; sz += X[3 * s + 2]; }
+    const float cnt = (float)kIdealAtoms[min(max(a.aatype[r0 + i], 0), 20)];
+    com[i][0] = sx / cnt; com[i][1] = sy / cnt; com[i][2] = sz / cnt;
+    for (int c = 0; c < 3; ++c) { ca[i][c] = X[3 + c]; cb[i][c] = X[12 + c]; }
+  }
+  __syncthreads();
+  const float zero3[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int gi = r0 + i;
+    const float* X = a.x14 + (size_t)gi * 42;
+    const float *N_ = X, *CA = X + 3, *C = X + 6, *O = X + 9;
+    const float* P = i > 0 ? X - 42 : nullptr;             // previous residue in array order (zeros before the first)
+    float* ns = a.node_s + (size_t)gi * 9;
+    ns[0] = 0.1f * norm_eps(CA[0] - O[0], CA[1] - O[1], CA[2] - O[2]);
+    ns[1] = 0.1f * norm_eps(N_[0] - O[0], N_[1] - O[1], N_[2] - O[2]);
+    ns[2] = 0.1f * norm_eps(N_[0] - C[0], N_[1] - C[1], N_[2] - C[2]);
+    dihedral_sc(P ? P + 3 : zero3, P ? P + 6 : zero3, N_, CA, 1.f, ns + 3);     // pre-omega: CA-1, C-1, N, CA
+    dihedral_sc(P ? P + 6 : zero3, N_, CA, C, 1.f, ns + 5);                     // phi: C-1, N, CA, C
+    dihedral_sc(N_, CA, C, O, -1.f, ns + 7);                                    // psi: N, CA, C, O (negated)
+    float* nv = a.node_v + (size_t)gi * 9;
+    if (i + 1 < n) unit3(ca[i + 1][0] - ca[i][0], ca[i + 1][1] - ca[i][1], ca[i + 1][2] - ca[i][2], nv); else nv[0] = nv[1] = nv[2] = 0.f;
+    if (i > 0) unit3(ca[i - 1][0] - ca[i][0], ca[i - 1][1] - ca[i][1], ca[i - 1][2] - ca[i][2], nv + 3); else nv[3] = nv[4] = nv[5] = 0.f;
+    {
+      float c[3], nn[3], bis[3], perp[3];
+      unit3(C[0] - CA[0], C[1] - CA[1], C[2] - CA[2], c);
+      unit3(N_[0] - CA[0], N_[1] - CA[1], N_[2] - CA[2], nn);
+      unit3(c[0] + nn[0], c[1] + nn[1], c[2] + nn[2], bis);
+      unit3(c[1] * nn[2] - c[2] * nn[1], c[2] * nn[0] - c[0] * nn[2], c[0] * nn[1] - c[1] * nn[0], perp);
+      const float s13 = 0.5773502691896257f, s23 = 0.816496580927726f;
+      for (int q = 0; q < 3; ++q) nv[6 + q] = -bis[q] * s13 - perp[q] * s23;
+    }
+    // k nearest other residues by CA distance (stable: ties keep the lower index first)
+    float bd[PF_MAXK]; int bj[PF_MAXK]; int cnt = 0;
+    for (int j = 0; j < n; ++j) {
+      if (j == i) continue;
+      const float dx = ca[i][0] - ca[j][0], dy = ca[i][1] - ca[j][1], dz = ca[i][2] - ca[j][2];
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      if (cnt == k_eff && !(d2 < bd[cnt - 1])) continue;
+      int p = cnt < k_eff ? cnt++ : cnt - 1;
+      while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; bj[p] = bj[p - 1]; --p; }
+      bd[p] = d2; bj[p] = j;
+    }
+    const int e0 = a.edge_ptr[g] + i * k_eff;
+    a.in_ptr[gi] = e0;
+    for (int r = 0; r < k_eff; ++r) {
+      const int j = bj[r], e = e0 + r;
+      a.edge_src[e] = r0 + j; a.edge_dst[e] = gi;
+      const float dx = ca[j][0] - ca[i][0], dy = ca[j][1] - ca[i][1], dz = ca[j][2] - ca[i][2];
+      const float dca = 0.1f * norm_eps(dx, dy, dz);
+      const float dcb = 0.1f * norm_eps(cb[j][0] - cb[i][0], cb[j][1] - cb[i][1], cb[j][2] - cb[i][2]);
+      const double cx = (double)com[j][0] - (double)com[i][0], cy = (double)com[j][1] - (double)com[i][1], cz = (double)com[j][2] - (double)com[i][2];
+      float* es = a.edge_s + (size_t)e * 21;
+      es[0] = dca < 4.5f ? 1.f : 0.f;
+      es[1] = norm_eps(dx, dy, dz) * 0.1f;                     // pairwise_distance(eps = 1e-6) * 0.1
+      es[2] = (float)(sqrt(cx * cx + cy * cy + cz * cz) * 0.1);
+      es[3] = dca; es[4] = dcb;
+      for (int q = 0; q < 16; ++q) { const float u = (dca - (20.0f / 15.0f) * (float)q) / 1.25f; es[5 + q] = expf(-(u * u)); }
+      unit3(dx, dy, dz, a.edge_v + (size_t)e * 3);
+    }
+  }
+  if (g == gridDim.x - 1 && threadIdx.x == 0) a.in_ptr[a.n_res] = a.edge_ptr[gridDim.x];
+}
+
+extern "C" int dbfr_mdn_pocket_features(int32_t n_graph, int32_t n_res, const int32_t* res_ptr, const int32_t* edge_ptr,
+                                        const int32_t* aatype, const float* atom14_pos, int32_t topk, float* node_s, float* node_v,
+                                        int32_t* edge_src, int32_t* edge_dst, int32_t* in_ptr, float* edge_s, float* edge_v,
+                                        void* hip_stream) {
+  if (n_graph <= 0 || n_res <= 0 || !res_ptr || !edge_ptr || !aatype || !atom14_pos || !node_s || !node_v || !edge_src || !edge_dst ||
+      !in_ptr || !edge_s || !edge_v) { dbfr_set_error("null argument"); return DBFR_ERR_ARG; }
+  if (topk < 1 || topk > PF_MAXK) { dbfr_set_error("topk must be in [1, 32]"); return DBFR_ERR_ARG; }
+  PocketFeatArgs a{res_ptr, edge_ptr, aatype, atom14_pos, topk, n_res, node_s, node_v, edge_src, edge_dst, in_ptr, edge_s, edge_v};
+  hipLaunchKernelGGL(k_pocket_features, dim3(n_graph), dim3(128), 0, (hipStream_t)hip_stream, a);
+  MCHECK(hipGetLastError());
+  return DBFR_OK;
+}

@@ -101,7 +101,7 @@ SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_workspace_bytes", "d
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_build_id", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths",
            "dbfr_profile_enable", "dbfr_profile_read", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
            "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket", "dbfr_sdf_format",
-           "dbfr_sdf_write_files", "dbfr_mdn_model_create", "dbfr_mdn_model_destroy", "dbfr_mdn_workspace_bytes", "dbfr_mdn_forward"]
+           "dbfr_sdf_write_files", "dbfr_mdn_model_create", "dbfr_mdn_model_destroy", "dbfr_mdn_workspace_bytes", "dbfr_mdn_forward", "dbfr_mdn_pocket_features"]
 
 _lib = None
 
@@ -157,6 +157,7 @@ def load():
     lib.dbfr_mdn_model_destroy.argtypes = [vp]
     lib.dbfr_mdn_model_destroy.restype = None
     lib.dbfr_mdn_workspace_bytes.argtypes = [C.POINTER(MdnBatch), C.POINTER(C.c_size_t)]
+    lib.dbfr_mdn_pocket_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dbfr_mdn_forward.argtypes = [vp, C.POINTER(MdnBatch), vp, vp, vp, vp, C.c_size_t, vp]
     if lib.dbfr_abi_version() != 1:
         raise DbfrError("libdbfr ABI version mismatch")

@@ -112,6 +112,41 @@ def batch_from_hetero(data):
                 pro_seq=g(pro, "seq"), pro_xyz_full=g(pro, "xyz_full"), pro_batch=g(pro, "batch"))
 
 
+@torch.no_grad()
+def pocket_features(aatype, atom14_pos, res_ptr=None, topk=30):
+    """The pocket half of the scorer's input on the device (``dbfr_mdn_pocket_features``): replaces ``get_protein_feature``
+    (DiffBindFR/scoring/dataset/protein_feature.py:137-216) behind its PDB parser for any number of pockets / poses at once.
+    aatype [N] (< 20), atom14_pos [N,14,3] device tensor with absent atoms at the origin (``dbfr_sample``'s atom14 output plus the
+    pocket centre), res_ptr [P+1] (None = one pocket).  Returns the ``pro_*`` entries of the flat batch dict ``score`` takes."""
+    lib = L.load()
+    dev = atom14_pos.device
+    if dev.type != "cuda":
+        raise L.DbfrError("pocket_features needs a ROCm device (no CPU path)")
+    n = int(atom14_pos.shape[0])
+    rp = torch.tensor([0, n]) if res_ptr is None else torch.as_tensor(res_ptr).cpu().long()
+    cnt = rp[1:] - rp[:-1]
+    if int(cnt.max()) > 1024 or int(cnt.min()) < 2:
+        raise L.DbfrError("pockets of 2 .. 1024 residues")
+    per = cnt * torch.minimum(torch.full_like(cnt, int(topk)), cnt - 1)
+    ep = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(per, 0)])
+    E, P = int(ep[-1]), int(cnt.numel())
+    i32 = lambda x: torch.as_tensor(x).to(device=dev, dtype=torch.int32).contiguous()
+    aa, x = i32(aatype), atom14_pos.to(torch.float32).contiguous()
+    rpd, epd = i32(rp), i32(ep)
+    out = dict(pro_node_s=torch.empty(n, 9, device=dev), pro_node_v=torch.empty(n, 3, 3, device=dev),
+               pro_edge_s=torch.empty(E, 21, device=dev), pro_edge_v=torch.empty(E, 1, 3, device=dev))
+    src, dst = torch.empty(E, dtype=torch.int32, device=dev), torch.empty(E, dtype=torch.int32, device=dev)
+    in_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        L.check(lib.dbfr_mdn_pocket_features(P, n, p(rpd), p(epd), p(aa), p(x), int(topk), p(out["pro_node_s"]), p(out["pro_node_v"]),
+                                             p(src), p(dst), p(in_ptr), p(out["pro_edge_s"]), p(out["pro_edge_v"]),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    out.update(pro_edge_index=torch.stack([src, dst]).long(), pro_seq=aa.long(), pro_xyz_full=x,
+               pro_batch=torch.repeat_interleave(torch.arange(P, device=dev), cnt.to(dev)))
+    return out
+
+
 class KarmaDockHIP(nn.Module):
     def __init__(self):
         super().__init__()
@@ -210,6 +245,36 @@ class KarmaDockHIP(nn.Module):
             L.check(lib.dbfr_mdn_forward(self.handle(dev), C.byref(b), p(score), p(ls), p(ps), C.c_void_p(ws.data_ptr()), ws.numel(), stream))
         self._keep = T                      # inputs stay alive until the stream has consumed them
         return (score, ls, ps) if return_embeddings else score
+
+    @torch.no_grad()
+    def score_poses(self, lig, aatype, atom14_poses, lig_poses, topk=30, reuse_ligand_embeddings=True):
+        """Scores P poses of ONE complex where the sampler left them: ``atom14_poses`` [P,N_r,14,3] and ``lig_poses`` [P,N_l,3]
+        device tensors in absolute coordinates (``dbfr_sample`` output + the pocket centre, absent atom14 slots zero), ``aatype``
+        [N_r]; ``lig``: the ligand's pose-independent features from the reference's featuriser (``lig_node_s`` [N_l,89],
+        ``lig_edge_s`` [E,20], ``lig_edge_index`` [2,E], covalent edges).  The pocket features of all poses come from one
+        ``dbfr_mdn_pocket_features`` launch, the ligand encoder runs once.  Returns mdn_score [P]."""
+        dev = atom14_poses.device
+        P, n_r = int(atom14_poses.shape[0]), int(atom14_poses.shape[1])
+        n_l = int(lig_poses.shape[1])
+        f = pocket_features(torch.as_tensor(aatype).to(dev).repeat(P), atom14_poses.reshape(P * n_r, 14, 3),
+                            res_ptr=torch.arange(P + 1) * n_r, topk=topk)
+        ei = torch.as_tensor(lig["lig_edge_index"]).to(dev).long()
+        off = (torch.arange(P, device=dev) * n_l).repeat_interleave(ei.shape[1])
+        d = dict(f, lig_node_s=torch.as_tensor(lig["lig_node_s"]).to(dev).float().repeat(P, 1),
+                 lig_edge_s=torch.as_tensor(lig["lig_edge_s"]).to(dev).float().repeat(P, 1),
+                 lig_edge_index=ei.repeat(1, P) + off, lig_pos=lig_poses.reshape(P * n_l, 3),
+                 lig_batch=torch.arange(P, device=dev).repeat_interleave(n_l))
+        lig_s = None
+        if reuse_ligand_embeddings and P > 1:
+            one = {k: (v[:n_l] if k in ("lig_node_s", "lig_pos", "lig_batch") else v) for k, v in d.items()}
+            one.update(lig_edge_s=d["lig_edge_s"][:ei.shape[1]], lig_edge_index=ei)
+            m0 = f["pro_batch"] == 0
+            e0 = f["pro_batch"][f["pro_edge_index"][1]] == 0
+            one.update(pro_node_s=f["pro_node_s"][m0], pro_node_v=f["pro_node_v"][m0], pro_seq=f["pro_seq"][m0], pro_xyz_full=f["pro_xyz_full"][m0],
+                       pro_batch=f["pro_batch"][m0], pro_edge_index=f["pro_edge_index"][:, e0], pro_edge_s=f["pro_edge_s"][e0], pro_edge_v=f["pro_edge_v"][e0])
+            _, ls, _ = self.score(one, return_embeddings=True)
+            lig_s = ls.repeat(P, 1)
+        return self.score(d, lig_s=lig_s)
 
     def forward(self, data):
         """KarmaDock.forward (KarmaDock_sc.py:58-70)."""

@@ -371,6 +371,17 @@ int dbfr_mdn_workspace_bytes(const dbfr_mdn_batch* b, size_t* bytes);
 int dbfr_mdn_forward(dbfr_mdn_model* m, const dbfr_mdn_batch* b, float* score, float* lig_s_out, float* pro_s_out,
                      void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* The pocket half of the scorer's input on the device, for n_graph pockets / poses at once: what `get_protein_feature`
+ * (DiffBindFR/scoring/dataset/protein_feature.py:137-216) computes behind its PDB parser from residue types (< 20) and
+ * atom14 coordinates with absent atoms at the origin (= dbfr_sample's atom14 output + the pocket centre): node_s [n_res,9],
+ * node_v [n_res,3,3], the topk (<= 32; the reference uses 30) nearest CA neighbours of every residue as edges j -> i grouped
+ * by i (edge_src / edge_dst / in_ptr [n_res+1]), edge_s [E,21], edge_v [E,3].  edge_ptr [n_graph+1]: first edge of every
+ * pocket, E_g = n_g * min(topk, n_g - 1) (the caller knows the residue counts).  Pockets of at most 1024 residues.        */
+int dbfr_mdn_pocket_features(int32_t n_graph, int32_t n_res, const int32_t* res_ptr, const int32_t* edge_ptr,
+                             const int32_t* aatype, const float* atom14_pos, int32_t topk, float* node_s, float* node_v,
+                             int32_t* edge_src, int32_t* edge_dst, int32_t* in_ptr, float* edge_s, float* edge_v,
+                             void* hip_stream);
+
 /* Synchronises the stream and returns the device-side status word of the last
  * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
  * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last

@@ -1005,6 +1005,51 @@ def golden_mdn():
     print("  mdn.npz:", os.path.getsize(os.path.join(HERE, "mdn.npz")) // 1024, "KiB; scores", npy(score_ref))
 
 
+
+def golden_mdn_features():
+    """f4 (featurisation, pocket half): the reference's own `get_protein_feature`
+    (DiffBindFR/scoring/dataset/protein_feature.py:137-216) on the 3DBS pocket of export.npz -- its PDB parser replaced by the
+    arrays a parser would return (Bio.PDB absent), everything behind it (openfold transforms the reference vendors, feature
+    arithmetic) the reference's code; torch_cluster.knn_graph stood in.  Asserts the oracle and freezes mdn_features.npz."""
+    print("[f4: pocket featurisation of the scorer]")
+    import importlib, importlib.util
+    from oracle import mdn_features as omf
+    if "openfold.data.data_transforms" not in sys.modules:
+        golden_chi_differ()                                        # installs the openfold stand-ins
+    tc = sys.modules["torch_cluster"]
+    tc.knn_graph = lambda x, k, **kw: omf.knn_graph(x, k)
+    importlib.import_module("openfold.np.protein")
+    spec = importlib.util.spec_from_file_location("ref_protein_feature", os.path.join(ref_shims.COPY, "DiffBindFR", "scoring", "dataset", "protein_feature.py"))
+    pf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pf)
+    z = np.load(os.path.join(HERE, "export.npz"))
+    pm = z["pocket_mask"]
+    aatype, pos37, m37 = z["aatype"][pm], z["atom37_pos"][pm].astype(np.float32), z["atom37_mask"][pm].astype(np.float32)
+    # perturbed side chains so that the centre-of-mass distances are those of a pose, and one residue without its side chain
+    rng = np.random.default_rng(3)
+    pos37 = pos37 + rng.normal(0, 0.3, pos37.shape).astype(np.float32) * (np.arange(37)[None, :, None] >= 5)
+    m37[7, 5:] = 0.0
+    pos37 = pos37 * m37[..., None]
+    obj = types.SimpleNamespace(aatype=aatype, atom_positions=pos37, atom_mask=m37, residue_index=np.arange(len(aatype)),
+                                b_factors=np.zeros_like(m37))
+    pf.protein.from_pdb_string = lambda s, c=None: obj
+    ca, xyz_full, seq, node_s, node_v, ei, edge_s, edge_v = pf.get_protein_feature("arrays instead of a PDB string", pdb_string=True)
+    a14 = torch.from_numpy(T["atom14_to_atom37"][aatype]).long()
+    pos14 = torch.from_numpy(pos37)[torch.arange(len(aatype))[:, None], a14] * torch.from_numpy(T["atom14_mask"][aatype]).float()[..., None]
+    pos14 = pos14 * torch.from_numpy(m37)[torch.arange(len(aatype))[:, None], a14][..., None]
+    close(pos14, xyz_full, 0.0, "f4feat/xyz_full == atom14 of the arrays")
+    ideal = torch.from_numpy(T["atom14_mask"][aatype]).sum(-1)
+    o = omf.pocket_features(torch.from_numpy(aatype), pos14, ideal, edge_index=ei)
+    close(o["node_s"], node_s.float(), 2e-5, "f4feat/node_s (3 distances + 6 backbone dihedral sin/cos)")
+    close(o["node_v"], node_v.float(), 2e-6, "f4feat/node_v")
+    close(o["edge_s"], edge_s.float(), 2e-5, "f4feat/edge_s (21)")
+    close(o["edge_v"], edge_v.float(), 2e-6, "f4feat/edge_v")
+    assert torch.equal(omf.knn_graph(ca, 30), ei) and torch.equal(seq, torch.from_numpy(aatype))
+    np.savez_compressed(os.path.join(HERE, "mdn_features.npz"), aatype=aatype, atom14_pos=npy(pos14), ideal_atom_count=npy(ideal),
+                        ref_node_s=npy(node_s.float()), ref_node_v=npy(node_v.float()), ref_edge_index=npy(ei),
+                        ref_edge_s=npy(edge_s.float()), ref_edge_v=npy(edge_v.float()))
+
+
 # --------------------------------------------------------------------------- boundary: the reference's REAL registry + checkpoint loader
 def _ref_function_source(path, start_marker, stop_marker):
     """Source text of one top-level function of a reference file, read at run time (never stored)."""
@@ -1141,5 +1186,6 @@ if __name__ == "__main__":
     golden_pocket_select()
     golden_chi_differ()
     golden_mdn()
+    golden_mdn_features()
     golden_boundary()           # last: swaps the stand-in registry for the reference's real one
     print("golden fixtures written to", HERE)

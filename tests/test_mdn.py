@@ -107,3 +107,100 @@ def test_gpu_scorer_refuses_cpu_tensors_and_bad_state():
     m = mdn.KarmaDockHIP()
     with pytest.raises(L.DbfrError):
         m.score(d)
+
+
+def test_oracle_pocket_features_match_reference_fixture():
+    """mdn_features.npz: the reference's own get_protein_feature on the 3DBS pocket (perturbed side chains, one residue
+    without its side chain)."""
+    from oracle import mdn_features as omf
+    z = np.load(os.path.join(GOLDEN, "mdn_features.npz"))
+    o = omf.pocket_features(torch.from_numpy(z["aatype"]), torch.from_numpy(z["atom14_pos"]), torch.from_numpy(z["ideal_atom_count"]))
+    assert torch.equal(o["edge_index"], torch.from_numpy(z["ref_edge_index"]))
+    assert (o["node_s"] - torch.from_numpy(z["ref_node_s"])).abs().max() < 2e-5
+    assert (o["node_v"] - torch.from_numpy(z["ref_node_v"])).abs().max() < 1e-6
+    assert (o["edge_s"] - torch.from_numpy(z["ref_edge_s"])).abs().max() < 1e-6
+    assert (o["edge_v"] - torch.from_numpy(z["ref_edge_v"])).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_pocket_features_match_reference_fixture_and_oracle():
+    from diffbindfr_amd import mdn
+    from oracle import mdn_features as omf
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, "mdn_features.npz"))
+    aa, x = torch.from_numpy(z["aatype"]), torch.from_numpy(z["atom14_pos"])
+    f = mdn.pocket_features(aa.to(dev), x.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(f["pro_edge_index"].cpu(), torch.from_numpy(z["ref_edge_index"]))
+    assert (f["pro_node_s"].cpu() - torch.from_numpy(z["ref_node_s"])).abs().max() < 5e-5
+    assert (f["pro_node_v"].cpu() - torch.from_numpy(z["ref_node_v"])).abs().max() < 1e-5
+    assert (f["pro_edge_s"].cpu() - torch.from_numpy(z["ref_edge_s"])).abs().max() < 1e-5
+    assert (f["pro_edge_v"].cpu() - torch.from_numpy(z["ref_edge_v"])).abs().max() < 1e-5
+    # several poses of several pockets in one launch (ragged), incl. a pocket smaller than k + 1
+    rng = np.random.default_rng(1)
+    sizes = [105, 12, 60]
+    parts, ptr = [], [0]
+    for n in sizes:
+        sel = rng.choice(105, n, replace=False)
+        sel.sort()
+        parts.append((aa[sel], x[sel] + torch.from_numpy(rng.normal(0, 0.2, (n, 14, 3))).float() * (x[sel].abs().sum(-1, keepdim=True) > 0)))
+        ptr.append(ptr[-1] + n)
+    A, X = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    f = mdn.pocket_features(A.to(dev), X.to(dev), res_ptr=ptr)
+    e0 = 0
+    T14 = torch.from_numpy(z["ideal_atom_count"])
+    for (a_, x_), n in zip(parts, sizes):
+        ideal = torch.tensor([5, 11, 8, 8, 6, 9, 9, 4, 10, 8, 8, 9, 8, 11, 7, 6, 7, 14, 12, 7])[a_]
+        o = omf.pocket_features(a_, x_, ideal)
+        ne = o["edge_index"].shape[1]
+        r0 = ptr[sizes.index(n)]
+        assert torch.equal(f["pro_edge_index"][:, e0:e0 + ne].cpu() - r0, o["edge_index"])
+        assert (f["pro_edge_s"][e0:e0 + ne].cpu() - o["edge_s"]).abs().max() < 1e-5
+        assert (f["pro_node_s"][r0:r0 + n].cpu() - o["node_s"]).abs().max() < 5e-5
+        e0 += ne
+    # the features feed the scorer directly
+    P, m = _hip_model(dev, 7)
+    d = mdn_small_batch(rng, f, ptr)
+    s = m.score(d)
+    assert torch.isfinite(s).all() and s.shape == (3,)
+
+
+def mdn_small_batch(rng, f, ptr):
+    """Ligand halves (synthetic features) for the three pockets of the test above."""
+    from tests.test_mdn_inputs import mdn_inputs
+    dev = f["pro_node_s"].device
+    lig = mdn_inputs(rng, [(8, 20), (5, 20), (11, 20)], coincident=False)
+    d = {k: v.to(dev) for k, v in lig.items() if k.startswith("lig_")}
+    d.update(f)
+    return d
+
+
+@pytest.mark.gpu
+def test_gpu_score_poses_of_one_complex_vs_oracle():
+    """P poses of one complex straight from (aatype, atom14 poses, ligand poses): device pocket features + one ligand-encoder
+    pass + the mixture head, against the oracle's featurisation + forward pose by pose."""
+    from diffbindfr_amd import mdn
+    from oracle import mdn_features as omf
+    from tests.test_mdn_inputs import mdn_inputs
+    dev = torch.device("cuda:0")
+    P_, m = _hip_model(dev, 11)
+    z = np.load(os.path.join(GOLDEN, "mdn_features.npz"))
+    rng = np.random.default_rng(2)
+    aa, x0 = torch.from_numpy(z["aatype"]), torch.from_numpy(z["atom14_pos"])
+    lig = {k: v for k, v in mdn_inputs(rng, [(17, 20)], coincident=False).items() if k in ("lig_node_s", "lig_edge_s", "lig_edge_index")}
+    n_pose = 5
+    present = (x0.abs().sum(-1, keepdim=True) > 0).float()
+    poses = torch.stack([x0 + torch.from_numpy(rng.normal(0, 0.4, x0.shape)).float() * present * (torch.arange(14)[None, :, None] >= 5) for _ in range(n_pose)])
+    ca = x0[:, 1]
+    lpos = torch.stack([ca[rng.integers(0, len(ca), 17)] + torch.from_numpy(rng.normal(0, 2.0, (17, 3))).float() for _ in range(n_pose)])
+    got = m.score_poses(lig, aa, poses.to(dev), lpos.to(dev)).cpu()
+    again = m.score_poses(lig, aa, poses.to(dev), lpos.to(dev), reuse_ligand_embeddings=False).cpu()
+    assert torch.equal(got, again)
+    ideal = torch.from_numpy(z["ideal_atom_count"])
+    for p in range(n_pose):
+        f = omf.pocket_features(aa, poses[p], ideal)
+        d = dict(lig, lig_pos=lpos[p], lig_batch=torch.zeros(17, dtype=torch.long), pro_node_s=f["node_s"], pro_node_v=f["node_v"],
+                 pro_edge_index=f["edge_index"], pro_edge_s=f["edge_s"], pro_edge_v=f["edge_v"], pro_seq=aa, pro_xyz_full=f["xyz_full"],
+                 pro_batch=torch.zeros(len(aa), dtype=torch.long))
+        ref, _, _ = oms.forward(P_, d)
+        assert abs(float(got[p]) - float(ref[0])) <= 2e-4 * max(1.0, abs(float(ref[0]))), (p, got[p], ref[0])
