@@ -9,6 +9,7 @@
 
 // ---- kernel launchers (conv.hip / graph.hip / heads.hip)
 void launch_conv(const ConvArgs& a, hipStream_t st);
+void launch_conv_layer(const ConvArgs* c4, hipStream_t st);
 void launch_conv2(const Conv2Args& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
                       const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
@@ -87,6 +88,8 @@ struct dbfr_model {
   ConvW final_conv, tor_conv, sc_conv;
   ConvW2 layer2[8][4], tor_conv2, sc_conv2;   // k_conv2 layouts of the K=144 convs
   int use_conv2;
+  int conv_fuse;       // big batches: the four convs of a layer as one k_conv grid (conv.hip: k_conv_layer)
+  int conv2_layers;    // big batches: interaction layers [0, conv2_layers) still go through k_conv2 (their short W2 favours it)
   int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
   Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
   Mlp2 tr_final, rot_final, tor_final, sc_final;
@@ -533,6 +536,8 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   // is only a few rounds of workgroups (predict.py-sized batches), k_conv (conv.hip) at bench-sized batches.
   // DBFR_CONV2 = 0 / 1 forces one of them, default -1 = by batch size
   m->use_conv2 = getenv("DBFR_CONV2") ? atoi(getenv("DBFR_CONV2")) : -1;
+  m->conv2_layers = getenv("DBFR_CONV2_LAYERS") ? atoi(getenv("DBFR_CONV2_LAYERS")) : 0;
+  m->conv_fuse = getenv("DBFR_CONV_FUSE") ? atoi(getenv("DBFR_CONV_FUSE")) : 1;
   const char* fam[4] = {"lig_conv_layers", "cross_al_conv_layers", "atom_conv_layers", "cross_la_conv_layers"};
   for (int l = 0; l < cfg->num_conv_layers && !rc; ++l)
     for (int f = 0; f < 4 && !rc; ++f)
@@ -673,10 +678,12 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   static const long multi_edges = getenv("DBFR_MULTI_EDGES") ? atol(getenv("DBFR_MULTI_EDGES")) : 512 * 1024;
   w->multi = maxcap <= multi_edges;
   w->conv2 = m->use_conv2 > 0 || (m->use_conv2 < 0 && w->multi);
-  if (w->conv2) {   // fused launches: every conv of a launch writes its own message buffer, sized by its own edge set
-    const long mc[4] = {std::max({caps[SET_LL], (long)NL, cap_t}), std::max(caps[SET_AL], cap_s), caps[SET_AA], caps[SET_LA]};
+  if (w->conv2 || m->conv2_layers > 0 || (m->conv_fuse && !w->multi)) {   // fused launches: every conv of a launch writes its own message buffer, sized by its own edge set
+    // (layers left to k_conv in the mixed mode push all four convs through msg[0])
+    const bool all_fused = w->conv2 || (m->conv_fuse && !w->multi && m->conv2_layers <= 0);
+    const long mc[4] = {all_fused ? std::max({caps[SET_LL], (long)NL, cap_t, cap_s}) : maxcap, std::max(caps[SET_AL], cap_s), caps[SET_AA], caps[SET_LA]};
     for (int i = 0; i < 4; ++i) w->msg[i] = b.take<float>((size_t)std::max(mc[i], 1L) * MAXD, i == 0 ? "msg" : nullptr);
-    w->multi = 0;
+    if (w->conv2) w->multi = 0;
   } else
   for (int i = 0; i < 4; ++i) w->msg[i] = (i == 0 || w->multi) ? b.take<float>((size_t)maxcap * MAXD, i == 0 ? "msg" : nullptr) : nullptr;
   w->gp = b.take<float>((size_t)G * 12, "gp");
@@ -814,7 +821,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     const float *lx = w.lig_x[cur], *ax = w.atom_x[cur];
     float *lnew = w.lig_x[cur ^ 1], *anew = w.atom_x[cur ^ 1];
     const EdgeSet &LL = w.set[SET_LL], &AA = w.set[SET_AA], &AL = w.set[SET_AL], &LA = w.set[SET_LA];
-    if (w.conv2) {   // all four convs of the layer in ONE persistent launch (conv2.hip)
+    if (w.conv2 || l < m->conv2_layers) {   // all four convs of the layer in ONE persistent launch (conv2.hip)
       const Conv2Desc ds[4] = {
           conv2_desc(m->layer2[l][0], LL.n_edges, LL.cap, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0]),
           conv2_desc(m->layer2[l][1], AL.n_edges, AL.cap, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[1]),
@@ -822,6 +829,35 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
           conv2_desc(m->layer2[l][3], LA.n_edges, LA.cap, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3])};
       const int Ws[4] = {m->layer[l][0].W, m->layer[l][1].W, m->layer[l][2].W, m->layer[l][3].W};
       conv2_call(m, ds, Ws, 4, st);
+      ReduceLayerArgs ra;
+      const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
+      for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
+      ra.NL = NL; ra.NA = NA; ra.D = Do; ra.D_old = Di; ra.old_l = lx; ra.old_a = ax; ra.out_l = lnew; ra.out_a = anew;
+      launch_reduce_ln_layer(ra, st);
+    } else if (m->conv_fuse && !w.multi) {   // bench-sized batches: the layer's four convs as ONE k_conv grid, one reduction launch
+      auto mk = [&](const ConvW& cw, const EdgeSet& S, const float* tab1, const int* idx1, const float* tab2, const int* idx2, const float* x, float* msg) {
+        ConvArgs a;
+        a.n_edges = S.n_edges; a.max_edges = S.cap; a.tgt = S.tgt; a.gth = S.gth; a.emb = S.emb; a.sh = S.sh; a.sh_sign = 1.f;
+        a.tab1 = tab1; a.ld1 = Di; a.idx1 = idx1; a.tab2 = tab2; a.ld2 = Di; a.idx2 = idx2; a.x = x; a.ldx = Di; a.w = cw; a.msg = msg; a.trace = nullptr;
+        return a;
+      };
+      const ConvArgs c4[4] = {mk(m->layer[l][0], LL, lx, LL.tgt, lx, LL.gth, lx, w.msg[0]), mk(m->layer[l][1], AL, lx, AL.tgt, ax, AL.gth, ax, w.msg[1]),
+                              mk(m->layer[l][2], AA, ax, AA.tgt, ax, AA.gth, ax, w.msg[2]), mk(m->layer[l][3], LA, ax, LA.tgt, lx, LA.gth, lx, w.msg[3])};
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (m->profile == 1) {
+        if (m->ev_used + 2 > m->ev.size()) {
+          size_t old = m->ev.size();
+          m->ev.resize(old + 512);
+          for (size_t i = old; i < m->ev.size(); ++i) (void)hipEventCreate(&m->ev[i]);
+        }
+        e0 = m->ev[m->ev_used++]; e1 = m->ev[m->ev_used++];
+        (void)hipEventRecord(e0, st);
+      }
+      launch_conv_layer(c4, st);
+      if (m->profile == 1) (void)hipEventRecord(e1, st);
+      if (m->profile)
+        for (int i = 0; i < 4; ++i)
+          launch_acc_flops(c4[i].n_edges, 2.0 * 144 * (144.0 + m->layer[l][i].W), 4.0 * (m->layer[l][i].W + Di + 9) + 16.0, m->flops_dev, st);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
       for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
@@ -981,7 +1017,7 @@ static int begin(dbfr_model* m, const dbfr_batch* B, void* workspace, size_t wby
     m->streams_ready = true;
   }
   HIPCHECK(hipMemsetAsync(workspace, 0, 1024, st));   // err @0, counters @256, n_edges6 @512
-  if (w->conv2) HIPCHECK(hipMemsetAsync(m->queue, 0, 16, st));   // the kernel re-arms it itself; this covers an aborted run
+  if (w->conv2 || m->conv2_layers > 0) HIPCHECK(hipMemsetAsync(m->queue, 0, 16, st));   // the kernel re-arms it itself; this covers an aborted run
   launch_set_int(w->n_edges6 + 7, B->NL, st);           // the centre set has exactly one edge per ligand atom
   launch_batch_vectors(*B, w->lig_batch, w->atm_batch, w->is_cab, w->n_cab, w->tor_batch, w->sc_batch, st);
   return DBFR_OK;

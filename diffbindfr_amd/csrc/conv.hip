@@ -39,13 +39,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TRACE_BLOCKS 1024
 #define TRACE_TILES 48
 #define TRACE_REC (2 + 3 * TRACE_TILES + 8)
-#define RSTAMP(k) do { if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * TRACE_REC + 2 + 3 * TRACE_TILES + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define TSTAMP(k) do { if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * TRACE_REC + 2 + 3 * TRACE_TILES + (k)] = __builtin_readcyclecounter(); } while (0)
+#define RSTAMP(k) do { if ((ABL & 16) && a.trace && bid < TRACE_BLOCKS && lane == 0) a.trace[((size_t)bid * 4 + wave) * TRACE_REC + 2 + 3 * TRACE_TILES + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TSTAMP(k) do { if ((ABL & 16) && a.trace && bid < TRACE_BLOCKS && lane == 0) a.trace[((size_t)bid * 4 + wave) * TRACE_REC + 2 + 3 * TRACE_TILES + (k)] = __builtin_readcyclecounter(); } while (0)
 
 // K: radial-MLP width (144 / 96); NB: 16-edge blocks per workgroup (TE = 16 NB edges share every A fragment
 // fetched from L2 -- the L2->CU fabric, not HBM, is what the weight stream loads); ABL: developer ablations.
 template <int K, int NB, int ABL>
-__global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
+__device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid) {
   constexpr int TE = 16 * NB;
   constexpr int KT = K / 16;  // 16-wide tiles along the MLP input/hidden dim
   constexpr int KS = K / 4;   // MFMA k-steps
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float ms[TE * 8];   // per edge: the symmetric traceless l=2 matrix (m00 m01 m02 m11 m12 m22) of PT_VTV
 
   const int E = min(*a.n_edges, a.max_edges);
-  if (blockIdx.x * TE >= E) return;
+  if (bid * TE >= E) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile0 = blockIdx.x * TE;
+  const int tile0 = bid * TE;
   const int ne = min(TE, E - tile0);
   int* s_gth = s_idx;
   int* s_i1 = s_gth + TE;
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
   for (int b = 0; b < NB; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
   unsigned long long* trc = nullptr;
   int trc_n = 0;
-  if ((ABL & 16) && a.trace && blockIdx.x < TRACE_BLOCKS) {
-    trc = a.trace + ((size_t)blockIdx.x * 4 + wave) * TRACE_REC;
+  if ((ABL & 16) && a.trace && bid < TRACE_BLOCKS) {
+    trc = a.trace + ((size_t)bid * 4 + wave) * TRACE_REC;
     if (lane == 0) { trc[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); trc[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20); }
   }
   const float* xs_lane = xs + n * XS_LD;      // + 16 b XS_LD per edge block (immediate offsets)
@@ -368,9 +368,34 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
   TSTAMP(5);
 }
 
+template <int K, int NB, int ABL>
+__global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
+  conv_body<K, NB, ABL>(a, blockIdx.x);
+}
+
+// The four convs of an interaction layer as ONE grid (bench-sized batches): blocks [first[c], first[c+1]) belong to conv c, so
+// the partially filled last round of one conv is topped up by the first workgroups of the next instead of idling (4 tails
+// per layer -> 1) and three launch gaps disappear.
+struct ConvLayerArgs { ConvArgs c[4]; int first[5]; };
+template <int NB>
+__global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv_layer(ConvLayerArgs a) {
+  const int b = blockIdx.x;
+  const int c = b < a.first[1] ? 0 : b < a.first[2] ? 1 : b < a.first[3] ? 2 : 3;     // uniform: scalar loads of the conv's arguments
+  conv_body<144, NB, 0>(a.c[c], b - a.first[c]);
+}
+
 #ifndef CONV_NB
 #define CONV_NB 3
 #endif
+
+void launch_conv_layer(const ConvArgs* c4, hipStream_t st) {
+  ConvLayerArgs a;
+  const int te = 16 * CONV_NB;
+  a.first[0] = 0;
+  for (int i = 0; i < 4; ++i) { a.c[i] = c4[i]; a.c[i].trace = nullptr; a.first[i + 1] = a.first[i] + (c4[i].max_edges + te - 1) / te; }
+  if (a.first[4] <= 0) return;
+  hipLaunchKernelGGL((k_conv_layer<CONV_NB>), dim3(a.first[4]), dim3(256), 0, st, a);
+}
 
 void launch_conv(const ConvArgs& a, hipStream_t st) {
   static int abl = -1;   // developer knob DBFR_CONV_ABL: 1 no contraction, 2 no W2 re-load, 8 prologue only (timing only, wrong results)

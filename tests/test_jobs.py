@@ -108,7 +108,7 @@ def _gloo_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     ddist.init(backend="gloo")
     raw, jobs = make_jobs(3, 5, 60, 10)
-    res = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 4, 1, 2], seed=11, device="cpu", batch_poses=4)
+    res = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 9, 1, 2], seed=11, device="cpu", batch_poses=4)
     q.put((rank, [(l.numpy(), a.numpy()) for l, a in res]))
     import torch.distributed as dist
     dist.barrier()
@@ -118,8 +118,10 @@ def _gloo_worker(rank, world, port, q):
 def test_run_sharded_over_gloo_world2_equals_one_rank():
     import torch.multiprocessing as mp
     raw, jobs = make_jobs(3, 5, 60, 10)
-    one = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 4, 1, 2], seed=11, device="cpu", batch_poses=4)
-    assert [tuple(l.shape) for l, _ in one] == [(p, j.n_l, 3) for p, j in zip([3, 2, 4, 1, 2], jobs)]
+    # job 2 has more poses than a batch holds: it is cut into chunks (0,4) (4,4) (8,1), each with its own random stream
+    one = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 9, 1, 2], seed=11, device="cpu", batch_poses=4)
+    assert [tuple(l.shape) for l, _ in one] == [(p, j.n_l, 3) for p, j in zip([3, 2, 9, 1, 2], jobs)]
+    assert not torch.equal(one[2][0][0], one[2][0][4])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
