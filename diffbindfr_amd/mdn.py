@@ -9,6 +9,7 @@ the scoring forward reads (``lig_encoder.*``, ``pro_encoder.*``, ``mdn_layer.*``
 """
 import ctypes as C
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -275,6 +276,38 @@ class KarmaDockHIP(nn.Module):
             _, ls, _ = self.score(one, return_embeddings=True)
             lig_s = ls.repeat(P, 1)
         return self.score(d, lig_s=lig_s)
+
+    @torch.no_grad()
+    def score_complexes(self, items, topk=30):
+        """``score_poses`` for several complexes in ONE pocket-feature launch and ONE network forward.
+        ``items``: list of (lig, aatype, atom14_poses [P_c,N_r,14,3], lig_poses [P_c,N_l,3]).  Returns list of score tensors [P_c]."""
+        dev = items[0][2].device
+        aa, x14, rp = [], [], [0]
+        L_ = {k: [] for k in ("lig_node_s", "lig_edge_s", "lig_edge_index", "lig_pos", "lig_batch")}
+        n_graph = lo = 0
+        for lig, aatype, a14, lp in items:
+            P, n_r, n_l = int(a14.shape[0]), int(a14.shape[1]), int(lp.shape[1])
+            aa.append(torch.as_tensor(aatype).to(dev).repeat(P))
+            x14.append(a14.reshape(P * n_r, 14, 3))
+            rp += [rp[-1] + n_r * (i + 1) for i in range(P)]
+            ei = torch.as_tensor(lig["lig_edge_index"]).to(dev).long()
+            L_["lig_node_s"].append(torch.as_tensor(lig["lig_node_s"]).to(dev).float().repeat(P, 1))
+            L_["lig_edge_s"].append(torch.as_tensor(lig["lig_edge_s"]).to(dev).float().repeat(P, 1))
+            L_["lig_edge_index"].append(ei.repeat(1, P) + lo + (torch.arange(P, device=dev) * n_l).repeat_interleave(ei.shape[1]))
+            L_["lig_pos"].append(lp.reshape(P * n_l, 3))
+            L_["lig_batch"].append(n_graph + torch.arange(P, device=dev).repeat_interleave(n_l))
+            lo += P * n_l
+            n_graph += P
+        rp = [0] + list(np.cumsum([int(it[2].shape[1]) for it in items for _ in range(int(it[2].shape[0]))]))
+        f = pocket_features(torch.cat(aa), torch.cat(x14), res_ptr=rp, topk=topk)
+        d = dict(f, **{k: torch.cat(v, 1 if k == "lig_edge_index" else 0) for k, v in L_.items()})
+        s = self.score(d)
+        out, g = [], 0
+        for it in items:
+            P = int(it[2].shape[0])
+            out.append(s[g:g + P])
+            g += P
+        return out
 
     def forward(self, data):
         """KarmaDock.forward (KarmaDock_sc.py:58-70)."""

@@ -196,6 +196,11 @@ def test_gpu_score_poses_of_one_complex_vs_oracle():
     got = m.score_poses(lig, aa, poses.to(dev), lpos.to(dev)).cpu()
     again = m.score_poses(lig, aa, poses.to(dev), lpos.to(dev), reuse_ligand_embeddings=False).cpu()
     assert torch.equal(got, again)
+    # several complexes in one call: same scores as one by one
+    sub = slice(10, 70)
+    many = m.score_complexes([(lig, aa, poses.to(dev), lpos.to(dev)), (lig, aa[sub], poses[:3, sub].to(dev), lpos[:3].to(dev))])
+    assert torch.equal(many[0].cpu(), got)
+    assert torch.equal(many[1].cpu(), m.score_poses(lig, aa[sub], poses[:3, sub].to(dev), lpos[:3].to(dev), reuse_ligand_embeddings=False).cpu())
     ideal = torch.from_numpy(z["ideal_atom_count"])
     for p in range(n_pose):
         f = omf.pocket_features(aa, poses[p], ideal)

@@ -38,6 +38,21 @@ for ci in range(a.complexes):
                                      synthetic.make_ligand(rng, max(4, int(round(c["n_lig"] * rng.uniform(0.85, 1.15))))), rng))
 
 
+from diffbindfr_amd import mdn  # noqa: E402
+scorer = mdn.KarmaDockHIP().to(dev)
+_g = torch.Generator().manual_seed(5)
+_sd = scorer.state_dict()
+for _k, _v in _sd.items():
+    if _v.dim() == 2:
+        _v.copy_((torch.rand(_v.shape, generator=_g) * 2 - 1) / np.sqrt(_v.shape[1]))
+scorer.load_state_dict(_sd, strict=True)
+lig_feats = []
+for r in raw:
+    ei = torch.as_tensor(r["lig_edge_index"])
+    lig_feats.append(dict(lig_node_s=torch.randn(r["lig_pos"].shape[0], 89, generator=_g), lig_edge_s=torch.randn(ei.shape[1], 20, generator=_g),
+                          lig_edge_index=ei))
+
+
 def sync():
     torch.cuda.synchronize(dev)
 
@@ -97,6 +112,19 @@ def run():
             nbytes += sum(os.path.getsize(p) for p in paths)
     t["pdb_files_s"] = time.perf_counter() - t0
     t["pdb_bytes"] = nbytes
+    # ---- row f4: the MDN scorer on the final poses, where they are (device pocket featurisation + network forward);
+    # the ligand's pose-independent features are synthetic here (the reference computes them with RDKit, once per ligand)
+    t0 = time.perf_counter()
+    g = 0
+    items = []
+    for ci, rec in enumerate(recs):
+        lt = torch.stack([res[g + i][0][-1] for i in range(a.poses)])
+        pt = torch.stack([res[g + i][1][-1] for i in range(a.poses)])
+        g += a.poses
+        items.append((lig_feats[ci], rec.sequence.clamp(max=19), pt, lt))
+    scores = scorer.score_complexes(items)
+    sync()
+    t["mdn_score_s"] = time.perf_counter() - t0
     return t
 
 
