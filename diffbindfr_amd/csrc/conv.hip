@@ -32,6 +32,9 @@
 
 #include "common.h"
 
+#ifndef CONV_PRIO
+#define CONV_PRIO 0
+#endif
 #define XS_LD (MAXD + 4)   // 172: rows 16-B aligned (ds_read_b128), 16 consecutive rows hit 16 distinct 16-B slots
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -293,6 +296,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid) {
           for (int b = 0; b < NB; ++b) asm volatile("" ::"v"(acc[b]));
           continue;
         }
+#if CONV_PRIO == 1
+        __builtin_amdgcn_s_setprio(3);
+#elif CONV_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const f32x4 v = acc[b];
@@ -327,6 +335,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#if CONV_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif CONV_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if ((ABL & 16) && trc && trc_n < TRACE_TILES) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(oacc[b][0]));

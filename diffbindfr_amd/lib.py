@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdbfr.so")
+LIB_PATH = os.environ.get("DBFR_LIB") or os.path.join(HERE, "libdbfr.so")      # DBFR_LIB: developer override (kernel variants)
 
 DBFR_OK = 0
 DBFR_ERR_CAPACITY = -3
