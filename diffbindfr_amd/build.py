@@ -21,7 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # graph/heads: every fp op rounded separately (edge-in/out decisions and the SDE update mirror the oracle's
 # operation order); conv: contraction allowed (fewer VALU slots next to the MFMAs; results are tolerance-checked)
 FILE_FLAGS = {"conv.hip": ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-array-bounds"] + ([f"-DCONV_NB={os.environ['DBFR_BUILD_NB']}"] if "DBFR_BUILD_NB" in os.environ else [])
-              + ([f"-DCONV_PRIO={os.environ['DBFR_BUILD_PRIO']}"] if "DBFR_BUILD_PRIO" in os.environ else [])}
+              + ([f"-DCONV_PRIO={os.environ['DBFR_BUILD_PRIO']}"] if "DBFR_BUILD_PRIO" in os.environ else [])
+              + ([f"-DCONV_XPF={os.environ['DBFR_BUILD_XPF']}"] if "DBFR_BUILD_XPF" in os.environ else [])}
 FILE_FLAGS["mdn.hip"] = ["-ffp-contract=off"]
 FILE_FLAGS["conv2.hip"] = ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-array-bounds"]
 DEFAULT_FP = ["-ffp-contract=off"]

@@ -35,6 +35,9 @@
 #ifndef CONV_PRIO
 #define CONV_PRIO 0
 #endif
+#ifndef CONV_XPF
+#define CONV_XPF 0
+#endif
 #define XS_LD (MAXD + 4)   // 172: rows 16-B aligned (ds_read_b128), 16 consecutive rows hit 16 distinct 16-B slots
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -301,17 +304,40 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid) {
 #elif CONV_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
+#if CONV_XPF
+        // x rows requested one edge block ahead: the LDS latency of block b+1 runs under the FMAs of block b
+        f32x4 XA[NB], XB[NB], XC[NB];
+        {
+          const f32x4* x4 = reinterpret_cast<const f32x4*>(xp);
+          XA[0] = x4[0];
+          if (VIN) { XB[0] = x4[1]; XC[0] = x4[2]; }
+        }
+#endif
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const f32x4 v = acc[b];
+#if CONV_XPF
+          if (b + 1 < NB) {
+            const f32x4* xn = reinterpret_cast<const f32x4*>(xp + 16 * (b + 1) * XS_LD);
+            XA[b + 1] = xn[0];
+            if (VIN) { XB[b + 1] = xn[1]; XC[b + 1] = xn[2]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 xa = XA[b];
+#else
           const f32x4* x4 = reinterpret_cast<const f32x4*>(xp + 16 * b * XS_LD);
           const f32x4 xa = x4[0];
+#endif
           if (!VIN) {
             const float z = v[0] * xa[0] + v[1] * xa[1] + v[2] * xa[2] + v[3] * xa[3];
             oacc[b][0] += z * S[b][0];
             if (TYPE == PT_SV) { oacc[b][1] += z * S[b][1]; oacc[b][2] += z * S[b][2]; }
           } else {
+#if CONV_XPF
+            const f32x4 xb = XB[b], xc = XC[b];
+#else
             const f32x4 xb = x4[1], xc = x4[2];   // [u0..u0+3][3] = 12 consecutive floats
+#endif
             const float z0 = v[0] * xa[0] + v[1] * xa[3] + v[2] * xb[2] + v[3] * xc[1];
             const float z1 = v[0] * xa[1] + v[1] * xb[0] + v[2] * xb[3] + v[3] * xc[2];
             const float z2 = v[0] * xa[2] + v[1] * xb[1] + v[2] * xc[0] + v[3] * xc[3];
