@@ -711,6 +711,16 @@ extern "C" int dbfr_workspace_bytes(const dbfr_model* m, const dbfr_batch* b, co
 }
 
 // ------------------------------------------------------------------------------------------------ score network
+// HIP-event pair around one fused-conv launch on its launch stream (profile mode 1)
+static void prof_events(dbfr_model* m, hipEvent_t* e0, hipEvent_t* e1) {
+  if (m->ev_used + 2 > m->ev.size()) {
+    size_t old = m->ev.size();
+    m->ev.resize(old + 512);
+    for (size_t i = old; i < m->ev.size(); ++i) (void)hipEventCreate(&m->ev[i]);
+  }
+  *e0 = m->ev[m->ev_used++]; *e1 = m->ev[m->ev_used++];
+}
+
 static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int max_edges, const int* tgt, const int* gth,
                       const float* emb, const float* sh, const float* tab1, int ld1, const int* idx1, const float* tab2,
                       int ld2, const int* idx2, const float* x, int ldx, float* msg, hipStream_t st) {
@@ -724,12 +734,7 @@ static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int ma
   const bool prof = m->profile == 1 && cw.K == 144;
   const bool count = m->profile && cw.K == 144;
   if (prof) {
-    if (m->ev_used + 2 > m->ev.size()) {
-      size_t old = m->ev.size();
-      m->ev.resize(old + 512);
-      for (size_t i = old; i < m->ev.size(); ++i) (void)hipEventCreate(&m->ev[i]);
-    }
-    e0 = m->ev[m->ev_used++]; e1 = m->ev[m->ev_used++];
+    prof_events(m, &e0, &e1);
     (void)hipEventRecord(e0, st);
   }
   launch_conv(a, st);
@@ -759,12 +764,7 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
   a.n_conv = n; a.queue = m->queue;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (m->profile == 1) {
-    if (m->ev_used + 2 > m->ev.size()) {
-      size_t old = m->ev.size();
-      m->ev.resize(old + 512);
-      for (size_t i = old; i < m->ev.size(); ++i) (void)hipEventCreate(&m->ev[i]);
-    }
-    e0 = m->ev[m->ev_used++]; e1 = m->ev[m->ev_used++];
+    prof_events(m, &e0, &e1);
     (void)hipEventRecord(e0, st);
   }
   launch_conv2(a, st);
@@ -845,12 +845,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
                               mk(m->layer[l][2], AA, ax, AA.tgt, ax, AA.gth, ax, w.msg[2]), mk(m->layer[l][3], LA, ax, LA.tgt, lx, LA.gth, lx, w.msg[3])};
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (m->profile == 1) {
-        if (m->ev_used + 2 > m->ev.size()) {
-          size_t old = m->ev.size();
-          m->ev.resize(old + 512);
-          for (size_t i = old; i < m->ev.size(); ++i) (void)hipEventCreate(&m->ev[i]);
-        }
-        e0 = m->ev[m->ev_used++]; e1 = m->ev[m->ev_used++];
+        prof_events(m, &e0, &e1);
         (void)hipEventRecord(e0, st);
       }
       launch_conv_layer(c4, st);

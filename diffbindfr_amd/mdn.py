@@ -94,13 +94,6 @@ def _put(root, name, tensor, buffer):
         m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
 
 
-def _get(data, *path):
-    cur = data
-    for p in path:
-        cur = cur[p] if isinstance(cur, dict) or not hasattr(cur, p if isinstance(p, str) else "") else getattr(cur, p)
-    return cur
-
-
 def batch_from_hetero(data):
     """The tensors ``KarmaDock.forward`` reads from its HeteroData batch (KarmaDock_sc.py:58-96) as a flat dict."""
     lig, pro = data["ligand"], data["protein"]

@@ -148,12 +148,11 @@ def test_gpu_pocket_features_match_reference_fixture_and_oracle():
     A, X = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     f = mdn.pocket_features(A.to(dev), X.to(dev), res_ptr=ptr)
     e0 = 0
-    T14 = torch.from_numpy(z["ideal_atom_count"])
     for (a_, x_), n in zip(parts, sizes):
         ideal = torch.tensor([5, 11, 8, 8, 6, 9, 9, 4, 10, 8, 8, 9, 8, 11, 7, 6, 7, 14, 12, 7])[a_]
         o = omf.pocket_features(a_, x_, ideal)
         ne = o["edge_index"].shape[1]
-        r0 = ptr[sizes.index(n)]
+        r0 = ptr[sizes.index(n)]                                   # sizes are distinct
         assert torch.equal(f["pro_edge_index"][:, e0:e0 + ne].cpu() - r0, o["edge_index"])
         assert (f["pro_edge_s"][e0:e0 + ne].cpu() - o["edge_s"]).abs().max() < 1e-5
         assert (f["pro_node_s"][r0:r0 + n].cpu() - o["node_s"]).abs().max() < 5e-5
