@@ -159,7 +159,7 @@ def load():
     lib.dbfr_mdn_workspace_bytes.argtypes = [C.POINTER(MdnBatch), C.POINTER(C.c_size_t)]
     lib.dbfr_mdn_pocket_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dbfr_mdn_forward.argtypes = [vp, C.POINTER(MdnBatch), vp, vp, vp, vp, C.c_size_t, vp]
-    if lib.dbfr_abi_version() != 1:
+    if lib.dbfr_abi_version() != 2:
         raise DbfrError("libdbfr ABI version mismatch")
     _lib = lib
     return lib

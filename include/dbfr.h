@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DBFR_ABI_VERSION 1
+#define DBFR_ABI_VERSION 2   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2 (additions only) */
 
 typedef enum {
   DBFR_OK = 0,
