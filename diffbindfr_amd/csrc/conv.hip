@@ -38,6 +38,9 @@
 #ifndef CONV_XPF
 #define CONV_XPF 0
 #endif
+#ifndef CONV_NB2_WAVES
+#define CONV_NB2_WAVES 2     // developer: 3 = three 32-edge workgroups per CU (needs <= 168 VGPRs)
+#endif
 #define XS_LD (MAXD + 4)   // 172: rows 16-B aligned (ds_read_b128), 16 consecutive rows hit 16 distinct 16-B slots
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -408,7 +411,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid) {
 }
 
 template <int K, int NB, int ABL>
-__global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
+__global__ __launch_bounds__(256, (NB > 3 ? 1 : NB == 2 ? CONV_NB2_WAVES : 2)) void k_conv(ConvArgs a) {
   conv_body<K, NB, ABL>(a, blockIdx.x);
 }
 
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv(ConvArgs a) {
 // per layer -> 1) and three launch gaps disappear.
 struct ConvLayerArgs { ConvArgs c[4]; int first[5]; };
 template <int NB>
-__global__ __launch_bounds__(256, (NB > 3 ? 1 : 2)) void k_conv_layer(ConvLayerArgs a) {
+__global__ __launch_bounds__(256, (NB > 3 ? 1 : NB == 2 ? CONV_NB2_WAVES : 2)) void k_conv_layer(ConvLayerArgs a) {
   const int b = blockIdx.x;
   const int c = b < a.first[1] ? 0 : b < a.first[2] ? 1 : b < a.first[3] ? 2 : 3;     // uniform: scalar loads of the conv's arguments
   conv_body<144, NB, 0>(a.c[c], b - a.first[c]);
