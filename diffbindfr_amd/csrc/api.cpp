@@ -673,11 +673,14 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   w->c_tgt = b.take<int>(NL); w->c_gth = b.take<int>(NL); w->c_dist = b.take<float>(NL); w->c_sh = b.take<float>((size_t)NL * SH_LD, "center.sh");
   w->c_emb = b.take<float>((size_t)NL * NS, "center.emb"); w->c_row_start = b.take<int>(G); w->c_row_cnt = b.take<int>(G);
   w->c_n = w->n_edges6 ? w->n_edges6 + 6 : nullptr;
-  // small batches: one message buffer per concurrent conv (4 independent convs per layer run on 4 streams so that
-  // launches of a few hundred workgroups still fill 256 CUs); large batches: one buffer, one stream
-  static const long multi_edges = getenv("DBFR_MULTI_EDGES") ? atol(getenv("DBFR_MULTI_EDGES")) : 512 * 1024;
+  // Which conv path a call takes (measured on MI355X, tools/latency_run.py):
+  //   largest edge set <= 128 k edges (predict.py-sized batches: 1 complex x 4 poses, -bs 16): persistent k_conv2, one launch per layer;
+  //   above: k_conv_layer (the four convs of a layer as one k_conv grid) -- faster than k_conv2 from ~40 poses on and faster than
+  //   the former four-streams-per-layer mode at every size (that mode is kept behind DBFR_MULTI_EDGES for comparison only).
+  static const long multi_edges = getenv("DBFR_MULTI_EDGES") ? atol(getenv("DBFR_MULTI_EDGES")) : 0;
+  static const long conv2_edges = getenv("DBFR_CONV2_EDGES") ? atol(getenv("DBFR_CONV2_EDGES")) : 128 * 1024;
   w->multi = maxcap <= multi_edges;
-  w->conv2 = m->use_conv2 > 0 || (m->use_conv2 < 0 && w->multi);
+  w->conv2 = m->use_conv2 > 0 || (m->use_conv2 < 0 && maxcap <= conv2_edges);
   if (w->conv2 || m->conv2_layers > 0 || (m->conv_fuse && !w->multi)) {   // fused launches: every conv of a launch writes its own message buffer, sized by its own edge set
     // (layers left to k_conv in the mixed mode push all four convs through msg[0])
     const bool all_fused = w->conv2 || (m->conv_fuse && !w->multi && m->conv2_layers <= 0);
