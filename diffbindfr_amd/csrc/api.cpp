@@ -11,6 +11,7 @@
 void launch_conv(const ConvArgs& a, hipStream_t st);
 void launch_conv_layer(const ConvArgs* c4, hipStream_t st);
 void launch_conv2(const Conv2Args& a, hipStream_t st);
+void launch_conv2s(const Conv2Args& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
                       const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
 struct ReduceLayerArgs {
@@ -81,6 +82,13 @@ static thread_local std::string g_err;
 void dbfr_set_error(const std::string& s) { g_err = s; }
 static int fail(int code, const std::string& s) { g_err = s; return code; }
 
+// DBFR_GEMM = f32 | split: which matrix instruction carries the 144 x W GEMM of the K=144 convs (dbfr_model_set_gemm overrides)
+static int gemm_from_env() {
+  const char* e = getenv("DBFR_GEMM");
+  if (!e || !*e) return DBFR_GEMM_DEFAULT;
+  return (!strcmp(e, "split") || !strcmp(e, "1")) ? DBFR_GEMM_SPLIT_BF16 : DBFR_GEMM_F32;
+}
+
 struct dbfr_model {
   dbfr_model_cfg cfg;
   std::vector<void*> allocs;
@@ -88,6 +96,7 @@ struct dbfr_model {
   ConvW final_conv, tor_conv, sc_conv;
   ConvW2 layer2[8][4], tor_conv2, sc_conv2;   // k_conv2 layouts of the K=144 convs
   int use_conv2;
+  int gemm_split;      // 1: the 144 x W GEMM of the K=144 convs runs on the bf16 matrix pipe with 3-piece operands (conv2s.hip), any batch size
   int conv_fuse;       // big batches: the four convs of a layer as one k_conv grid (conv.hip: k_conv_layer)
   int conv2_layers;    // big batches: interaction layers [0, conv2_layers) still go through k_conv2 (their short W2 favours it)
   int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
@@ -458,6 +467,27 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   o->W1p = base.W1p; o->b1 = base.b1;
   o->W2q = upload(m, w2q, &rc);
   o->b2q = upload(m, b2q, &rc);
+  {   // the same fragments cut into three bf16 pieces (conv2s.hip).  Per tile: [3 pieces][4 k-steps of 32][64][8] -- step s = fp32
+      // k-steps 2s and 2s+1 of the same lane -- then [3 pieces][64][4] for the last 16 k (fp32 k-step 8)
+    const size_t tile_h = 13824 / 2, tail_off = 12288 / 2;
+    std::vector<uint16_t> w2s((size_t)n_tiles * tile_h, 0);
+    for (int t = 0; t < n_tiles; ++t)
+      for (int s4 = 0; s4 < KT; ++s4)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q) {
+            const float v = w2q[(((size_t)t * KT + s4) * 64 + lane) * 4 + q];
+            const uint16_t p0 = dbfr_bf16_rne(v);
+            const float r1 = v - dbfr_bf16_to_f32(p0);
+            const uint16_t p1 = dbfr_bf16_rne(r1);
+            const uint16_t p2 = dbfr_bf16_rne(r1 - dbfr_bf16_to_f32(p1));
+            const uint16_t pc[3] = {p0, p1, p2};
+            for (int i = 0; i < 3; ++i) {
+              if (s4 < 8) w2s[t * tile_h + ((size_t)(i * 4 + (s4 >> 1)) * 64 + lane) * 8 + 4 * (s4 & 1) + q] = pc[i];
+              else w2s[t * tile_h + tail_off + ((size_t)i * 64 + lane) * 4 + q] = pc[i];
+            }
+          }
+    o->W2s = upload(m, w2s, &rc);
+  }
   o->runs = upload(m, runs, &rc);
   // contiguous group ranges of near-equal tile count for S = 1, 2, 4, 8
   const int n_g = (int)groups.size();
@@ -475,6 +505,13 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   }
   return rc;
 }
+
+extern "C" int dbfr_model_set_gemm(dbfr_model* m, int32_t mode) {
+  if (!m || (mode != DBFR_GEMM_F32 && mode != DBFR_GEMM_SPLIT_BF16)) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
+  m->gemm_split = mode;
+  return DBFR_OK;
+}
+extern "C" int dbfr_model_get_gemm(const dbfr_model* m) { return m ? m->gemm_split : DBFR_ERR_ARG; }
 
 extern "C" int dbfr_abi_version(void) { return DBFR_ABI_VERSION; }
 #ifndef DBFR_BUILD_ID
@@ -536,6 +573,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   // is only a few rounds of workgroups (predict.py-sized batches), k_conv (conv.hip) at bench-sized batches.
   // DBFR_CONV2 = 0 / 1 forces one of them, default -1 = by batch size
   m->use_conv2 = getenv("DBFR_CONV2") ? atoi(getenv("DBFR_CONV2")) : -1;
+  m->gemm_split = gemm_from_env();
   m->conv2_layers = getenv("DBFR_CONV2_LAYERS") ? atoi(getenv("DBFR_CONV2_LAYERS")) : 0;
   m->conv_fuse = getenv("DBFR_CONV_FUSE") ? atoi(getenv("DBFR_CONV_FUSE")) : 1;
   const char* fam[4] = {"lig_conv_layers", "cross_al_conv_layers", "atom_conv_layers", "cross_la_conv_layers"};
@@ -680,7 +718,7 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   static const long multi_edges = getenv("DBFR_MULTI_EDGES") ? atol(getenv("DBFR_MULTI_EDGES")) : 0;
   static const long conv2_edges = getenv("DBFR_CONV2_EDGES") ? atol(getenv("DBFR_CONV2_EDGES")) : 128 * 1024;
   w->multi = maxcap <= multi_edges;
-  w->conv2 = m->use_conv2 > 0 || (m->use_conv2 < 0 && maxcap <= conv2_edges);
+  w->conv2 = m->gemm_split || m->use_conv2 > 0 || (m->use_conv2 < 0 && maxcap <= conv2_edges);
   if (w->conv2 || m->conv2_layers > 0 || (m->conv_fuse && !w->multi)) {   // fused launches: every conv of a launch writes its own message buffer, sized by its own edge set
     // (layers left to k_conv in the mixed mode push all four convs through msg[0])
     const bool all_fused = w->conv2 || (m->conv_fuse && !w->multi && m->conv2_layers <= 0);
@@ -770,7 +808,8 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     prof_events(m, &e0, &e1);
     (void)hipEventRecord(e0, st);
   }
-  launch_conv2(a, st);
+  if (m->gemm_split) launch_conv2s(a, st);
+  else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);
   if (m->profile)
     for (int i = 0; i < n; ++i)
@@ -1015,7 +1054,7 @@ static int begin(dbfr_model* m, const dbfr_batch* B, void* workspace, size_t wby
     m->streams_ready = true;
   }
   HIPCHECK(hipMemsetAsync(workspace, 0, 1024, st));   // err @0, counters @256, n_edges6 @512
-  if (w->conv2 || m->conv2_layers > 0) HIPCHECK(hipMemsetAsync(m->queue, 0, 16, st));   // the kernel re-arms it itself; this covers an aborted run
+  if (w->conv2 || m->gemm_split || m->conv2_layers > 0) HIPCHECK(hipMemsetAsync(m->queue, 0, 16, st));   // the kernel re-arms it itself; this covers an aborted run
   launch_set_int(w->n_edges6 + 7, B->NL, st);           // the centre set has exactly one edge per ligand atom
   launch_batch_vectors(*B, w->lig_batch, w->atm_batch, w->is_cab, w->n_cab, w->tor_batch, w->sc_batch, st);
   return DBFR_OK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -79,6 +80,7 @@ struct ConvW2 {
   const float* b1;
   const float* W2q;   // [n_tiles][K/16][64][4]
   const float* b2q;   // [n_tiles*16]
+  const void* W2s;    // [n_tiles] x 13824 B: W2q cut into three bf16 pieces for k_conv2s (conv2s.hip; layout: api.cpp pack_conv2)
   const RunDesc* runs;    // meta bit 20: run reads the second x layout; x offsets already mapped to the LDS row
   int part_run[4][9];     // part_run[si][p] = first run of part p when the conv is cut into 1 << si parts
 };
@@ -102,6 +104,19 @@ struct Conv2Args {
   int run_barrier, no_split;   // developer knobs (launch_conv2)
   int skew;                    // start delay of the second half of the waves, in 512-cycle sleeps
 };
+
+static inline uint16_t dbfr_bf16_rne(float x) {   // round-to-nearest-even fp32 -> bf16 (finite inputs)
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float dbfr_bf16_to_f32(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
 
 struct Mlp2 {              // SimpleLinear: Linear(in,hid) -> act -> Linear(hid,out)
   int in, hid, out;

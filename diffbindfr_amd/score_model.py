@@ -111,6 +111,9 @@ class TensorProductModelHIP(nn.Module):
         assert g("task", "struct_gen") == "struct_gen", "only the score-matching task is on this path"
         assert not g("use_second_order_repr", False), "use_second_order_repr=True is not supported"
         self.no_sc_torsion = bool(g("no_sc_torsion", False))
+        # which matrix instruction carries the radial MLP's big GEMM: None = the library's default (or $DBFR_GEMM),
+        # "f32" = v_mfma_f32_16x16x4_f32, "split" = three bf16 pieces per fp32 operand on v_mfma_f32_16x16x32_bf16 (include/dbfr.h)
+        self.gemm = g("gemm", None)
         ns, nv = int(g("ns", 48)), int(g("nv", 12))
         se, de = int(g("sigma_embed_dim", 32)), int(g("distance_embed_dim", 32))
         self.ns = ns
@@ -223,8 +226,21 @@ class TensorProductModelHIP(nn.Module):
         h = C.c_void_p()
         with torch.cuda.device(idx):            # the library allocates on the current device
             L.check(lib.dbfr_model_create(C.byref(self.mcfg), arr, len(sd), C.byref(h)))
+        if self.gemm is not None:
+            L.check(lib.dbfr_model_set_gemm(h, {"f32": 0, "split": 1}[self.gemm]))
         self._handles[idx] = (fp, h)
         return h
+
+    def set_gemm(self, mode):
+        """Switch the GEMM mode ("f32" | "split" | None = library default at the next re-pack) of this model on every device."""
+        assert mode in (None, "f32", "split")
+        self.gemm = mode
+        if mode is not None:
+            for _, h in self._handles.values():
+                L.check(L.load().dbfr_model_set_gemm(h, {"f32": 0, "split": 1}[mode]))
+
+    def gemm_mode(self, device=None):
+        return "split" if L.load().dbfr_model_get_gemm(self.handle(device)) == 1 else "f32"
 
     def workspace(self, batch, device):
         lib = L.load()

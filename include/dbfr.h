@@ -388,6 +388,20 @@ int dbfr_mdn_pocket_features(int32_t n_graph, int32_t n_res, const int32_t* res_
  * step in the order {lig, atom, cross, center, tor, sc_tor, 0, 0}.                */
 int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 
+/* Which matrix instruction carries the 144 x W GEMM of the radial MLP (97-99 % of the arithmetic) in the K=144 convs.
+ * Both produce fp32 results from fp32 weights and fp32 activations:
+ *   DBFR_GEMM_F32         v_mfma_f32_16x16x4_f32 (fp32 operands), k_conv / k_conv2;
+ *   DBFR_GEMM_SPLIT_BF16  every operand cut into three bf16 pieces (a = a1 + a2 + a3 exactly), the six partial products
+ *                         with i + j <= 4 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (k_conv2s, csrc/conv2s.hip):
+ *                         measured error vs fp64 one third of the fp32 instruction's, 2.4x less matrix-pipe time.
+ * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split) says otherwise.
+ * Set it before the first dbfr_workspace_bytes of a batch: a workspace is laid out for the mode it was sized in.      */
+#define DBFR_GEMM_F32 0
+#define DBFR_GEMM_SPLIT_BF16 1
+#define DBFR_GEMM_DEFAULT DBFR_GEMM_F32
+int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
+int dbfr_model_get_gemm(const dbfr_model* model);
+
 /* ---- introspection / test hooks */
 int         dbfr_abi_version(void);
 /* First 16 hex digits of the sha256 over the library's source files at build time (diffbindfr_amd/build.py:
