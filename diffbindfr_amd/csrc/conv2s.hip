@@ -36,6 +36,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define C3_TILE_BYTES 13824         // [3 pieces][4 k-steps of 32][64 lanes][8 bf16] + [3 pieces][64 lanes][4 bf16] (the last 16 k)
 #define C3_TAIL_OFF 12288
+#define SB_CROSS 0x086              // sched_barrier mask: VALU, SALU and LDS instructions may cross (MFMA and VMEM may not)
 
 // two fp32 values -> three words of packed bf16 pairs (low half = x0's piece): x = p0 + p1 + p2 exactly, every piece rounded
 // to nearest even by v_cvt_pk_bf16_f32
@@ -222,6 +223,74 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
     // burst, then both in their contraction, the matrix pipe idle).  The second-dispatched half starts its tiles a
     // fraction of a tile late; the offset then persists (a wave that contracts lets its partner run at full rate)
     if (wave >= NW / 2) for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(8);
+    // One wave issues a v_mfma_f32_16x16x32_bf16 every ~17 cycles whatever its SIMD partner does (two waves of a SIMD
+    // run their MFMAs side by side at that rate each: tools/exp/mfma_dep.hip), so matrix time and contraction time of
+    // a wave ADD unless the wave itself interleaves them.  The tile is therefore taken block by block,
+    //     pass(block 0, tile i)    with   contraction(block 1, tile i-1)   in its issue gaps
+    //     pass(block 1, tile i)    with   contraction(block 0, tile i)
+    // and the interleaving is written out by hand: the contraction is a list of micro-operations (one LDS read group,
+    // then single FMAs), operation k sits behind MFMA k + 4 of the 30 of a pass, and a scheduling barrier after every
+    // slot keeps hipcc from re-clustering them (left alone it moves all vector work behind, or in front of, the MFMAs).
+    // The W2 re-loads sit behind the last MFMA that reads the registers they overwrite.
+    f32x4 acc[2];
+    auto pass = [&](auto bc, auto last_c, int tn, auto&& op) {
+      constexpr int b = decltype(bc)::value;
+      constexpr bool RELOAD = decltype(last_c)::value && !(ABL & 2);   // block 1 is the last reader of the tile's fragments
+#define SLOT(m) do { op(std::integral_constant<int, (m) - 4>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
+      op(std::integral_constant<int, 0>{});                            // the LDS reads of the travelling contraction
+      __builtin_amdgcn_sched_barrier(0);
+      acc[b] = bias_n;
+      auto step = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const bf16x8 a0 = A[0][s], a1 = A[1][s], a2 = A[2][s];
+        // the six partial products with i + j <= 4, smallest first
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, Bh[b][0][s]), acc[b], 0, 0, 0); SLOT(6 * s + 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[b][1][s]), acc[b], 0, 0, 0); SLOT(6 * s + 1);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[b][2][s]), acc[b], 0, 0, 0); SLOT(6 * s + 2);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[b][0][s]), acc[b], 0, 0, 0); SLOT(6 * s + 3);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[b][1][s]), acc[b], 0, 0, 0); SLOT(6 * s + 4);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[b][0][s]), acc[b], 0, 0, 0);
+        if (RELOAD) {
+          if (s == 0) bias_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB, tn * 64, 0));
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            A[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, tn * C3_TILE_BYTES + (i * 4 + s) * 1024, 0));
+        }
+        SLOT(6 * s + 5);
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+      // k = 128..143 on v_mfma_f32_16x16x16_bf16 (two-register operands).
+      // Hazard (found the hard way, MI355X + ROCm 7.2): an x16 MFMA that takes as SrcC an accumulator an x32 MFMA has just
+      // written reads stale data -- hipcc pads nothing between the two opcodes (wrong, timing-dependent results; either
+      // opcode alone chains cleanly, tools/exp/mfma_x16_chain.hip).  16 wait states put any pass count behind us.
+      asm volatile("s_nop 15");
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const s16x4 a0 = At[0], a1 = At[1], a2 = At[2];
+#define TB(i) __builtin_bit_cast(s16x4, Bt[b][i])
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, TB(0), acc[b], 0, 0, 0); SLOT(24);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(1), acc[b], 0, 0, 0); SLOT(25);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(2), acc[b], 0, 0, 0); SLOT(26);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(0), acc[b], 0, 0, 0); SLOT(27);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(1), acc[b], 0, 0, 0); SLOT(28);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(0), acc[b], 0, 0, 0);
+#undef TB
+        if (RELOAD) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            At[i] = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rW, vT, tn * C3_TILE_BYTES + C3_TAIL_OFF + i * 512, 0));
+        }
+        SLOT(29);
+      }
+#undef SLOT
+    };
+    auto no_op = [](auto) {};
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    __builtin_amdgcn_sched_barrier(0);
+    if (r_begin < r_end) pass(B0{}, std::false_type{}, 0, no_op);   // block 0 of the part's first tile
+    __builtin_amdgcn_sched_barrier(0);
     for (int r = r_begin; r < r_end; ++r) {
       const RunDesc rd = d.w.runs[r];
       const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
@@ -255,138 +324,84 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
             for (int k = 0; k < NSV; ++k) S[b][k] = sp[k];
           }
         }
+        // the contraction of one edge block as micro-operations: K = 0 the LDS reads, K >= 1 one FMA each (K beyond the
+        // type's count: nothing).  State lives in cx* / cz* between the operations of one contraction.
+        f32x4 cxa, cxb, cxc, cma;
+        float2 cmb;
+        float cz0, cz1, cz2;
+        auto cop = [&](auto bc, auto kc, const float* xp) {
+          constexpr int b = decltype(bc)::value;
+          constexpr int K = decltype(kc)::value;
+          if (ABL & 1) { if (K == 1) asm volatile("" ::"v"(acc[b])); return; }
+          const f32x4 v = acc[b];
+          if (K == 0) {
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(xp + 16 * b * C2_XLD);
+            cxa = x4[0];
+            if (VIN) { cxb = x4[1]; cxc = x4[2]; }   // [u0..u0+3][3] = 12 consecutive floats
+            if (TYPE == PT_VTV) {                      // symmetric traceless matrix of the l=2 harmonics
+              cma = *reinterpret_cast<const f32x4*>(ms + (16 * b + n) * 8);
+              cmb = *reinterpret_cast<const float2*>(ms + (16 * b + n) * 8 + 4);
+            }
+          }
+          if (!VIN) {
+            if (K == 1) cz0 = v[0] * cxa[0];
+            if (K == 2) cz0 += v[1] * cxa[1];
+            if (K == 3) cz0 += v[2] * cxa[2];
+            if (K == 4) cz0 += v[3] * cxa[3];
+            if (K == 5) oacc[b][0] += cz0 * S[b][0];
+            if (TYPE == PT_SV) {
+              if (K == 6) oacc[b][1] += cz0 * S[b][1];
+              if (K == 7) oacc[b][2] += cz0 * S[b][2];
+            }
+          } else {
+            if (K == 1) cz0 = v[0] * cxa[0];
+            if (K == 2) cz1 = v[0] * cxa[1];
+            if (K == 3) cz2 = v[0] * cxa[2];
+            if (K == 4) cz0 += v[1] * cxa[3];
+            if (K == 5) cz1 += v[1] * cxb[0];
+            if (K == 6) cz2 += v[1] * cxb[1];
+            if (K == 7) cz0 += v[2] * cxb[2];
+            if (K == 8) cz1 += v[2] * cxb[3];
+            if (K == 9) cz2 += v[2] * cxc[0];
+            if (K == 10) cz0 += v[3] * cxc[1];
+            if (K == 11) cz1 += v[3] * cxc[2];
+            if (K == 12) cz2 += v[3] * cxc[3];
+            if (TYPE == PT_VS) {
+              if (K == 13) oacc[b][0] += cz0 * S[b][0];
+              if (K == 14) oacc[b][1] += cz1 * S[b][0];
+              if (K == 15) oacc[b][2] += cz2 * S[b][0];
+            } else if (TYPE == PT_VVS) {
+              if (K == 13) oacc[b][0] += cz0 * S[b][0];
+              if (K == 14) oacc[b][0] += cz1 * S[b][1];
+              if (K == 15) oacc[b][0] += cz2 * S[b][2];
+            } else if (TYPE == PT_VVV) {
+              if (K == 13) oacc[b][0] += cz1 * S[b][2];
+              if (K == 14) oacc[b][1] += cz2 * S[b][0];
+              if (K == 15) oacc[b][2] += cz0 * S[b][1];
+              if (K == 16) oacc[b][0] -= cz2 * S[b][1];
+              if (K == 17) oacc[b][1] -= cz0 * S[b][2];
+              if (K == 18) oacc[b][2] -= cz1 * S[b][0];
+            } else {   // PT_VTV
+              if (K == 13) oacc[b][0] += cma[0] * cz0;
+              if (K == 14) oacc[b][1] += cma[1] * cz0;
+              if (K == 15) oacc[b][2] += cma[2] * cz0;
+              if (K == 16) oacc[b][0] += cma[1] * cz1;
+              if (K == 17) oacc[b][1] += cma[3] * cz1;
+              if (K == 18) oacc[b][2] += cmb.x * cz1;
+              if (K == 19) oacc[b][0] += cma[2] * cz2;
+              if (K == 20) oacc[b][1] += cmb.x * cz2;
+              if (K == 21) oacc[b][2] += cmb.y * cz2;
+            }
+          }
+        };
         const float* xp = xs_lane + xo;
         for (int i = 0; i < nt; ++i, xp += x_step) {
           const int t = tile0 + i;
           const int tn = t < t_last ? t + 1 : t;
-          f32x4 acc[2];
           if (RB >= 2) __builtin_amdgcn_s_barrier();
-          acc[0] = bias_n; acc[1] = bias_n;
-          bias_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB, tn * 64, 0));
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const bf16x8 a0 = A[0][s], a1 = A[1][s], a2 = A[2][s];
-            // the six partial products with i + j <= 4, smallest first; two independent accumulator chains
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, Bh[0][0][s]), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, Bh[1][0][s]), acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[0][1][s]), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[1][1][s]), acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[0][2][s]), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[1][2][s]), acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[0][0][s]), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[1][0][s]), acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[0][1][s]), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[1][1][s]), acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[0][0][s]), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[1][0][s]), acc[1], 0, 0, 0);
-            // pin the re-loads BEHIND the last MFMA that reads these registers (one fragment set, no spills)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              if (!(ABL & 2)) A[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, tn * C3_TILE_BYTES + (i * 4 + s) * 1024, 0));
-          }
-          if (ABL & 8) {   // developer: the last 16 k on the x32 instruction with zero-padded operands
-            bf16x8 ta[3], tb[2][3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              const u32x2 av = __builtin_bit_cast(u32x2, At[i]);
-              ta[i] = __builtin_bit_cast(bf16x8, (u32x4){av[0], av[1], 0u, 0u});
-#pragma unroll
-              for (int b = 0; b < 2; ++b) tb[b][i] = __builtin_bit_cast(bf16x8, (u32x4){Bt[b][i][0], Bt[b][i][1], 0u, 0u});
-            }
-            const int oi[6] = {2, 1, 0, 1, 0, 0}, oj[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-              for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta[oi[q]], tb[b][oj[q]], acc[b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              At[i] = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rW, vT, tn * C3_TILE_BYTES + C3_TAIL_OFF + i * 512, 0));
-          } else if (ABL & 16) {   // developer: the x16 chain in its own accumulators
-            const s16x4 a0 = At[0], a1 = At[1], a2 = At[2];
-            f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-#define TB(b, i) __builtin_bit_cast(s16x4, Bt[b][i])
-            t0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, TB(0, 0), t0, 0, 0, 0);
-            t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, TB(1, 0), t1, 0, 0, 0);
-            t0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(0, 1), t0, 0, 0, 0);
-            t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(1, 1), t1, 0, 0, 0);
-            t0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(0, 2), t0, 0, 0, 0);
-            t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(1, 2), t1, 0, 0, 0);
-            t0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(0, 0), t0, 0, 0, 0);
-            t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(1, 0), t1, 0, 0, 0);
-            t0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(0, 1), t0, 0, 0, 0);
-            t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(1, 1), t1, 0, 0, 0);
-            t0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(0, 0), t0, 0, 0, 0);
-            t1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(1, 0), t1, 0, 0, 0);
-#undef TB
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              At[i] = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rW, vT, tn * C3_TILE_BYTES + C3_TAIL_OFF + i * 512, 0));
-            acc[0] += t0; acc[1] += t1;
-          } else {   // k = 128..143 on v_mfma_f32_16x16x16_bf16 (two-register operands).
-            // Hazard (found the hard way, MI355X + ROCm 7.2): an x16 MFMA that takes as SrcC an accumulator an x32 MFMA has just
-            // written reads stale data -- hipcc pads nothing between the two opcodes (wrong, timing-dependent results; the same
-            // chain is clean when either opcode is used alone, tools/exp/mfma_x16_chain.hip).  16 wait states and the acc[0] chain
-            // first (its last x32 write is six MFMAs old) put any pass count behind us; costs < 1 % of a tile.
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15");
-            __builtin_amdgcn_sched_barrier(0);
-            const s16x4 a0 = At[0], a1 = At[1], a2 = At[2];
-#define TB(b, i) __builtin_bit_cast(s16x4, Bt[b][i])
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, TB(b, 0), acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(b, 1), acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(b, 2), acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(b, 0), acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(b, 1), acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(b, 0), acc[b], 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-#undef TB
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              if (!(ABL & 2)) At[i] = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rW, vT, tn * C3_TILE_BYTES + C3_TAIL_OFF + i * 512, 0));
-          }
-          if (ABL & 1) {
-            asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
-            continue;
-          }
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const f32x4 v = acc[b];
-            const f32x4* x4 = reinterpret_cast<const f32x4*>(xp + 16 * b * C2_XLD);
-            const f32x4 xa = x4[0];
-            if (!VIN) {
-              const float z = v[0] * xa[0] + v[1] * xa[1] + v[2] * xa[2] + v[3] * xa[3];
-              oacc[b][0] += z * S[b][0];
-              if (TYPE == PT_SV) { oacc[b][1] += z * S[b][1]; oacc[b][2] += z * S[b][2]; }
-            } else {
-              const f32x4 xb = x4[1], xc = x4[2];   // [u0..u0+3][3] = 12 consecutive floats
-              const float z0 = v[0] * xa[0] + v[1] * xa[3] + v[2] * xb[2] + v[3] * xc[1];
-              const float z1 = v[0] * xa[1] + v[1] * xb[0] + v[2] * xb[3] + v[3] * xc[2];
-              const float z2 = v[0] * xa[2] + v[1] * xb[1] + v[2] * xc[0] + v[3] * xc[3];
-              if (TYPE == PT_VS) {
-                oacc[b][0] += z0 * S[b][0]; oacc[b][1] += z1 * S[b][0]; oacc[b][2] += z2 * S[b][0];
-              } else if (TYPE == PT_VVS) {
-                oacc[b][0] += z0 * S[b][0] + z1 * S[b][1] + z2 * S[b][2];
-              } else if (TYPE == PT_VVV) {
-                oacc[b][0] += z1 * S[b][2] - z2 * S[b][1];
-                oacc[b][1] += z2 * S[b][0] - z0 * S[b][2];
-                oacc[b][2] += z0 * S[b][1] - z1 * S[b][0];
-              } else {   // PT_VTV: symmetric traceless matrix of the l=2 harmonics
-                const f32x4 ma = *reinterpret_cast<const f32x4*>(ms + (16 * b + n) * 8);
-                const float2 mb = *reinterpret_cast<const float2*>(ms + (16 * b + n) * 8 + 4);
-                oacc[b][0] += ma[0] * z0 + ma[1] * z1 + ma[2] * z2;
-                oacc[b][1] += ma[1] * z0 + ma[3] * z1 + mb.x * z2;
-                oacc[b][2] += ma[2] * z0 + mb.x * z1 + mb.y * z2;
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
+          pass(B1{}, std::true_type{}, tn, [&](auto kc) { cop(B0{}, kc, xp); });
+          // block 0 of the NEXT tile, whichever run it belongs to (behind the part's last tile: computed, never used)
+          pass(B0{}, std::false_type{}, 0, [&](auto kc) { cop(B1{}, kc, xp); });
         }
         if (flags & 2) {   // last run of the channel group: this lane owns msg[e][oo .. oo + (VOUT ? 3 : 1))
           if (oo < D_out) {
