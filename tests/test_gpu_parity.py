@@ -4,6 +4,7 @@
      BASELINE.json shapes (SE(3) equivariance of the scores, graph-permutation invariance).
 Tolerances (fp32 path, stated per test): scores relative 1e-4 of the per-output max (achieved
 ~1e-6); poses 1e-3 A after 20 steps (achieved ~2e-4 A)."""
+import contextlib
 import copy
 import ctypes as C
 
@@ -43,6 +44,24 @@ def hip_scores(model, d, dev):
     return model(namespace_to(d, dev))
 
 
+@contextlib.contextmanager
+def gemm(model, mode):
+    """Run a block with the radial MLP's big GEMM on the fp32 matrix instruction ("f32": k_conv / k_conv2) or on the bf16 one
+    with three-piece operands ("split": k_conv2s, the library default); include/dbfr.h: dbfr_model_set_gemm."""
+    before = model.gemm
+    model.set_gemm(mode)
+    try:
+        yield
+    finally:
+        model.set_gemm(before if before is not None else "split")
+
+
+@pytest.fixture(params=["split", "f32"])
+def both_gemms(request, setup):
+    with gemm(setup[2], request.param):
+        yield request.param
+
+
 def test_native_library_is_loaded(setup):
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
@@ -53,7 +72,7 @@ def test_native_library_is_loaded(setup):
 
 
 @pytest.mark.parametrize("step", [0, 10, 19])
-def test_scores_match_reference_fixture(setup, dev, step):
+def test_scores_match_reference_fixture(setup, dev, step, both_gemms):
     mcfg, params, model = setup
     d, z = load_golden_batch()
     sc = osched.step_scalars(osched.default_sample_cfg(), step)
@@ -62,7 +81,7 @@ def test_scores_match_reference_fixture(setup, dev, step):
         assert rel_err(a, torch.from_numpy(z[f"score_{nm}_{step}"])) < SCORE_RTOL, nm
 
 
-def test_trajectory_matches_reference_fixture(setup, dev):
+def test_trajectory_matches_reference_fixture(setup, dev, both_gemms):
     mcfg, params, model = setup
     d, z = load_golden_batch()
     samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
@@ -255,10 +274,15 @@ def test_graph_permutation_invariance(setup, dev):
 @pytest.mark.parametrize("layer,fam,name", [(0, 0, "lig_conv_layers.0"), (1, 2, "atom_conv_layers.1"),
                                             (2, 1, "cross_al_conv_layers.2"), (5, 3, "cross_la_conv_layers.5"),
                                             (-1, 0, "final_conv"), (-2, 0, "tor_bond_conv"), (-3, 0, "sc_tor_bond_conv")])
-@pytest.mark.parametrize("kernel", ["k_conv", "k_conv2"])
+@pytest.mark.parametrize("kernel", ["k_conv", "k_conv2", "k_conv2s"])
 def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name, kernel):
-    if kernel == "k_conv2" and layer == -1:
+    if kernel != "k_conv" and layer == -1:
         pytest.skip("final_conv (K=96) runs on k_conv only")
+    with gemm(setup[2], "split" if kernel == "k_conv2s" else "f32"):
+        _fused_conv_and_reduce(setup, dev, layer, fam, name, kernel)
+
+
+def _fused_conv_and_reduce(setup, dev, layer, fam, name, kernel):
     mcfg, p, model = setup
     lib, h = L.load(), model.handle(dev)
     g = torch.Generator().manual_seed(5 + abs(layer))
@@ -284,7 +308,7 @@ def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name, kernel):
     xd, xtd, embd, shd, tgtd, gthd, ned, msg = keep
     ptr = lambda t: C.c_void_p(t.data_ptr())
     if nef == 144:
-        rc = (lib.dbfr_test_conv2 if kernel == "k_conv2" else lib.dbfr_test_conv)(h, layer, fam, E, ptr(ned), ptr(tgtd), ptr(gthd), ptr(embd), ptr(shd), ptr(xtd),
+        rc = (lib.dbfr_test_conv if kernel == "k_conv" else lib.dbfr_test_conv2)(h, layer, fam, E, ptr(ned), ptr(tgtd), ptr(gthd), ptr(embd), ptr(shd), ptr(xtd),
                                 xtd.shape[1], ptr(tgtd), ptr(xd), Din, ptr(gthd), ptr(xd), Din, ptr(msg), None)
     else:
         rc = lib.dbfr_test_conv(h, layer, fam, E, ptr(ned), ptr(tgtd), ptr(gthd), ptr(embd), ptr(shd), ptr(xd), Din,
@@ -437,13 +461,7 @@ def test_pocket_larger_than_the_old_2048_atom_limit(setup, dev):
     assert max(errs) < SCORE_RTOL, errs
 
 
-@pytest.mark.parametrize("layer,fam,E", [(3, 2, 70000), (0, 0, 5000), (4, 1, 1234), (-2, 0, 20000)])
-def test_k_conv2_equals_k_conv_bitwise(setup, dev, layer, fam, E):
-    """The two fused-conv kernels on the same random edges: k_conv2 (persistent, edge-owner waves, tail blocks split along
-    the output channels into 8 / 4 / 2 parts, whole blocks when there are more than 256) must give the very bits of k_conv:
-    both keep the channel-owner summation order."""
-    mcfg, p, model = setup
-    lib, h = L.load(), model.handle(dev)
+def _random_conv_inputs(dev, layer, E):
     Din = [48, 84, 120, 168][min(layer, 3)] if layer >= 0 else 168
     Dout = [84, 120, 168, 168][min(layer, 3)] if layer >= 0 else 96
     g = torch.Generator(device=dev).manual_seed(100 + E)
@@ -452,14 +470,78 @@ def test_k_conv2_equals_k_conv_bitwise(setup, dev, layer, fam, E):
     tgt = torch.sort(torch.randint(0, N, (E,), device=dev, generator=g)).values.to(torch.int32)
     gth = torch.randint(0, N, (E,), device=dev, generator=g).to(torch.int32)
     emb, sh = torch.randn(E, 48, device=dev, generator=g), torch.randn(E, 9, device=dev, generator=g)
-    ne = torch.tensor([E], dtype=torch.int32, device=dev)
+    return dict(x=x, xt=xt, tgt=tgt, gth=gth, emb=emb, sh=sh, Din=Din, Dout=Dout)
+
+
+def _run_conv_hook(fn, h, layer, fam, c, E, dev):
+    """One fused conv over the first E edges of the inputs c through a C-ABI test hook; messages [E, Dout]."""
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    outs = []
-    for fn in (lib.dbfr_test_conv, lib.dbfr_test_conv2):
-        msg = torch.full((E, Dout), float("nan"), device=dev)
-        L.check(fn(h, layer, fam, E, ptr(ne), ptr(tgt), ptr(gth), ptr(emb), ptr(sh), ptr(xt), xt.shape[1], ptr(tgt), ptr(x), Din,
-                   ptr(gth), ptr(x), Din, ptr(msg), None))
-        torch.cuda.synchronize()
-        outs.append(msg)
+    ne = torch.tensor([E], dtype=torch.int32, device=dev)
+    msg = torch.full((E, c["Dout"]), float("nan"), device=dev)
+    L.check(fn(h, layer, fam, E, ptr(ne), ptr(c["tgt"]), ptr(c["gth"]), ptr(c["emb"]), ptr(c["sh"]), ptr(c["xt"]), c["xt"].shape[1],
+               ptr(c["tgt"]), ptr(c["x"]), c["Din"], ptr(c["gth"]), ptr(c["x"]), c["Din"], ptr(msg), None))
+    torch.cuda.synchronize()
+    return msg
+
+
+CONV_CASES = [(3, 2, 70000), (0, 0, 5000), (4, 1, 1234), (-2, 0, 20000)]
+
+
+@pytest.mark.parametrize("layer,fam,E", CONV_CASES)
+def test_k_conv2_equals_k_conv_bitwise(setup, dev, layer, fam, E):
+    """The two fp32-MFMA fused-conv kernels on the same random edges: k_conv2 (persistent, edge-owner waves, tail blocks split
+    along the output channels into 8 / 4 / 2 parts, whole blocks when there are more than 256) must give the very bits of
+    k_conv: both keep the channel-owner summation order."""
+    mcfg, p, model = setup
+    lib, h = L.load(), model.handle(dev)
+    c = _random_conv_inputs(dev, layer, E)
+    with gemm(model, "f32"):
+        outs = [_run_conv_hook(fn, h, layer, fam, c, E, dev) for fn in (lib.dbfr_test_conv, lib.dbfr_test_conv2)]
     assert torch.isfinite(outs[1]).all()                     # every message element was written exactly by its owner
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("layer,fam,E", CONV_CASES)
+def test_k_conv2s_matches_k_conv_and_is_unit_independent(setup, dev, layer, fam, E):
+    """k_conv2s (operands cut into three bf16 pieces, bf16 matrix instruction, fp32 accumulation) against k_conv (fp32 matrix
+    instruction) on the same random edges: equal to fp32 rounding noise; bit-identical from run to run; and the message of an
+    edge does not depend on which workgroup / which tail split processed it (the first third of the edges alone -- other
+    unit boundaries, another split of the last round -- gives the very same bits for those edges)."""
+    mcfg, p, model = setup
+    lib, h = L.load(), model.handle(dev)
+    c = _random_conv_inputs(dev, layer, E)
+    ref = _run_conv_hook(lib.dbfr_test_conv, h, layer, fam, c, E, dev)
+    with gemm(model, "split"):
+        a = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E, dev)
+        b = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E, dev)
+        E3 = E // 3
+        part = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E3, dev)
+    assert torch.isfinite(a).all()
+    assert rel_err(a, ref) < 2e-6
+    assert torch.equal(a, b)
+    assert torch.equal(part, a[:E3])
+
+
+def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, dev):
+    """The claim that makes the split path the default: against a float64 evaluation of the same conv (the oracle run in
+    double), the messages of k_conv2s are at least as close as those of k_conv.  (Measured on the bare GEMM: 1.05e-7 vs
+    3.1e-7 of sum|w h|, tools/exp/split_bf16.hip -- 30 roundings per dot product instead of 144.)"""
+    mcfg, p, model = setup
+    lib, h = L.load(), model.handle(dev)
+    name, layer, fam, E = "atom_conv_layers.3", 3, 2, 600
+    i, shirr, o, nef = sm.conv_specs(mcfg)[name]
+    c = _random_conv_inputs(dev, layer, E)
+    c["sh"] = o3.spherical_harmonics(shirr, torch.randn(E, 3, generator=torch.Generator().manual_seed(4)), True, "component").to(dev).contiguous()
+    x, xt, emb, sh = (c[k].cpu().double() for k in ("x", "xt", "emb", "sh"))
+    tgt, gth = c["tgt"].cpu().long(), c["gth"].cpu().long()
+    p64 = {k: v.double() for k, v in p.items()}
+    a64 = torch.cat([emb, xt[tgt, :48], x[gth, :48]], -1)
+    m64 = sm._tp(i, shirr, o)(x[gth], sh, sm.simple_linear(p64, f"{name}.fc", a64))
+    assert m64.dtype == torch.float64
+    err = {}
+    for mode, fn in (("f32", lib.dbfr_test_conv), ("split", lib.dbfr_test_conv2)):
+        with gemm(model, mode):
+            m = _run_conv_hook(fn, h, layer, fam, c, E, dev)
+        err[mode] = float((m.cpu().double() - m64).abs().max() / m64.abs().max())
+    assert err["f32"] < 2e-6 and err["split"] < 2e-6, err
+    assert err["split"] <= 1.25 * err["f32"] + 5e-8, err
