@@ -12,6 +12,7 @@ void launch_conv(const ConvArgs& a, hipStream_t st);
 void launch_conv_layer(const ConvArgs* c4, hipStream_t st);
 void launch_conv2(const Conv2Args& a, hipStream_t st);
 void launch_conv2s(const Conv2Args& a, hipStream_t st);
+void launch_conv2r(const Conv2Args& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
                       const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
 struct ReduceLayerArgs {
@@ -470,7 +471,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   {   // the same fragments cut into three bf16 pieces (conv2s.hip).  Per tile: [3 pieces][4 k-steps of 32][64][8] -- step s = fp32
       // k-steps 2s and 2s+1 of the same lane -- then [3 pieces][64][4] for the last 16 k (fp32 k-step 8)
     const size_t tile_h = 13824 / 2, tail_off = 12288 / 2;
-    std::vector<uint16_t> w2s((size_t)n_tiles * tile_h, 0);
+    std::vector<uint16_t> w2s((size_t)n_tiles * tile_h + 512, 0);   // (+ 1 KiB of slack behind the last tile)
     for (int t = 0; t < n_tiles; ++t)
       for (int s4 = 0; s4 < KT; ++s4)
         for (int lane = 0; lane < 64; ++lane)
@@ -808,7 +809,9 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     prof_events(m, &e0, &e1);
     (void)hipEventRecord(e0, st);
   }
-  if (m->gemm_split) launch_conv2s(a, st);
+  static const int ring = getenv("DBFR_CONV2_RING") ? atoi(getenv("DBFR_CONV2_RING")) : 0;   // developer: 0 W2 through L1 (k_conv2s), 1 through the LDS ring (k_conv2r)
+  if (m->gemm_split && ring) launch_conv2r(a, st);
+  else if (m->gemm_split) launch_conv2s(a, st);
   else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);
   if (m->profile)

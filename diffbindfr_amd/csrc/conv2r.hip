@@ -1,27 +1,21 @@
-// Fused tensor-product convolution, third generation (gfx950): k_conv2's persistent edge-owner structure with the radial
-// MLP's big GEMM (hidden layer -> per-edge tensor-product weights, 144 x W, 97-99 % of the conv's arithmetic) moved from the
-// fp32 matrix instruction (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD) to the bf16 one (v_mfma_f32_16x16x32_bf16, 16x the rate)
-// WITHOUT giving up fp32 results:
+// Fused tensor-product convolution, split-bf16 GEMM (see conv2s.hip for the arithmetic), W2 through an LDS ring.
 //
-//   * every fp32 operand is cut into three bf16 pieces, a = a1 + a2 + a3 (round-to-nearest each time; 3 x 8 significand bits
-//     hold all 24 bits of an fp32 number, so the sum is exact).  W2 is cut once at model creation (api.cpp pack_conv2), the
-//     hidden layer h is cut in registers right after its ReLU;
-//   * a product a b = sum_ij a_i b_j; each a_i b_j (8 x 8 bits) is exact in the fp32 accumulator of the matrix pipe.  The six
-//     partial products with i + j <= 4 are evaluated, smallest first; the three dropped ones are below 2^-23 |a b|.  Measured
-//     against an fp64 reference (tools/exp/split_bf16.hip, K = 144, ReLU-like h): max error 1.05e-7 of sum|w h| (rms 9.7e-9),
-//     vs 3.13e-7 (rms 2.8e-8) for the native fp32 MFMA chain this replaces and for a host fmaf chain -- the split form is
-//     the MORE accurate of the two, because it rounds 30 times per dot product instead of 144;
-//   * the reduction index is padded 144 -> 160 (5 k-steps of 32) and permuted so that the hidden layer's MFMA result
-//     registers are, piece by piece, the B operand of the W2 tiles: step s, lane group g, slot j holds hidden unit
-//     16 (2 s + (j >> 2)) + 4 g + (j & 3) -- no transpose, no LDS, as in k_conv2;
-//   * the first GEMM (144 x 144, 2-5 % of the arithmetic) stays on the native fp32 instruction.
-//
-// 30 bf16 MFMAs (16 cycles each) replace 36 fp32 ones (32 cycles each) per 16 x 16 weight tile: 2.4x less matrix-pipe time.
-// The W2 fragment stream grows from 9 to 15 KiB per tile (three pieces, padded k), which is why the edge-owner structure
-// (one stream per CU through L1, shared by the 8 waves of the workgroup) is the one that carries it.
-// Everything after the accumulators -- bias as initial value, closed-form Clebsch-Gordan contraction, channel-owner
-// accumulation, unit queue, tail split -- is k_conv2's (conv2.hip), the C/D register layout of the two instructions being
-// the same.  Results are bitwise independent of the unit -> workgroup assignment and of the split.
+// k_conv2s lets every one of the eight waves of the workgroup fetch the same 13.5 KiB of W2 pieces per tile through the
+// vector L1: 64 B/clk of L1 bandwidth are ~80 % busy with it and the sweep waits for its loads (no re-load: 279, with: 194
+// fp32-equivalent TFLOP/s on one big conv).  Here ONE copy per tile enters the CU:
+//   * an LDS ring of five slots, one per k-step of a tile (4 x three 1-KiB pieces, the last 16 k, + the tile's 16 bias
+//     values), laid out like the tile in memory and filled by LDS-DMA (global_load_lds, no register path);
+//   * a wave keeps only TWO k-steps of W2 fragments in registers (the one its MFMAs read, the next one arriving from the ring
+//     by ds_read_b128, lane-linear = conflict-free) instead of a whole tile, which pays for a second accumulator set:
+//     both edge blocks run through a k-step together (two accumulator chains, fragments read once per tile), and the
+//     contraction of tile i - 1 is hand-interleaved into the issue gaps of tile i's 60 MFMAs (conv2s.hip explains why the
+//     wave has to hide it itself);
+//   * slot s is read by everybody during k-step s - 1; at the start of k-step s one s_barrier says "all have read it", wave s
+//     re-arms it with k-step s of the next tile -- a whole tile period to land -- and the wave that armed slot s + 1 a tile
+//     ago first makes sure its copy is there.  Five barriers per tile, not waited for in steady state: the waves of a
+//     workgroup do identical work.
+// Everything else (unit queue, hidden layer in registers, x rows / harmonics in wave-private LDS, channel-owner accumulation,
+// tail split, bitwise independence from the unit -> workgroup assignment) is conv2s.hip's.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -36,6 +30,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define C3_TILE_BYTES 13824         // [3 pieces][4 k-steps of 32][64 lanes][8 bf16] + [3 pieces][64 lanes][4 bf16] (the last 16 k)
 #define C3_TAIL_OFF 12288
+#define C3_RING_BYTES 14336         // one tile (13824 B) + its 16 bias values, padded
 #define SB_CROSS 0x086              // sched_barrier mask: VALU, SALU and LDS instructions may cross (MFMA and VMEM may not)
 
 // two fp32 values -> three words of packed bf16 pairs (low half = x0's piece): x = p0 + p1 + p2 exactly, every piece rounded
@@ -56,17 +51,17 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned& p0, unsig
 #define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
 #define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
 
-// RB 2: s_barrier at every tile start (keeps the 8 waves on the same W2 tile: the L1 window is two 15-KiB tiles);
-// ABL (developer, wrong results): 1 no contraction, 2 no W2 fragment re-load, 4 no hidden layer
-template <int NW, int RB = 0, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction
+__global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
   constexpr int K = 144, KT = 9;
   constexpr int EPB = 32 * NW;                       // edges per block (unit)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_unit[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
-  float* xs = lds + wave * C2_WAVE_FLOATS;           // [32][C2_XLD]
+  const char* ring = reinterpret_cast<const char*>(lds);          // [C3_RING_BYTES] first: inside the 16-bit offset of ds_read
+  const unsigned ring_lds = (unsigned)(size_t)ring;               // its LDS byte address (low half of the flat address)
+  float* xs = lds + C3_RING_BYTES / 4 + wave * C2_WAVE_FLOATS;    // [32][C2_XLD]
   float* shs = xs + 32 * C2_XLD;                     // [32][10]
   float* ms = shs + 32 * 10;                         // [32][8]
   int* s_gth = reinterpret_cast<int*>(ms + 32 * 8);  // [32]
@@ -86,6 +81,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
 
   for (int it = 0;; ++it) {
     if (tid == 0) s_unit[it & 1] = atomicAdd(a.queue, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing of the last unit still reads or arms the ring
     __syncthreads();
     const int u = s_unit[it & 1];
     if (u >= total) break;
@@ -97,8 +93,39 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
     const Conv2Desc& d = a.c[c];
     const int E = min(*d.n_edges, d.max_edges);
     const int e0 = blk * EPB + 32 * wave;
-    if (RB == 0 && e0 >= E) continue;                           // this wave has no edge in the block (the loop-top barrier is still reached)
+    // (a wave without edges in this block runs along on clamped edges and stores nothing: the ring barriers need all eight)
+    //                        // this wave has no edge in the block (the loop-top barrier is still reached)
     const int D_in = d.w.D_in, D_out = d.w.D_out;
+    const int vW = lane * 16, vB = g * 16;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int r_begin = d.w.part_run[psi][part], r_end = d.w.part_run[psi][part + 1];
+    int t_last = 0, t_first = 0;
+    if (r_begin < r_end) {
+      const RunDesc rl = d.w.runs[r_end - 1];
+      t_last = (rl.tile0_n & 0xfffff) + (rl.tile0_n >> 20) - 1;
+      t_first = d.w.runs[r_begin].tile0_n & 0xfffff;
+    }
+    // ring slot j <- k-step j of `tile` (j < 4: three 1-KiB pieces; j = 4: the last 16 k, 1.5 KiB; with slot 0: the bias values).
+    // Inline asm on purpose: behind the builtin hipcc parks an s_waitcnt vmcnt(0) in front of EVERY later LDS read (it cannot
+    // tell the slots apart), which would make the arming wave sit out its own copy.  SGPR base + lane offset addressing.
+    auto arm = [&](int j, int tile) {
+      const char* src = reinterpret_cast<const char*>(d.w.W2s) + (size_t)tile * C3_TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int off = j < 4 ? (i * 4 + j) * 1024 : C3_TAIL_OFF + i * 1024;
+        if (j < 4 || i == 0 || (i == 1 && lane < 32)) {   // (the second piece of the last-16-k slot is half a kilobyte)
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(vW), "s"(src + off), "s"(__builtin_amdgcn_readfirstlane(ring_lds + off)) : "memory");
+        }
+      }
+      if (j == 0 && lane < 16) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane * 4), "s"(d.w.b2q + (size_t)tile * 16), "s"(__builtin_amdgcn_readfirstlane(ring_lds + C3_TILE_BYTES)) : "memory");
+      }
+    };
+    if (r_begin < r_end && wv < 5) arm(wv, t_first);   // the first tile travels while the hidden layer is computed
 
     // ---- my two edges (block b, column n), clamped; gather indices
     int ev[2], gthv[2];
@@ -130,7 +157,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
     // registers (k-step q of lane group g of 16-group s4 takes k = 16 s4 + 4 g + q, api.cpp pack_conv);
     // D[row = hidden unit, col = edge] -> lane (g, n) ends up with h[16 m + 4 g + r][edge n], r = 0..3, which it cuts
     // into bf16 pieces and files as slots 4 (m & 1) + r of k-step m >> 1 of the W2 tiles' B operand
-    const int vW = lane * 16;
     u32x4 Bh[2][3][4];                                 // h pieces: [edge block][piece][k-step of 32] = 8 bf16 each, 96 VGPRs
     u32x2 Bt[2][3];                                    // ... and of the last 16 k (v_mfma_f32_16x16x16_bf16): 4 bf16 each, 12 VGPRs
     {
@@ -188,109 +214,81 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
       }
     }
     __builtin_amdgcn_wave_barrier();
-    int x_phase = 0;
 
     // ---- the W2 row tiles of this part, run by run (channel-owner order, api.cpp pack_conv2)
-    const int r_begin = d.w.part_run[psi][part], r_end = d.w.part_run[psi][part + 1];
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.W2s, 0, d.w.n_tiles * C3_TILE_BYTES, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.b2q, 0, d.w.n_tiles * 64, 0x00020000);
-    const int vB = g * 16;
-    bf16x8 A[3][4];                                    // W2 pieces of the current tile: 48 VGPRs ...
-    s16x4 At[3];                                       // ... + 6 for the last 16 k
-    const int vT = lane * 8;
-    f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
-    int t_last = 0;
-    if (r_begin < r_end) {
-      const RunDesc rl = d.w.runs[r_end - 1];
-      t_last = (rl.tile0_n & 0xfffff) + (rl.tile0_n >> 20) - 1;
-      const int t0 = d.w.runs[r_begin].tile0_n & 0xfffff;
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          A[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, t0 * C3_TILE_BYTES + (i * 4 + s) * 1024, 0));
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        At[i] = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rW, vT, t0 * C3_TILE_BYTES + C3_TAIL_OFF + i * 512, 0));
-      bias_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB, t0 * 64, 0));
-    }
     float oacc[2][3];
 #pragma unroll
     for (int b = 0; b < 2; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
     const float* xs_lane = xs + n * C2_XLD;          // + 16 b C2_XLD per edge block
     const float* sh_lane = shs + n * 10;
-    // the two waves of a SIMD run the same code from the same start: left alone they stay IN phase (both in their MFMA
-    // burst, then both in their contraction, the matrix pipe idle).  The second-dispatched half starts its tiles a
-    // fraction of a tile late; the offset then persists (a wave that contracts lets its partner run at full rate)
-    if (wave >= NW / 2) for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(8);
-    // One wave issues a v_mfma_f32_16x16x32_bf16 every ~17 cycles whatever its SIMD partner does (two waves of a SIMD
-    // run their MFMAs side by side at that rate each: tools/exp/mfma_dep.hip), so matrix time and contraction time of
-    // a wave ADD unless the wave itself interleaves them.  The tile is therefore taken block by block,
-    //     pass(block 0, tile i)    with   contraction(block 1, tile i-1)   in its issue gaps
-    //     pass(block 1, tile i)    with   contraction(block 0, tile i)
-    // and the interleaving is written out by hand: the contraction is a list of micro-operations (one LDS read group,
-    // then single FMAs), operation k sits behind MFMA k + 4 of the 30 of a pass, and a scheduling barrier after every
-    // slot keeps hipcc from re-clustering them (left alone it moves all vector work behind, or in front of, the MFMAs).
-    // The W2 re-loads sit behind the last MFMA that reads the registers they overwrite.
-    f32x4 acc[2];
-    auto pass = [&](auto bc, auto last_c, int tn, auto&& op) {
-      constexpr int b = decltype(bc)::value;
-      constexpr bool RELOAD = decltype(last_c)::value && !(ABL & 2);   // block 1 is the last reader of the tile's fragments
-#define SLOT(m) do { op(std::integral_constant<int, (m) - 4>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
-      op(std::integral_constant<int, 0>{});                            // the LDS reads of the travelling contraction
-      __builtin_amdgcn_sched_barrier(0);
-      acc[b] = bias_n;
-      auto step = [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        const bf16x8 a0 = A[0][s], a1 = A[1][s], a2 = A[2][s];
-        // the six partial products with i + j <= 4, smallest first
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, __builtin_bit_cast(bf16x8, Bh[b][0][s]), acc[b], 0, 0, 0); SLOT(6 * s + 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[b][1][s]), acc[b], 0, 0, 0); SLOT(6 * s + 1);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[b][2][s]), acc[b], 0, 0, 0); SLOT(6 * s + 2);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, __builtin_bit_cast(bf16x8, Bh[b][0][s]), acc[b], 0, 0, 0); SLOT(6 * s + 3);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[b][1][s]), acc[b], 0, 0, 0); SLOT(6 * s + 4);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, __builtin_bit_cast(bf16x8, Bh[b][0][s]), acc[b], 0, 0, 0);
-        if (RELOAD) {
-          if (s == 0) bias_n = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, vB, tn * 64, 0));
+    bf16x8 FA[3], FB[3];                               // W2 pieces of two k-steps: 24 VGPRs
+    s16x4 FT[3];                                       // ... and of the last 16 k: 6
+    f32x4 bias_r;                                      // bias of the tile whose first MFMA comes next
+    f32x4 acc[2], accp[2];                             // this tile's accumulators; the previous tile's, being contracted
+    auto rd_step = [&](auto jc, bf16x8 (&F)[3]) {
+      constexpr int j = decltype(jc)::value;
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
-            A[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, vW, tn * C3_TILE_BYTES + (i * 4 + s) * 1024, 0));
-        }
-        SLOT(6 * s + 5);
+      for (int i = 0; i < 3; ++i) F[i] = *reinterpret_cast<const bf16x8*>(ring + (i * 4 + j) * 1024 + vW);
+    };
+    // start of k-step s: my reads of slot s are in; once everybody's are, wave s re-arms the slot with the next tile's step s
+    auto turn = [&](int s, int t_next) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (wv == (s + 1) % 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slot s + 1, armed a tile ago, is read next
+      __builtin_amdgcn_s_barrier();
+      if (wv == s) arm(s, t_next);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#define X32(b, ai, hi, F, s) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ai], __builtin_bit_cast(bf16x8, Bh[b][hi][s]), acc[b], 0, 0, 0)
+#define X16(b, ai, hi) acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(FT[ai], __builtin_bit_cast(s16x4, Bt[b][hi]), acc[b], 0, 0, 0)
+#define SLOT(m) do { op(std::integral_constant<int, (m)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // one tile: 60 MFMAs = 5 k-steps x 6 partial products (smallest first) x 2 edge blocks, `op(m)` = what travels behind MFMA m
+    auto tile = [&](int t_next, auto&& op) {
+      auto kstep = [&](auto sc, bf16x8 (&F)[3]) {
+        constexpr int s = decltype(sc)::value;
+        X32(0, 2, 0, F, s); SLOT(12 * s + 0); X32(1, 2, 0, F, s); SLOT(12 * s + 1);
+        X32(0, 1, 1, F, s); SLOT(12 * s + 2); X32(1, 1, 1, F, s); SLOT(12 * s + 3);
+        X32(0, 0, 2, F, s); SLOT(12 * s + 4); X32(1, 0, 2, F, s); SLOT(12 * s + 5);
+        X32(0, 1, 0, F, s); SLOT(12 * s + 6); X32(1, 1, 0, F, s); SLOT(12 * s + 7);
+        X32(0, 0, 1, F, s); SLOT(12 * s + 8); X32(1, 0, 1, F, s); SLOT(12 * s + 9);
+        X32(0, 0, 0, F, s); SLOT(12 * s + 10); X32(1, 0, 0, F, s); SLOT(12 * s + 11);
       };
-      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
-      // k = 128..143 on v_mfma_f32_16x16x16_bf16 (two-register operands).
-      // Hazard (found the hard way, MI355X + ROCm 7.2): an x16 MFMA that takes as SrcC an accumulator an x32 MFMA has just
-      // written reads stale data -- hipcc pads nothing between the two opcodes (wrong, timing-dependent results; either
-      // opcode alone chains cleanly, tools/exp/mfma_x16_chain.hip).  16 wait states put any pass count behind us.
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      turn(0, t_next); rd_step(I1{}, FB);
+      acc[0] = bias_r; acc[1] = bias_r;
+      kstep(I0{}, FA);
+      turn(1, t_next); rd_step(I2{}, FA);
+      kstep(I1{}, FB);
+      turn(2, t_next); rd_step(I3{}, FB);
+      kstep(I2{}, FA);
+      turn(3, t_next);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) FT[i] = *reinterpret_cast<const s16x4*>(ring + C3_TAIL_OFF + i * 512 + lane * 8);
+      kstep(I3{}, FB);
+      turn(4, t_next); rd_step(I0{}, FA);              // the NEXT tile's first k-step and bias
+      bias_r = *reinterpret_cast<const f32x4*>(ring + C3_TILE_BYTES + vB);
+      // k = 128..143 on v_mfma_f32_16x16x16_bf16.  Hazard (MI355X + ROCm 7.2, conv2s.hip): an x16 MFMA taking as SrcC an
+      // accumulator an x32 MFMA has just written reads stale data; 16 wait states put any pass count behind us.
       asm volatile("s_nop 15");
       __builtin_amdgcn_sched_barrier(0);
-      {
-        const s16x4 a0 = At[0], a1 = At[1], a2 = At[2];
-#define TB(i) __builtin_bit_cast(s16x4, Bt[b][i])
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, TB(0), acc[b], 0, 0, 0); SLOT(24);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(1), acc[b], 0, 0, 0); SLOT(25);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(2), acc[b], 0, 0, 0); SLOT(26);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, TB(0), acc[b], 0, 0, 0); SLOT(27);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(1), acc[b], 0, 0, 0); SLOT(28);
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, TB(0), acc[b], 0, 0, 0);
-#undef TB
-        if (RELOAD) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-            At[i] = __builtin_bit_cast(s16x4, __builtin_amdgcn_raw_buffer_load_b64(rW, vT, tn * C3_TILE_BYTES + C3_TAIL_OFF + i * 512, 0));
-        }
-        SLOT(29);
-      }
-#undef SLOT
+      X16(0, 2, 0); SLOT(48); X16(1, 2, 0); SLOT(49);
+      X16(0, 1, 1); SLOT(50); X16(1, 1, 1); SLOT(51);
+      X16(0, 0, 2); SLOT(52); X16(1, 0, 2); SLOT(53);
+      X16(0, 1, 0); SLOT(54); X16(1, 1, 0); SLOT(55);
+      X16(0, 0, 1); SLOT(56); X16(1, 0, 1); SLOT(57);
+      X16(0, 0, 0); SLOT(58); X16(1, 0, 0); SLOT(59);
+      accp[0] = acc[0]; accp[1] = acc[1];
+      __builtin_amdgcn_sched_barrier(0);
     };
-    auto no_op = [](auto) {};
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    __builtin_amdgcn_sched_barrier(0);
-    if (r_begin < r_end) pass(B0{}, std::false_type{}, 0, no_op);   // block 0 of the part's first tile
-    __builtin_amdgcn_sched_barrier(0);
+#undef SLOT
+    int x_phase = 0;
+    if (r_begin < r_end) {                             // the ring holds the part's first tile (armed before the hidden layer)
+      if (wv < 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      rd_step(std::integral_constant<int, 0>{}, FA);
+      bias_r = *reinterpret_cast<const f32x4*>(ring + C3_TILE_BYTES + vB);
+    }
     for (int r = r_begin; r < r_end; ++r) {
       const RunDesc rd = d.w.runs[r];
       const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
@@ -324,18 +322,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
             for (int k = 0; k < NSV; ++k) S[b][k] = sp[k];
           }
         }
-        // the contraction of one edge block as micro-operations: K = 0 the LDS reads, K >= 1 one FMA each (K beyond the
-        // type's count: nothing).  State lives in cx* / cz* between the operations of one contraction.
+        // the contraction of one edge block of the PREVIOUS tile (accp) as micro-operations: K = 0 the first LDS reads, K >= 1
+        // one FMA each (K beyond the type's count: nothing).  State lives in cx* / cz* between the operations.
         f32x4 cxa, cxb, cxc, cma;
         float2 cmb;
         float cz0, cz1, cz2;
         auto cop = [&](auto bc, auto kc, const float* xp) {
           constexpr int b = decltype(bc)::value;
           constexpr int K = decltype(kc)::value;
-          if (ABL & 1) { if (K == 1) asm volatile("" ::"v"(acc[b])); return; }
-          const f32x4 v = acc[b];
+          if (ABL & 1) { if (K == 1) asm volatile("" ::"v"(accp[b])); return; }
+          const f32x4 v = accp[b];
           const f32x4* x4 = reinterpret_cast<const f32x4*>(xp + 16 * b * C2_XLD);   // [u0..u0+3][3] = 12 consecutive floats (VIN)
-          if (VIN && K == 2) cxb = x4[1];            // (each quad requested three operations ahead of its first use: 4 fewer live registers)
+          if (VIN && K == 2) cxb = x4[1];            // (each quad requested a few operations ahead of its first use)
           if (VIN && K == 6) cxc = x4[2];
           if (K == 0) {
             cxa = x4[0];
@@ -395,20 +393,42 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
             }
           }
         };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        // what travels behind MFMA m of a tile: block 0 of the previous tile in slots 0 (reads) and 5..26, block 1 in 28 and 33..54
+        auto travel = [&](auto mc, const float* xp) {
+          constexpr int m = decltype(mc)::value;
+          if constexpr (m == 0) cop(B0{}, std::integral_constant<int, 0>{}, xp);
+          else if constexpr (m >= 5 && m <= 26) cop(B0{}, std::integral_constant<int, m - 4>{}, xp);
+          else if constexpr (m == 28) cop(B1{}, std::integral_constant<int, 0>{}, xp);
+          else if constexpr (m >= 33 && m <= 54) cop(B1{}, std::integral_constant<int, m - 32>{}, xp);
+        };
         const float* xp = xs_lane + xo;
-        for (int i = 0; i < nt; ++i, xp += x_step) {
-          const int t = tile0 + i;
-          const int tn = t < t_last ? t + 1 : t;
-          if (RB >= 2) __builtin_amdgcn_s_barrier();
-          pass(B1{}, std::true_type{}, tn, [&](auto kc) { cop(B0{}, kc, xp); });
-          // block 0 of the NEXT tile, whichever run it belongs to (behind the part's last tile: computed, never used)
-          pass(B0{}, std::false_type{}, 0, [&](auto kc) { cop(B1{}, kc, xp); });
+        {   // the run's first tile: nothing of this run is pending
+          const int t = tile0;
+          tile(t < t_last ? t + 1 : t, [](auto) {});
         }
+        for (int i = 1; i < nt; ++i, xp += x_step) {
+          const int t = tile0 + i;
+          tile(t < t_last ? t + 1 : t, [&](auto mc) { travel(mc, xp); });     // tile i with the contraction of tile i - 1
+        }
+        // the run's last tile is contracted in the open (its successor belongs to another path type)
+        __builtin_amdgcn_sched_barrier(0);
+#define COPS(b) cop(b, std::integral_constant<int, 0>{}, xp); cop(b, std::integral_constant<int, 1>{}, xp); cop(b, std::integral_constant<int, 2>{}, xp); \
+        cop(b, std::integral_constant<int, 3>{}, xp); cop(b, std::integral_constant<int, 4>{}, xp); cop(b, std::integral_constant<int, 5>{}, xp); \
+        cop(b, std::integral_constant<int, 6>{}, xp); cop(b, std::integral_constant<int, 7>{}, xp); cop(b, std::integral_constant<int, 8>{}, xp); \
+        cop(b, std::integral_constant<int, 9>{}, xp); cop(b, std::integral_constant<int, 10>{}, xp); cop(b, std::integral_constant<int, 11>{}, xp); \
+        cop(b, std::integral_constant<int, 12>{}, xp); cop(b, std::integral_constant<int, 13>{}, xp); cop(b, std::integral_constant<int, 14>{}, xp); \
+        cop(b, std::integral_constant<int, 15>{}, xp); cop(b, std::integral_constant<int, 16>{}, xp); cop(b, std::integral_constant<int, 17>{}, xp); \
+        cop(b, std::integral_constant<int, 18>{}, xp); cop(b, std::integral_constant<int, 19>{}, xp); cop(b, std::integral_constant<int, 20>{}, xp); \
+        cop(b, std::integral_constant<int, 21>{}, xp);
+        COPS(B0{}) COPS(B1{})
+#undef COPS
         if (flags & 2) {   // last run of the channel group: this lane owns msg[e][oo .. oo + (VOUT ? 3 : 1))
           if (oo < D_out) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-              if (e0 + 16 * b + n < E) {                       // (edge index recomputed: nothing per edge stays live across the sweep)
+              if (e0 + 16 * b + n < E) {
                 float* op = d.msg + (size_t)(e0 + 16 * b + n) * D_out + oo;
                 op[0] = oacc[b][0];
                 if (VOUT) { op[1] = oacc[b][1]; op[2] = oacc[b][2]; }
@@ -425,6 +445,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
         default: run(std::integral_constant<int, PT_VTV>{}); break;
       }
     }
+#undef X32
+#undef X16
   }
   // ---- the last workgroup to leave re-arms the queue for the next launch
   if (tid == 0) {
@@ -433,44 +455,24 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2s(Conv2Args a) {
   }
 }
 
-void launch_conv2s(const Conv2Args& a, hipStream_t st) {
+void launch_conv2r(const Conv2Args& a, hipStream_t st) {
   static int n_cu = 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
-  static int skew = getenv("DBFR_CONV2_SKEW") ? atoi(getenv("DBFR_CONV2_SKEW")) : 0;
+  static int abl = getenv("DBFR_CONV2R_ABL") ? atoi(getenv("DBFR_CONV2R_ABL")) : 0;
   constexpr int NW = 8;
-  const size_t lds = (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
+  const size_t lds = C3_RING_BYTES + (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
   if (!n_cu) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  static int var = getenv("DBFR_CONV2S_VAR") ? atoi(getenv("DBFR_CONV2S_VAR")) : 0;   // developer: 10 RB + ABL
   Conv2Args b = a;
-  b.skew = skew;
+  b.skew = 0;
   b.run_barrier = 0;
   b.no_split = no_split;
-  const dim3 gr(n_cu), bl(64 * NW);
-  switch (var) {
-    case 20: hipLaunchKernelGGL((k_conv2s<NW, 2, 0>), gr, bl, lds, st, b); break;
-    case 22: hipLaunchKernelGGL((k_conv2s<NW, 2, 2>), gr, bl, lds, st, b); break;
-    case 1: hipLaunchKernelGGL((k_conv2s<NW, 0, 1>), gr, bl, lds, st, b); break;
-    case 2: hipLaunchKernelGGL((k_conv2s<NW, 0, 2>), gr, bl, lds, st, b); break;
-    case 3: hipLaunchKernelGGL((k_conv2s<NW, 0, 3>), gr, bl, lds, st, b); break;
-    case 4: hipLaunchKernelGGL((k_conv2s<NW, 0, 4>), gr, bl, lds, st, b); break;
-    case 8: hipLaunchKernelGGL((k_conv2s<NW, 0, 8>), gr, bl, lds, st, b); break;
-    case 16: hipLaunchKernelGGL((k_conv2s<NW, 0, 16>), gr, bl, lds, st, b); break;
-    case 32: hipLaunchKernelGGL((k_conv2s<NW, 0, 32>), gr, bl, lds, st, b); break;
-    default: hipLaunchKernelGGL((k_conv2s<NW, 0, 0>), gr, bl, lds, st, b); break;
-  }
+  if (abl == 1) hipLaunchKernelGGL((k_conv2r<NW, 1>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else hipLaunchKernelGGL((k_conv2r<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
 }
