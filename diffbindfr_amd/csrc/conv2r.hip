@@ -51,7 +51,7 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned& p0, unsig
 #define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
 #define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
 
-template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no re-arming, 8 no hazard nop
 __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
   constexpr int K = 144, KT = 9;
   constexpr int EPB = 32 * NW;                       // edges per block (unit)
@@ -105,27 +105,41 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
       t_last = (rl.tile0_n & 0xfffff) + (rl.tile0_n >> 20) - 1;
       t_first = d.w.runs[r_begin].tile0_n & 0xfffff;
     }
-    // ring slot j <- k-step j of `tile` (j < 4: three 1-KiB pieces; j = 4: the last 16 k, 1.5 KiB; with slot 0: the bias values).
-    // Inline asm on purpose: behind the builtin hipcc parks an s_waitcnt vmcnt(0) in front of EVERY later LDS read (it cannot
-    // tell the slots apart), which would make the arming wave sit out its own copy.  SGPR base + lane offset addressing.
-    auto arm = [&](int j, int tile) {
-      const char* src = reinterpret_cast<const char*>(d.w.W2s) + (size_t)tile * C3_TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int off = j < 4 ? (i * 4 + j) * 1024 : C3_TAIL_OFF + i * 1024;
-        if (j < 4 || i == 0 || (i == 1 && lane < 32)) {   // (the second piece of the last-16-k slot is half a kilobyte)
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(vW), "s"(src + off), "s"(__builtin_amdgcn_readfirstlane(ring_lds + off)) : "memory");
-        }
-      }
-      if (j == 0 && lane < 16) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane * 4), "s"(d.w.b2q + (size_t)tile * 16), "s"(__builtin_amdgcn_readfirstlane(ring_lds + C3_TILE_BYTES)) : "memory");
-      }
+    // Filling the ring: every k-step slot (three 1-KiB pieces) is cut into six 512-byte shares; wave w moves share w % 6 of
+    // every slot (piece >> 1, half & 1: one 8-byte load per lane into a staging register pair, one ds_write_b64 three k-steps
+    // later), share w % 3 of the last-16-k slot, and the tile's 16 bias values -- waves 6, 7 (and 3..7 on the short slot)
+    // duplicate a neighbour's share: same bytes to the same place.  No branch around any of it, on purpose: behind a
+    // wave-uniform `if` hipcc's wait-count pass loses track and parks an s_waitcnt vmcnt(0) in front of every ds_write, i.e.
+    // the wave sits out the load it has just issued.  Plain loads rather than LDS-DMA for the same kind of reason: a
+    // global_load_lds piece costs its issuing wave 60-185 cycles next to MFMAs (14 a tile: measured 40 % of the sweep).
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.W2s, 0, d.w.n_tiles * C3_TILE_BYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.b2q, 0, d.w.n_tiles * 64, 0x00020000);
+    const int sh6 = wv % 6, sh_i = sh6 >> 1, v8 = lane * 8 + (sh6 & 1) * 512, sh3 = wv % 3;
+    const int vb4 = lane < 16 ? lane * 4 : 0x40000000;   // lanes 16..63: out of the buffer's range, the load returns 0 ...
+    const int wb4 = lane < 16 ? lane * 4 : 64 + lane * 4; // ... and lands in the padding behind the bias values
+    char* ringw = const_cast<char*>(ring);
+    u32x2 stg[5];
+    unsigned stgb = 0;
+    auto fetch = [&](auto sc, int tile) {
+      constexpr int s = decltype(sc)::value;
+      if (ABL & 4) return;
+      if (s < 4) stg[s] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rW, v8, tile * C3_TILE_BYTES + (sh_i * 4 + s) * 1024, 0));
+      else stg[4] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rW, lane * 8, tile * C3_TILE_BYTES + C3_TAIL_OFF + sh3 * 512, 0));
+      if (s == 0) stgb = __builtin_amdgcn_raw_buffer_load_b32(rB, vb4, tile * 64, 0);
     };
-    if (r_begin < r_end && wv < 5) arm(wv, t_first);   // the first tile travels while the hidden layer is computed
+    auto put = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if (ABL & 4) return;
+      if (s < 4) *reinterpret_cast<u32x2*>(ringw + (sh_i * 4 + s) * 1024 + v8) = stg[s];
+      else *reinterpret_cast<u32x2*>(ringw + C3_TAIL_OFF + sh3 * 512 + lane * 8) = stg[4];
+      if (s == 0) *reinterpret_cast<unsigned*>(ringw + C3_TILE_BYTES + wb4) = stgb;
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    if (r_begin < r_end) {   // the part's first tile travels while the hidden layer is computed
+      fetch(I0{}, t_first); fetch(I1{}, t_first); fetch(I2{}, t_first); fetch(I3{}, t_first); fetch(I4{}, t_first);
+    }
 
     // ---- my two edges (block b, column n), clamped; gather indices
     int ev[2], gthv[2];
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
     {
       const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.W1p, 0, KT * KT * 1024, 0x00020000);
 #pragma unroll
-      for (int b = 0; b < ((ABL & 4) ? 0 : 2); ++b) {
+      for (int b = 0; b < 2; ++b) {
         f32x4 Ba[KT];
 #pragma unroll
         for (int s4 = 0; s4 < KT; ++s4) {
@@ -230,13 +244,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) F[i] = *reinterpret_cast<const bf16x8*>(ring + (i * 4 + j) * 1024 + vW);
     };
-    // start of k-step s: my reads of slot s are in; once everybody's are, wave s re-arms the slot with the next tile's step s
-    auto turn = [&](int s, int t_next) {
+    // start of k-step s: my reads of slot s are in (and my earlier writes to the ring); once that holds for everybody the
+    // slot is free: my share of the next tile's k-step s sets out for its staging registers, and the share fetched three
+    // k-steps ago goes into its slot -- read again four k-steps from now, behind the barrier after next
+    auto turn = [&](auto sc, int t_next) {
+      constexpr int s = decltype(sc)::value;
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (wv == (s + 1) % 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slot s + 1, armed a tile ago, is read next
-      __builtin_amdgcn_s_barrier();
-      if (wv == s) arm(s, t_next);
+      if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+      fetch(sc, t_next);
+      put(std::integral_constant<int, (s + 2) % 5>{});
       __builtin_amdgcn_sched_barrier(0);
     };
 #define X32(b, ai, hi, F, s) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ai], __builtin_bit_cast(bf16x8, Bh[b][hi][s]), acc[b], 0, 0, 0)
@@ -253,24 +270,22 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
         X32(0, 0, 1, F, s); SLOT(12 * s + 8); X32(1, 0, 1, F, s); SLOT(12 * s + 9);
         X32(0, 0, 0, F, s); SLOT(12 * s + 10); X32(1, 0, 0, F, s); SLOT(12 * s + 11);
       };
-      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-      turn(0, t_next); rd_step(I1{}, FB);
+      turn(I0{}, t_next); rd_step(I1{}, FB);
       acc[0] = bias_r; acc[1] = bias_r;
       kstep(I0{}, FA);
-      turn(1, t_next); rd_step(I2{}, FA);
+      turn(I1{}, t_next); rd_step(I2{}, FA);
       kstep(I1{}, FB);
-      turn(2, t_next); rd_step(I3{}, FB);
+      turn(I2{}, t_next); rd_step(I3{}, FB);
       kstep(I2{}, FA);
-      turn(3, t_next);
+      turn(I3{}, t_next);
 #pragma unroll
       for (int i = 0; i < 3; ++i) FT[i] = *reinterpret_cast<const s16x4*>(ring + C3_TAIL_OFF + i * 512 + lane * 8);
       kstep(I3{}, FB);
-      turn(4, t_next); rd_step(I0{}, FA);              // the NEXT tile's first k-step and bias
+      turn(I4{}, t_next); rd_step(I0{}, FA);              // the NEXT tile's first k-step and bias
       bias_r = *reinterpret_cast<const f32x4*>(ring + C3_TILE_BYTES + vB);
       // k = 128..143 on v_mfma_f32_16x16x16_bf16.  Hazard (MI355X + ROCm 7.2, conv2s.hip): an x16 MFMA taking as SrcC an
       // accumulator an x32 MFMA has just written reads stale data; 16 wait states put any pass count behind us.
-      asm volatile("s_nop 15");
+      if (!(ABL & 8)) asm volatile("s_nop 15");
       __builtin_amdgcn_sched_barrier(0);
       X16(0, 2, 0); SLOT(48); X16(1, 2, 0); SLOT(49);
       X16(0, 1, 1); SLOT(50); X16(1, 1, 1); SLOT(51);
@@ -283,10 +298,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
     };
 #undef SLOT
     int x_phase = 0;
-    if (r_begin < r_end) {                             // the ring holds the part's first tile (armed before the hidden layer)
-      if (wv < 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (r_begin < r_end) {                             // the part's first tile into the ring (its shares left before the hidden layer)
+      put(I0{}); put(I1{}); put(I2{}); put(I3{}); put(I4{});   // (stg[2..4] keep these shares: the first three turns write them once more)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      rd_step(std::integral_constant<int, 0>{}, FA);
+      rd_step(I0{}, FA);
       bias_r = *reinterpret_cast<const f32x4*>(ring + C3_TILE_BYTES + vB);
     }
     for (int r = r_begin; r < r_end; ++r) {
@@ -403,14 +419,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
           else if constexpr (m == 28) cop(B1{}, std::integral_constant<int, 0>{}, xp);
           else if constexpr (m >= 33 && m <= 54) cop(B1{}, std::integral_constant<int, m - 32>{}, xp);
         };
+        // tile i carries the contraction of tile i - 1; the run's first tile carries one of zeros (same code, no second copy
+        // of the loop body for the register allocator to fit)
         const float* xp = xs_lane + xo;
-        {   // the run's first tile: nothing of this run is pending
-          const int t = tile0;
-          tile(t < t_last ? t + 1 : t, [](auto) {});
-        }
-        for (int i = 1; i < nt; ++i, xp += x_step) {
+        accp[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accp[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < nt; ++i) {
           const int t = tile0 + i;
-          tile(t < t_last ? t + 1 : t, [&](auto mc) { travel(mc, xp); });     // tile i with the contraction of tile i - 1
+          tile(t < t_last ? t + 1 : t, [&](auto mc) { travel(mc, xp); });
+          if (i) xp += x_step;
         }
         // the run's last tile is contracted in the open (its successor belongs to another path type)
         __builtin_amdgcn_sched_barrier(0);
@@ -468,11 +484,25 @@ void launch_conv2r(const Conv2Args& a, hipStream_t st) {
     if (n_cu <= 0) n_cu = 256;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   Conv2Args b = a;
   b.skew = 0;
   b.run_barrier = 0;
   b.no_split = no_split;
   if (abl == 1) hipLaunchKernelGGL((k_conv2r<NW, 1>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else if (abl == 2) hipLaunchKernelGGL((k_conv2r<NW, 2>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else if (abl == 4) hipLaunchKernelGGL((k_conv2r<NW, 4>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else if (abl == 2) hipLaunchKernelGGL((k_conv2r<NW, 2>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else if (abl == 4) hipLaunchKernelGGL((k_conv2r<NW, 4>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else if (abl == 6) hipLaunchKernelGGL((k_conv2r<NW, 6>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else if (abl == 7) hipLaunchKernelGGL((k_conv2r<NW, 7>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  else if (abl == 8) hipLaunchKernelGGL((k_conv2r<NW, 8>), dim3(n_cu), dim3(64 * NW), lds, st, b);
   else hipLaunchKernelGGL((k_conv2r<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
 }
