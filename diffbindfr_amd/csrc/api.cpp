@@ -87,7 +87,9 @@ static int fail(int code, const std::string& s) { g_err = s; return code; }
 static int gemm_from_env() {
   const char* e = getenv("DBFR_GEMM");
   if (!e || !*e) return DBFR_GEMM_DEFAULT;
-  return (!strcmp(e, "split") || !strcmp(e, "1")) ? DBFR_GEMM_SPLIT_BF16 : DBFR_GEMM_F32;
+  if (!strcmp(e, "split") || !strcmp(e, "1")) return DBFR_GEMM_SPLIT_BF16;
+  if (!strcmp(e, "split_l1") || !strcmp(e, "2")) return DBFR_GEMM_SPLIT_BF16_L1;
+  return DBFR_GEMM_F32;
 }
 
 struct dbfr_model {
@@ -97,7 +99,7 @@ struct dbfr_model {
   ConvW final_conv, tor_conv, sc_conv;
   ConvW2 layer2[8][4], tor_conv2, sc_conv2;   // k_conv2 layouts of the K=144 convs
   int use_conv2;
-  int gemm_split;      // 1: the 144 x W GEMM of the K=144 convs runs on the bf16 matrix pipe with 3-piece operands (conv2s.hip), any batch size
+  int gemm_split;      // DBFR_GEMM_*; non-zero: the 144 x W GEMM of the K=144 convs runs on the bf16 matrix pipe with 3-piece operands (conv2s.hip), any batch size
   int conv_fuse;       // big batches: the four convs of a layer as one k_conv grid (conv.hip: k_conv_layer)
   int conv2_layers;    // big batches: interaction layers [0, conv2_layers) still go through k_conv2 (their short W2 favours it)
   int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
@@ -508,7 +510,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
 }
 
 extern "C" int dbfr_model_set_gemm(dbfr_model* m, int32_t mode) {
-  if (!m || (mode != DBFR_GEMM_F32 && mode != DBFR_GEMM_SPLIT_BF16)) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
+  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_SPLIT_BF16_L1) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
   m->gemm_split = mode;
   return DBFR_OK;
 }
@@ -809,8 +811,7 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     prof_events(m, &e0, &e1);
     (void)hipEventRecord(e0, st);
   }
-  static const int ring = getenv("DBFR_CONV2_RING") ? atoi(getenv("DBFR_CONV2_RING")) : 0;   // developer: 0 W2 through L1 (k_conv2s), 1 through the LDS ring (k_conv2r)
-  if (m->gemm_split && ring) launch_conv2r(a, st);
+  if (m->gemm_split == DBFR_GEMM_SPLIT_BF16) launch_conv2r(a, st);
   else if (m->gemm_split) launch_conv2s(a, st);
   else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);

@@ -389,16 +389,20 @@ int dbfr_mdn_pocket_features(int32_t n_graph, int32_t n_res, const int32_t* res_
 int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 
 /* Which matrix instruction carries the 144 x W GEMM of the radial MLP (97-99 % of the arithmetic) in the K=144 convs.
- * Both produce fp32 results from fp32 weights and fp32 activations:
- *   DBFR_GEMM_F32         v_mfma_f32_16x16x4_f32 (fp32 operands), k_conv / k_conv2;
- *   DBFR_GEMM_SPLIT_BF16  every operand cut into three bf16 pieces (a = a1 + a2 + a3 exactly), the six partial products
- *                         with i + j <= 4 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (k_conv2s, csrc/conv2s.hip):
- *                         measured error vs fp64 one third of the fp32 instruction's (tools/exp/split_bf16.hip; the tests
- *                         hold both modes to the same tolerances), 2.4x less matrix-pipe time; serves every batch size.
- * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split) says otherwise.
- * Set it before the first dbfr_workspace_bytes of a batch: a workspace is laid out for the mode it was sized in.      */
+ * All modes produce fp32 results from fp32 weights and fp32 activations:
+ *   DBFR_GEMM_F32            v_mfma_f32_16x16x4_f32 (fp32 operands): k_conv / k_conv2;
+ *   DBFR_GEMM_SPLIT_BF16     every operand cut into three bf16 pieces (a = a1 + a2 + a3 exactly), the six partial products
+ *                            with i + j <= 4 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: measured error vs fp64 one
+ *                            third of the fp32 instruction's (tools/exp/split_bf16.hip; the tests hold all modes to the same
+ *                            tolerances), 2.4x less matrix-pipe time; serves every batch size.  Kernel k_conv2r
+ *                            (csrc/conv2r.hip): the W2 pieces reach the waves through an LDS ring, one copy per tile per CU;
+ *   DBFR_GEMM_SPLIT_BF16_L1  the same arithmetic with every wave fetching its W2 pieces through the vector L1 (k_conv2s,
+ *                            csrc/conv2s.hip): the simpler kernel, ~10 % slower, kept for comparison.
+ * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_l1) says otherwise.
+ * A workspace is laid out for the mode it was sized in: set the mode before dbfr_workspace_bytes.                       */
 #define DBFR_GEMM_F32 0
 #define DBFR_GEMM_SPLIT_BF16 1
+#define DBFR_GEMM_SPLIT_BF16_L1 2
 #define DBFR_GEMM_DEFAULT DBFR_GEMM_SPLIT_BF16
 int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
 int dbfr_model_get_gemm(const dbfr_model* model);
