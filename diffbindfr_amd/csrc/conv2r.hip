@@ -244,16 +244,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) F[i] = *reinterpret_cast<const bf16x8*>(ring + (i * 4 + j) * 1024 + vW);
     };
-    // start of k-step s: my reads of slot s are in (and my earlier writes to the ring); once that holds for everybody the
-    // slot is free: my share of the next tile's k-step s sets out for its staging registers, and the share fetched three
-    // k-steps ago goes into its slot -- read again four k-steps from now, behind the barrier after next
+    // start of k-step s ("turn"): my share of the next tile's k-step s sets out for its staging registers (slot s was read during
+    // k-step s - 1), and the share fetched two turns ago goes into its slot, to be read two turns from now.  Turns 0, 2 and 4
+    // open with "my LDS reads and writes are done" + s_barrier; that is enough: between the last read of a slot (turn x) and its
+    // rewrite (turn x + 2), and between the rewrite and the next read (turn x + 4), there is always one of the three.
     auto turn = [&](auto sc, int t_next) {
       constexpr int s = decltype(sc)::value;
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+      if (s % 2 == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+      }
       fetch(sc, t_next);
-      put(std::integral_constant<int, (s + 2) % 5>{});
+      put(std::integral_constant<int, (s + 3) % 5>{});
       __builtin_amdgcn_sched_barrier(0);
     };
 #define X32(b, ai, hi, F, s) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ai], __builtin_bit_cast(bf16x8, Bh[b][hi][s]), acc[b], 0, 0, 0)
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
 #undef SLOT
     int x_phase = 0;
     if (r_begin < r_end) {                             // the part's first tile into the ring (its shares left before the hidden layer)
-      put(I0{}); put(I1{}); put(I2{}); put(I3{}); put(I4{});   // (stg[2..4] keep these shares: the first three turns write them once more)
+      put(I0{}); put(I1{}); put(I2{}); put(I3{}); put(I4{});   // (stg[3], stg[4] keep these shares: the first two turns write them once more)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       rd_step(I0{}, FA);
