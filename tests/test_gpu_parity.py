@@ -544,5 +544,6 @@ def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, 
         with gemm(model, mode):
             m = _run_conv_hook(fn, h, layer, fam, c, E, dev)
         err[mode] = float((m.cpu().double() - m64).abs().max() / m64.abs().max())
+    print("conv message error vs float64:", err)
     assert max(err.values()) < 2e-6, err
     assert err["split"] <= 1.25 * err["f32"] + 5e-8 and err["split_l1"] <= 1.25 * err["f32"] + 5e-8, err
