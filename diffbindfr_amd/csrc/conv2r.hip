@@ -244,54 +244,57 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) F[i] = *reinterpret_cast<const bf16x8*>(ring + (i * 4 + j) * 1024 + vW);
     };
-    // start of k-step s ("turn"): my share of the next tile's k-step s sets out for its staging registers (slot s was read during
-    // k-step s - 1), and the share fetched two turns ago goes into its slot, to be read two turns from now.  Turns 0, 2 and 4
-    // open with "my LDS reads and writes are done" + s_barrier; that is enough: between the last read of a slot (turn x) and its
-    // rewrite (turn x + 2), and between the rewrite and the next read (turn x + 4), there is always one of the three.
-    auto turn = [&](auto sc, int t_next) {
+    // k-step s ("turn"): my share of the next tile's k-step s sets out for its staging registers (slot s was read during k-step
+    // s - 1), the share fetched two turns ago goes into its slot, to be read two turns from now, and the next k-step's fragments
+    // are requested -- each of the three behind one of the turn's first MFMAs, so that a wave leaves a barrier straight into matrix
+    // work (the waves of a workgroup pass the barriers together: whatever follows one is a bubble on every SIMD at once).
+    // Turns 0, 2 and 4 open with "my LDS reads and writes are done" + s_barrier; that is enough: between the last read of a slot
+    // (turn x) and its rewrite (turn x + 2), and between the rewrite and the next read (turn x + 4), there is always one of the three.
+    auto turn = [&](auto sc) {
       constexpr int s = decltype(sc)::value;
-      __builtin_amdgcn_sched_barrier(0);
       if (s % 2 == 0) {
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
       }
-      fetch(sc, t_next);
-      put(std::integral_constant<int, (s + 3) % 5>{});
-      __builtin_amdgcn_sched_barrier(0);
     };
 #define X32(b, ai, hi, F, s) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ai], __builtin_bit_cast(bf16x8, Bh[b][hi][s]), acc[b], 0, 0, 0)
 #define X16(b, ai, hi) acc[b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(FT[ai], __builtin_bit_cast(s16x4, Bt[b][hi]), acc[b], 0, 0, 0)
 #define SLOT(m) do { op(std::integral_constant<int, (m)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
     // one tile: 60 MFMAs = 5 k-steps x 6 partial products (smallest first) x 2 edge blocks, `op(m)` = what travels behind MFMA m
     auto tile = [&](int t_next, auto&& op) {
-      auto kstep = [&](auto sc, bf16x8 (&F)[3]) {
+      // e0 / e1 / e2: the turn's fetch, put and fragment request, behind MFMA 0 / 1 / 2 of the k-step
+      auto kstep = [&](auto sc, bf16x8 (&F)[3], auto&& e0, auto&& e1, auto&& e2) {
         constexpr int s = decltype(sc)::value;
-        X32(0, 2, 0, F, s); SLOT(12 * s + 0); X32(1, 2, 0, F, s); SLOT(12 * s + 1);
-        X32(0, 1, 1, F, s); SLOT(12 * s + 2); X32(1, 1, 1, F, s); SLOT(12 * s + 3);
+        X32(0, 2, 0, F, s); e0(); SLOT(12 * s + 0); X32(1, 2, 0, F, s); e1(); SLOT(12 * s + 1);
+        X32(0, 1, 1, F, s); e2(); SLOT(12 * s + 2); X32(1, 1, 1, F, s); SLOT(12 * s + 3);
         X32(0, 0, 2, F, s); SLOT(12 * s + 4); X32(1, 0, 2, F, s); SLOT(12 * s + 5);
         X32(0, 1, 0, F, s); SLOT(12 * s + 6); X32(1, 1, 0, F, s); SLOT(12 * s + 7);
         X32(0, 0, 1, F, s); SLOT(12 * s + 8); X32(1, 0, 1, F, s); SLOT(12 * s + 9);
         X32(0, 0, 0, F, s); SLOT(12 * s + 10); X32(1, 0, 0, F, s); SLOT(12 * s + 11);
       };
-      turn(I0{}, t_next); rd_step(I1{}, FB);
+      turn(I0{});
       acc[0] = bias_r; acc[1] = bias_r;
-      kstep(I0{}, FA);
-      turn(I1{}, t_next); rd_step(I2{}, FA);
-      kstep(I1{}, FB);
-      turn(I2{}, t_next); rd_step(I3{}, FB);
-      kstep(I2{}, FA);
-      turn(I3{}, t_next);
+      kstep(I0{}, FA, [&] { fetch(I0{}, t_next); }, [&] { put(I3{}); }, [&] { rd_step(I1{}, FB); });
+      turn(I1{});
+      kstep(I1{}, FB, [&] { fetch(I1{}, t_next); }, [&] { put(I4{}); }, [&] { rd_step(I2{}, FA); });
+      turn(I2{});
+      kstep(I2{}, FA, [&] { fetch(I2{}, t_next); }, [&] { put(I0{}); }, [&] { rd_step(I3{}, FB); });
+      turn(I3{});
+      kstep(I3{}, FB, [&] { fetch(I3{}, t_next); }, [&] { put(I1{}); }, [&] {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) FT[i] = *reinterpret_cast<const s16x4*>(ring + C3_TAIL_OFF + i * 512 + lane * 8);
-      kstep(I3{}, FB);
-      turn(I4{}, t_next); rd_step(I0{}, FA);              // the NEXT tile's first k-step and bias
-      bias_r = *reinterpret_cast<const f32x4*>(ring + C3_TILE_BYTES + vB);
+        for (int i = 0; i < 3; ++i) FT[i] = *reinterpret_cast<const s16x4*>(ring + C3_TAIL_OFF + i * 512 + lane * 8);
+      });
+      turn(I4{});
       // k = 128..143 on v_mfma_f32_16x16x16_bf16.  Hazard (MI355X + ROCm 7.2, conv2s.hip): an x16 MFMA taking as SrcC an
       // accumulator an x32 MFMA has just written reads stale data; 16 wait states put any pass count behind us.
-      if (!(ABL & 8)) asm volatile("s_nop 15");
+      asm volatile("s_nop 15");
       __builtin_amdgcn_sched_barrier(0);
-      X16(0, 2, 0); SLOT(48); X16(1, 2, 0); SLOT(49);
-      X16(0, 1, 1); SLOT(50); X16(1, 1, 1); SLOT(51);
+      X16(0, 2, 0); fetch(I4{}, t_next); SLOT(48); X16(1, 2, 0); put(I2{}); SLOT(49);
+      X16(0, 1, 1); rd_step(I0{}, FA);                   // the NEXT tile's first k-step and bias
+      bias_r = *reinterpret_cast<const f32x4*>(ring + C3_TILE_BYTES + vB);
+      SLOT(50); X16(1, 1, 1); SLOT(51);
       X16(0, 0, 2); SLOT(52); X16(1, 0, 2); SLOT(53);
       X16(0, 1, 0); SLOT(54); X16(1, 1, 0); SLOT(55);
       X16(0, 0, 1); SLOT(56); X16(1, 0, 1); SLOT(57);
