@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.dbfr_abi_version() == 2
 
 
+def test_gemm_mode_entry_points_reject_bad_arguments():
+    """dbfr_model_set_gemm / dbfr_model_get_gemm (include/dbfr.h): argument checks need no GPU."""
+    lib = L.load()
+    assert lib.dbfr_model_set_gemm(None, 1) == -1 and b"dbfr_model_set_gemm" in lib.dbfr_last_error()
+    assert lib.dbfr_model_get_gemm(None) == -1
+    hdr = open(os.path.join(ROOT, "include", "dbfr.h")).read()
+    modes = dict(re.findall(r"#define (DBFR_GEMM_[A-Z0-9_]+) (\w+)", hdr))
+    assert modes["DBFR_GEMM_F32"] == "0" and modes["DBFR_GEMM_SPLIT_BF16"] == "1" and modes["DBFR_GEMM_SPLIT_BF16_L1"] == "2"
+    assert modes["DBFR_GEMM_DEFAULT"] == "DBFR_GEMM_SPLIT_BF16"
+
+
 def test_product_schedule_matches_reference_fixture():
     z = np.load(os.path.join(GOLDEN, "schedule.npz"))
     recs, arr = psched.steps(psched.sample_cfg())
