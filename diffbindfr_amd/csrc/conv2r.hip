@@ -51,7 +51,7 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned& p0, unsig
 #define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
 #define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
 
-template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no re-arming, 8 no hazard nop
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling, 32 no LDS wait in front of the barriers, 8 no hazard nop
 __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
   constexpr int K = 144, KT = 9;
   constexpr int EPB = 32 * NW;                       // edges per block (unit)
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
       constexpr int s = decltype(sc)::value;
       if (s % 2 == 0) {
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(ABL & 32)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
 void launch_conv2r(const Conv2Args& a, hipStream_t st) {
   static int n_cu = 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
-  static int abl = getenv("DBFR_CONV2R_ABL") ? atoi(getenv("DBFR_CONV2R_ABL")) : 0;
+  static int abl = getenv("DBFR_CONV2R_ABL") ? atoi(getenv("DBFR_CONV2R_ABL")) : 0;   // developer ablations (wrong results)
   constexpr int NW = 8;
   const size_t lds = C3_RING_BYTES + (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
   if (!n_cu) {
@@ -489,26 +489,14 @@ void launch_conv2r(const Conv2Args& a, hipStream_t st) {
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   Conv2Args b = a;
   b.skew = 0;
   b.run_barrier = 0;
   b.no_split = no_split;
-  if (abl == 1) hipLaunchKernelGGL((k_conv2r<NW, 1>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 2) hipLaunchKernelGGL((k_conv2r<NW, 2>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 4) hipLaunchKernelGGL((k_conv2r<NW, 4>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 2) hipLaunchKernelGGL((k_conv2r<NW, 2>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 4) hipLaunchKernelGGL((k_conv2r<NW, 4>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 6) hipLaunchKernelGGL((k_conv2r<NW, 6>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 7) hipLaunchKernelGGL((k_conv2r<NW, 7>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 8) hipLaunchKernelGGL((k_conv2r<NW, 8>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else hipLaunchKernelGGL((k_conv2r<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+#define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                         hipLaunchKernelGGL((k_conv2r<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
+  V(1) V(2) V(34)
+#undef V
+  hipLaunchKernelGGL((k_conv2r<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
 }
