@@ -4,16 +4,17 @@
 // vector L1: 64 B/clk of L1 bandwidth are ~80 % busy with it and the sweep waits for its loads (no re-load: 279, with: 194
 // fp32-equivalent TFLOP/s on one big conv).  Here ONE copy per tile enters the CU:
 //   * an LDS ring of five slots, one per k-step of a tile (4 x three 1-KiB pieces, the last 16 k, + the tile's 16 bias
-//     values), laid out like the tile in memory and filled by LDS-DMA (global_load_lds, no register path);
+//     values), laid out like the tile in memory.  It is filled by the waves themselves in 512-byte shares: one 8-byte load per
+//     lane into a staging register pair, one ds_write_b64 two k-steps later (why not LDS-DMA, and why without a single
+//     branch: at `fetch` / `put` below);
 //   * a wave keeps only TWO k-steps of W2 fragments in registers (the one its MFMAs read, the next one arriving from the ring
 //     by ds_read_b128, lane-linear = conflict-free) instead of a whole tile, which pays for a second accumulator set:
 //     both edge blocks run through a k-step together (two accumulator chains, fragments read once per tile), and the
 //     contraction of tile i - 1 is hand-interleaved into the issue gaps of tile i's 60 MFMAs (conv2s.hip explains why the
 //     wave has to hide it itself);
-//   * slot s is read by everybody during k-step s - 1; at the start of k-step s one s_barrier says "all have read it", wave s
-//     re-arms it with k-step s of the next tile -- a whole tile period to land -- and the wave that armed slot s + 1 a tile
-//     ago first makes sure its copy is there.  Five barriers per tile, not waited for in steady state: the waves of a
-//     workgroup do identical work.
+//   * slot s is read by everybody during k-step s - 1, re-filled with the next tile's k-step s during k-step s + 2 and read
+//     again two k-steps later; an s_barrier at the start of k-steps 0, 2 and 4 is all the ordering that needs (`turn` below).
+//     Three barriers per tile, rarely waited for: the waves of a workgroup do identical work.
 // Everything else (unit queue, hidden layer in registers, x rows / harmonics in wave-private LDS, channel-owner accumulation,
 // tail split, bitwise independence from the unit -> workgroup assignment) is conv2s.hip's.
 #include <cstdio>
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
     const int E = min(*d.n_edges, d.max_edges);
     const int e0 = blk * EPB + 32 * wave;
     // (a wave without edges in this block runs along on clamped edges and stores nothing: the ring barriers need all eight)
-    //                        // this wave has no edge in the block (the loop-top barrier is still reached)
     const int D_in = d.w.D_in, D_out = d.w.D_out;
     const int vW = lane * 16, vB = g * 16;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -220,15 +220,25 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
     }
     // ---- x[gth] rows of the wave's 32 edges into its LDS region (columns [0, min(D_in, 120)))
     __builtin_amdgcn_wave_barrier();
-    {
+    {   // lane L moves the 16-byte chunks (L >> 5), (L >> 5) + 2, ... of row L & 31: all loads out before the first store, no
+        // index arithmetic (as `for (i = lane; i < 32 * d4; i += 64)` hipcc made every chunk a division, an LDS look-up, two
+        // scalar loads, a global load and its store in strict sequence: ~10 us per unit).  Chunks past the row's end repeat its
+        // last one: same bytes to the same place.
       const int d4 = min(D_in, 120) >> 2;
-      for (int i = lane; i < 32 * d4; i += 64) {
-        const int el = i / d4, c4 = i - el * d4;
-        *reinterpret_cast<f32x4*>(xs + el * C2_XLD + 4 * c4) = *reinterpret_cast<const f32x4*>(d.x + (size_t)s_gth[el] * d.ldx + 4 * c4);
-      }
+      const float* xsrc = d.x + (size_t)s_gth[lane & 31] * d.ldx;
+      float* xdst = xs + (lane & 31) * C2_XLD;
+      f32x4 v[15];
+#pragma unroll
+      for (int j = 0; j < 15; ++j) v[j] = *reinterpret_cast<const f32x4*>(xsrc + 4 * min(2 * j + (lane >> 5), d4 - 1));
+#pragma unroll
+      for (int j = 0; j < 15; ++j) *reinterpret_cast<f32x4*>(xdst + 4 * min(2 * j + (lane >> 5), d4 - 1)) = v[j];
     }
     __builtin_amdgcn_wave_barrier();
 
+    if (ABL & 64) {   // developer: the unit prologue alone
+      asm volatile("" ::"v"(Bh[0][0][0]), "v"(Bh[1][2][3]), "v"(Bt[1][2]));
+      continue;
+    }
     // ---- the W2 row tiles of this part, run by run (channel-owner order, api.cpp pack_conv2)
     float oacc[2][3];
 #pragma unroll
@@ -319,9 +329,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
       const int xo = (rd.x_off4 >> (8 * g)) & 0xff, oo = (rd.o_off4 >> (8 * g)) & 0xff;
       if (xph != x_phase) {   // second output half: the scalar slot [0,48) now holds the 48x0o inputs x[120:168]
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < 32 * 12; i += 64) {
-          const int el = i / 12, c4 = i - el * 12;
-          *reinterpret_cast<f32x4*>(xs + el * C2_XLD + 4 * c4) = *reinterpret_cast<const f32x4*>(d.x + (size_t)s_gth[el] * d.ldx + 120 + 4 * c4);
+        {
+          const float* xsrc = d.x + (size_t)s_gth[lane & 31] * d.ldx + 120;
+          float* xdst = xs + (lane & 31) * C2_XLD;
+          f32x4 v[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) v[j] = *reinterpret_cast<const f32x4*>(xsrc + 4 * (2 * j + (lane >> 5)));
+#pragma unroll
+          for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(xdst + 4 * (2 * j + (lane >> 5))) = v[j];
         }
         __builtin_amdgcn_wave_barrier();
         x_phase = xph;
@@ -496,7 +511,7 @@ void launch_conv2r(const Conv2Args& a, hipStream_t st) {
   b.no_split = no_split;
 #define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                          hipLaunchKernelGGL((k_conv2r<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
-  V(1) V(2) V(34)
+  V(1) V(2) V(34) V(64)
 #undef V
   hipLaunchKernelGGL((k_conv2r<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
 }
