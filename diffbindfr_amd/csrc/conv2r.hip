@@ -449,7 +449,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
           tile(t < t_last ? t + 1 : t, [&](auto mc) { travel(mc, xp); });
           if (i) xp += x_step;
         }
-        // the run's last tile is contracted in the open (its successor belongs to another path type)
+        // the run's last tile is contracted in the open (its successor belongs to another path type).  Its accumulators were
+        // last written by x16 MFMAs a few instructions ago: hipcc's wait states for that opcode are not to be relied on (see
+        // the hazard above), and nothing but LDS latency stands between them and the first FMA that reads them
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15");
         __builtin_amdgcn_sched_barrier(0);
 #define COPS(b) cop(b, std::integral_constant<int, 0>{}, xp); cop(b, std::integral_constant<int, 1>{}, xp); cop(b, std::integral_constant<int, 2>{}, xp); \
         cop(b, std::integral_constant<int, 3>{}, xp); cop(b, std::integral_constant<int, 4>{}, xp); cop(b, std::integral_constant<int, 5>{}, xp); \
