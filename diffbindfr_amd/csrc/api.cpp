@@ -811,6 +811,19 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     prof_events(m, &e0, &e1);
     (void)hipEventRecord(e0, st);
   }
+  // developer timeline of k_conv2r: DBFR_CONV2_TRACE=<file> (+ DBFR_CONV2R_ABL=128): the stamps of the LAST traced launch are written at exit
+  static unsigned long long* trace_dev = nullptr;
+  static const char* trace_file = getenv("DBFR_CONV2_TRACE");
+  if (trace_file && !trace_dev) {
+    if (hipMalloc(&trace_dev, 8 * C2_TRACE_CAP * sizeof(unsigned long long)) != hipSuccess) trace_dev = nullptr;
+    else atexit([] {
+      std::vector<unsigned long long> h(8 * C2_TRACE_CAP);
+      if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* f = fopen(getenv("DBFR_CONV2_TRACE"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      }
+    });
+  }
+  if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, 8 * C2_TRACE_CAP * sizeof(unsigned long long), st); a.trace = trace_dev; }
   if (m->gemm_split == DBFR_GEMM_SPLIT_BF16) launch_conv2r(a, st);
   else if (m->gemm_split) launch_conv2s(a, st);
   else launch_conv2(a, st);

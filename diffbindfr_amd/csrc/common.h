@@ -103,7 +103,9 @@ struct Conv2Args {
   int* queue;             // [2] device ints, zero at launch: next unit, workgroups done (re-armed by the last one)
   int run_barrier, no_split;   // developer knobs (launch_conv2)
   int skew;                    // start delay of the second half of the waves, in 512-cycle sleeps
+  unsigned long long* trace;   // developer timeline of k_conv2r (DBFR_CONV2_TRACE=<file>): [8 waves][C2_TRACE_CAP] shader-clock stamps of workgroup 0, or null
 };
+#define C2_TRACE_CAP 4096
 
 static inline uint16_t dbfr_bf16_rne(float x) {   // round-to-nearest-even fp32 -> bf16 (finite inputs)
   uint32_t u;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned& p0, unsig
 #define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
 #define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
 
-template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling, 32 no LDS wait in front of the barriers, 8 no hazard nop
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling, 32 no LDS wait in front of the barriers, 64 unit prologue only, 128 timeline stamps (DBFR_CONV2_TRACE), 8 no hazard nop
 __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
   constexpr int K = 144, KT = 9;
   constexpr int EPB = 32 * NW;                       // edges per block (unit)
@@ -66,6 +66,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
   float* shs = xs + 32 * C2_XLD;                     // [32][10]
   float* ms = shs + 32 * 10;                         // [32][8]
   int* s_gth = reinterpret_cast<int*>(ms + 32 * 8);  // [32]
+  // developer timeline (ABL 128): stamps (tag << 56 | shader clock) of workgroup 0, one list per wave (tools/exp/ring_trace.py)
+  int tr_n = 0;
+  auto stamp = [&](unsigned long long tag) {
+    if ((ABL & 128) && a.trace && blockIdx.x == 0 && lane == 0 && tr_n < C2_TRACE_CAP)
+      a.trace[(size_t)wave * C2_TRACE_CAP + tr_n++] = (tag << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull);
+  };
 
   // ---- the launch's unit list (every workgroup derives it from the device-side edge counts)
   int nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0;
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
     }
     __builtin_amdgcn_wave_barrier();
 
+    stamp(0x01);                                         // prologue done
     if (ABL & 64) {   // developer: the unit prologue alone
       asm volatile("" ::"v"(Bh[0][0][0]), "v"(Bh[1][2][3]), "v"(Bt[1][2]));
       continue;
@@ -264,8 +271,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
       constexpr int s = decltype(sc)::value;
       if (s % 2 == 0) {
         __builtin_amdgcn_sched_barrier(0);
+        stamp(0x10 + s);                                 // arrival at the turn
         if (!(ABL & 32)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(0x20 + s);                                 // my LDS operations are done
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        stamp(0x30 + s);                                 // everybody is here
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (ABL & 128) {
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(0x10 + s);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -311,6 +325,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
       X16(0, 0, 0); SLOT(58); X16(1, 0, 0); SLOT(59);
       accp[0] = acc[0]; accp[1] = acc[1];
       __builtin_amdgcn_sched_barrier(0);
+      stamp(0x40);                                       // tile done
     };
 #undef SLOT
     int x_phase = 0;
@@ -453,6 +468,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
         // last written by x16 MFMAs a few instructions ago: hipcc's wait states for that opcode are not to be relied on (see
         // the hazard above), and nothing but LDS latency stands between them and the first FMA that reads them
         __builtin_amdgcn_sched_barrier(0);
+        stamp(0x50);                                     // run's last contraction starts
         asm volatile("s_nop 15");
         __builtin_amdgcn_sched_barrier(0);
 #define COPS(b) cop(b, std::integral_constant<int, 0>{}, xp); cop(b, std::integral_constant<int, 1>{}, xp); cop(b, std::integral_constant<int, 2>{}, xp); \
@@ -465,6 +481,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
         cop(b, std::integral_constant<int, 21>{}, xp);
         COPS(B0{}) COPS(B1{})
 #undef COPS
+        stamp(0x51);
         if (flags & 2) {   // last run of the channel group: this lane owns msg[e][oo .. oo + (VOUT ? 3 : 1))
           if (oo < D_out) {
 #pragma unroll
@@ -515,7 +532,7 @@ void launch_conv2r(const Conv2Args& a, hipStream_t st) {
   b.no_split = no_split;
 #define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                          hipLaunchKernelGGL((k_conv2r<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
-  V(1) V(2) V(34) V(64)
+  V(1) V(2) V(34) V(64) V(128)
 #undef V
   hipLaunchKernelGGL((k_conv2r<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
 }
