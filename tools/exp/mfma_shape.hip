@@ -18,8 +18,8 @@ __device__ __forceinline__ bf16x8 rnd(unsigned seed) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int SHAPE, int FILL>
-__global__ __launch_bounds__(512, 1) void k(float* out, int tiles) {
+template <int SHAPE, int FILL, int FEAT = 0>
+__global__ __launch_bounds__(512, 1) void k(float* out, int tiles, const unsigned* src = nullptr) {
   __shared__ __attribute__((aligned(16))) char frag[32 * 1024];   // stands for the ring: fragments read lane-linear
   __shared__ __attribute__((aligned(16))) float xs[8 * 32 * 24];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int tiles) {
     bf16x8 B[2][3][5];
     for (int b = 0; b < 2; ++b) for (int i = 0; i < 3; ++i) for (int s = 0; s < 5; ++s) B[b][i][s] = rnd(lane * 31 + (b * 3 + i) * 5 + s);
     f32x4 tot = {0, 0, 0, 0};
+    unsigned long long stgv[5] = {0, 0, 0, 0, 0};
     for (int t = 0; t < tiles; ++t) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {          // two 16-row tiles = 32 rows
@@ -44,6 +45,21 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int tiles) {
         fcount = 0;
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
+          if ((FEAT & 1) && (s % 2 == 0)) {            // the ring's lock-step points: k-steps 0, 2, 4
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (FEAT & 2) {                                // ring filling: one 8-byte load per lane now, written two k-steps later
+            if (FEAT & 4) {                              // ... or a whole tile (five k-steps) later
+              *reinterpret_cast<unsigned long long*>(frag + 31 * 1024 + lane * 8) = stgv[s];
+              stgv[s] = *reinterpret_cast<const unsigned long long*>(src + ((t * 10 + half * 5 + s) & 1023) * 128 + lane * 2);
+            } else {
+              stgv[s] = *reinterpret_cast<const unsigned long long*>(src + ((t * 10 + half * 5 + s) & 1023) * 128 + lane * 2);
+              *reinterpret_cast<unsigned long long*>(frag + 31 * 1024 + lane * 8) = stgv[(s + 3) % 5];
+            }
+          }
           const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(fl + ((half * 15 + s) & 31) * 1024);
           const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(fl + ((half * 15 + 5 + s) & 31) * 1024);
           const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(fl + ((half * 15 + 10 + s) & 31) * 1024);
@@ -81,22 +97,22 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int tiles) {
 int main() {
   float* out; hipMalloc(&out, 256 * 512 * 4);
   const int tiles = 2000;
-  for (int fill = 0; fill < 2; ++fill)
-    for (int shape = 0; shape < 2; ++shape) {
-      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-      for (int rep = 0; rep < 2; ++rep) {
-        hipEventRecord(e0, 0);
-        if (shape == 0 && fill == 0) hipLaunchKernelGGL((k<0, 0>), dim3(256), dim3(512), 0, 0, out, tiles);
-        if (shape == 0 && fill == 1) hipLaunchKernelGGL((k<0, 1>), dim3(256), dim3(512), 0, 0, out, tiles);
-        if (shape == 1 && fill == 0) hipLaunchKernelGGL((k<1, 0>), dim3(256), dim3(512), 0, 0, out, tiles);
-        if (shape == 1 && fill == 1) hipLaunchKernelGGL((k<1, 1>), dim3(256), dim3(512), 0, 0, out, tiles);
-        hipEventRecord(e1, 0); hipEventSynchronize(e1);
-      }
-      float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-      const double flop = 256.0 * 8 * tiles * 32.0 * 32.0 * 144.0 * 2.0;   // algorithmic fp32 flops
-      printf("%-28s %-44s %8.3f ms  %7.1f fp32-equivalent TFLOP/s  (%6.1f ns per 32 rows x 32 edges per wave)\n",
-             shape == 0 ? "v_mfma_f32_16x16x32_bf16" : "v_mfma_f32_32x32x16_bf16", fill ? "fragments from LDS + interleaved fillers" : "fragments from LDS, MFMAs only",
-             ms, flop / (ms * 1e-3) * 1e-12, ms * 1e6 / tiles);
-    }
+  unsigned* src; hipMalloc(&src, 1024 * 128 * 4); hipMemset(src, 0x3c, 1024 * 128 * 4);
+  auto report = [&](const char* shape, const char* what, float ms) {
+    const double flop = 256.0 * 8 * tiles * 32.0 * 32.0 * 144.0 * 2.0;   // algorithmic fp32 flops
+    printf("%-28s %-64s %8.3f ms  %7.1f fp32-equivalent TFLOP/s\n", shape, what, ms, flop / (ms * 1e-3) * 1e-12);
+  };
+#define RUN(KERN, shape, what) do { hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms = 0; \
+    for (int rep = 0; rep < 3; ++rep) { hipEventRecord(e0, 0); hipLaunchKernelGGL((KERN), dim3(256), dim3(512), 0, 0, out, tiles, src); hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); } \
+    report(shape, what, ms); } while (0)
+  RUN((k<0, 0>), "v_mfma_f32_16x16x32_bf16", "fragments from LDS, MFMAs only");
+  RUN((k<1, 0>), "v_mfma_f32_32x32x16_bf16", "fragments from LDS, MFMAs only");
+  RUN((k<0, 1>), "v_mfma_f32_16x16x32_bf16", "+ interleaved fillers");
+  RUN((k<1, 1>), "v_mfma_f32_32x32x16_bf16", "+ interleaved fillers");
+  RUN((k<0, 1, 1>), "v_mfma_f32_16x16x32_bf16", "+ fillers + three barriers per 16-row tile");
+  RUN((k<0, 1, 2>), "v_mfma_f32_16x16x32_bf16", "+ fillers + ring filling (load, ds_write two k-steps later)");
+  RUN((k<0, 1, 3>), "v_mfma_f32_16x16x32_bf16", "+ fillers + barriers + ring filling");
+  RUN((k<0, 1, 6>), "v_mfma_f32_16x16x32_bf16", "+ fillers + ring filling, written five k-steps after the load");
+  RUN((k<0, 1, 7>), "v_mfma_f32_16x16x32_bf16", "+ fillers + barriers + ring filling written five k-steps later");
   return 0;
 }
