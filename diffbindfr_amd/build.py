@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdbfr.so")
-SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "conv2.hip", "conv2s.hip", "conv2r.hip", "graph.hip", "heads.hip", "export.hip", "mdn.hip"]
+SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "conv2.hip", "conv2s.hip", "conv2r.hip", "conv2h.hip", "graph.hip", "heads.hip", "export.hip", "mdn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # conv: no SLP vectorisation -- it pairs the contraction FMAs of different edge blocks into v_pk_fma_f32 with a v_mov
 # shuffle per operand pair, which costs more vector-pipe slots next to the MFMAs than it saves and makes the kernel spill.
@@ -27,6 +27,7 @@ FILE_FLAGS["mdn.hip"] = ["-ffp-contract=off"]
 FILE_FLAGS["conv2.hip"] = ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-array-bounds"]
 FILE_FLAGS["conv2s.hip"] = FILE_FLAGS["conv2.hip"]
 FILE_FLAGS["conv2r.hip"] = FILE_FLAGS["conv2.hip"] + ["-Rpass-analysis=kernel-resource-usage"]
+FILE_FLAGS["conv2h.hip"] = FILE_FLAGS["conv2r.hip"]
 DEFAULT_FP = ["-ffp-contract=off"]
 
 

@@ -13,6 +13,7 @@ void launch_conv_layer(const ConvArgs* c4, hipStream_t st);
 void launch_conv2(const Conv2Args& a, hipStream_t st);
 void launch_conv2s(const Conv2Args& a, hipStream_t st);
 void launch_conv2r(const Conv2Args& a, hipStream_t st);
+void launch_conv2h(const Conv2Args& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
                       const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
 struct ReduceLayerArgs {
@@ -72,7 +73,10 @@ void launch_extract_templates(int n_res, const int* aatype, const float* pos14, 
                               float* rigid, float* angle, hipStream_t st);
 void launch_select_pocket(int n_prot, int n_res_total, const int* res_ptr, int m, const float* pos, const float* mask, const int* ref_ptr,
                           const float* ref, float cut2, int max_neighbors, float* d2, unsigned char* out, hipStream_t st);
-void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st);
+void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double fused_bytes_per_edge, double* counter, hipStream_t st);
+// HBM bytes per edge of the FUSED conv (what the kernels of this library have to move): edge record (48 embedding floats, 9 harmonics,
+// 3 indices), two gathered 48-float rows for the radial MLP, the gathered D_in-float input row, the D_out-float message
+static inline double fused_bytes(int D_in, int D_out) { return 4.0 * (48 + 9 + 3 + 48 + 48 + D_in + D_out); }
 
 // AF2 residue constant tables (data only; generated from the reference's protein_constants.py by tests/golden/make_residue_tables.py)
 #define RT_TABLE static const
@@ -89,6 +93,7 @@ static int gemm_from_env() {
   if (!e || !*e) return DBFR_GEMM_DEFAULT;
   if (!strcmp(e, "split") || !strcmp(e, "1")) return DBFR_GEMM_SPLIT_BF16;
   if (!strcmp(e, "split_l1") || !strcmp(e, "2")) return DBFR_GEMM_SPLIT_BF16_L1;
+  if (!strcmp(e, "split_f16") || !strcmp(e, "3")) return DBFR_GEMM_SPLIT_F16;
   return DBFR_GEMM_F32;
 }
 
@@ -114,6 +119,7 @@ struct dbfr_model {
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   double* flops_dev;
+  double fused_bytes_last;   // third counter as of the last dbfr_profile_read (before its reset)
   double conv_ms_acc; int64_t conv_launches_acc;
   // side streams for small batches: the four convs of an interaction layer (and the three heads) are independent
   hipStream_t side[3];
@@ -355,6 +361,43 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
   return rc;
 }
 
+// Tiles [tile0, tile0 + nt) of a [tile][K/16][64][4] fp32 fragment array (K = 144) -> the k_conv2h tile format, all with ONE
+// power-of-two factor 2^k (returned).  hi = fp16(v 2^k), lo = fp16(v 2^k - hi), both rounded to nearest even: 2 x 11 significand
+// bits + the sign of lo = 23 of fp32's 24.  fp16 has five exponent bits, so 2^k puts the largest |v| of these tiles into
+// [2^14, 2^15): pieces of every value within 2^-17 of that maximum stay exact to 22 bits (fp16 subnormals reach down to 2^-24 and
+// the matrix pipe keeps them -- tools/exp/split_f16.hip part D), smaller ones keep an absolute error of 2^-40 of the maximum.
+// Per tile: [2 pieces][4 k-steps of 32][64][8] -- step s = fp32 k-steps 2s and 2s+1 of the same lane -- then [2 pieces][64][4]
+// for the last 16 k, then the tile's 16 bias values (fp32) x 2^k = 9280 B.
+#define CH_TILE_BYTES_HOST 9280
+static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int nt, uint16_t* out) {
+  constexpr int KT = 9;
+  const size_t tile_h = CH_TILE_BYTES_HOST / 2, tail_off = 8192 / 2, bias_off = 9216 / 2;
+  auto h16 = [](float v) { const _Float16 h = (_Float16)v; uint16_t u; memcpy(&u, &h, 2); return u; };
+  float mx = 0.f;
+  for (size_t i = (size_t)tile0 * KT * 256; i < (size_t)(tile0 + nt) * KT * 256; ++i) mx = std::max(mx, fabsf(frag[i]));
+  int e = 0;
+  if (mx > 0.f) (void)frexpf(mx, &e);            // mx = f 2^e, f in [0.5, 1)
+  const int k = mx > 0.f ? std::max(-120, std::min(120, 15 - e)) : 0;
+  const float sc = ldexpf(1.f, k);
+  for (int t = tile0; t < tile0 + nt; ++t) {
+    float b[16];
+    for (int i = 0; i < 16; ++i) b[i] = bias16[16 * t + i] * sc;
+    memcpy(&out[t * tile_h + bias_off], b, 64);
+    for (int s4 = 0; s4 < KT; ++s4)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int q = 0; q < 4; ++q) {
+          const float v = frag[(((size_t)t * KT + s4) * 64 + lane) * 4 + q] * sc;
+          const _Float16 hi = (_Float16)v;
+          const uint16_t pc[2] = {h16(v), h16(v - (float)hi)};
+          for (int i = 0; i < 2; ++i) {
+            if (s4 < 8) out[t * tile_h + ((size_t)(i * 4 + (s4 >> 1)) * 64 + lane) * 8 + 4 * (s4 & 1) + q] = pc[i];
+            else out[t * tile_h + tail_off + ((size_t)i * 64 + lane) * 4 + q] = pc[i];
+          }
+        }
+  }
+  return k;
+}
+
 // k_conv2 layout (conv2.hip): same channel-owner row order as pack_conv, but ONE tile sequence for all waves.
 static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, int kind, const ConvW& base, ConvW2* o) {
   ConvSpec sp = make_conv_spec(kind);
@@ -491,6 +534,29 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
           }
     o->W2s = upload(m, w2s, &rc);
   }
+  {   // ... and into TWO fp16 pieces (conv2h.hip), run by run (a run = the tiles of one tensor-product path of one channel group):
+      // pack_f16_tiles below.  k travels in RunDesc.meta bits 24..31; the kernel folds 2^-k into the run's harmonics.
+    std::vector<uint16_t> w2h((size_t)n_tiles * (CH_TILE_BYTES_HOST / 2) + 512, 0);
+    for (RunDesc& rd : runs) {
+      const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
+      const int k = pack_f16_tiles(w2q.data(), b2q.data(), tile0, nt, w2h.data());
+      rd.meta = (rd.meta & 0x00ffffffu) | ((uint32_t)(k & 0xff) << 24);
+    }
+    o->W2h = upload(m, w2h, &rc);
+    // the hidden layer W1 (144 x 144) the same way: nine 16-row tiles with ONE factor 2^k1
+    const float* W1 = need(tm, name + ".fc.lin.0.weight", (int64_t)K * K, &rc);
+    const float* B1 = need(tm, name + ".fc.lin.0.bias", K, &rc);
+    if (rc) return rc;
+    std::vector<float> w1q((size_t)KT * KT * 256);
+    for (int mt = 0; mt < KT; ++mt)
+      for (int s4 = 0; s4 < KT; ++s4)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q)
+            w1q[(((size_t)mt * KT + s4) * 64 + lane) * 4 + q] = W1[(size_t)(16 * mt + (lane & 15)) * K + 16 * s4 + 4 * (lane >> 4) + q];
+    std::vector<uint16_t> w1h((size_t)KT * (CH_TILE_BYTES_HOST / 2) + 512, 0);
+    o->k1 = pack_f16_tiles(w1q.data(), B1, 0, KT, w1h.data());
+    o->W1h = upload(m, w1h, &rc);
+  }
   o->runs = upload(m, runs, &rc);
   // contiguous group ranges of near-equal tile count for S = 1, 2, 4, 8
   const int n_g = (int)groups.size();
@@ -510,7 +576,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
 }
 
 extern "C" int dbfr_model_set_gemm(dbfr_model* m, int32_t mode) {
-  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_SPLIT_BF16_L1) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
+  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_SPLIT_F16) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
   m->gemm_split = mode;
   return DBFR_OK;
 }
@@ -570,7 +636,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   for (int i = 0; i < n_tensors; ++i) tm[tensors[i].name] = &tensors[i];
   dbfr_model* m = new dbfr_model();
   m->cfg = *cfg;
-  m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
+  m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
   m->streams_ready = false;
   // which fused-conv kernel the K=144 convs use: k_conv2 (persistent, one launch per layer, tail split) wins while a layer
   // is only a few rounds of workgroups (predict.py-sized batches), k_conv (conv.hip) at bench-sized batches.
@@ -626,7 +692,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
     if (!rc) { *gs[i].off = upload(m, std::vector<float>(off, off + EMB), &rc); *gs[i].c = upload(m, std::vector<float>(c, c + 1), &rc); }
   }
   if (!rc) m->a14_group = upload(m, std::vector<int>(kAtom14ToGroup, kAtom14ToGroup + 21 * 14), &rc);
-  if (!rc) { m->flops_dev = upload(m, std::vector<double>(2, 0.0), &rc); }
+  if (!rc) { m->flops_dev = upload(m, std::vector<double>(3, 0.0), &rc); }
   if (!rc) { m->queue = upload(m, std::vector<int>(4, 0), &rc); }
   if (rc) { dbfr_model_destroy(m); return rc; }
   *out = m;
@@ -787,7 +853,7 @@ static void conv_call(dbfr_model* m, const ConvW& cw, const int* n_edges, int ma
     // algorithmic flops per edge: radial MLP 2K(K + W) + tensor-product contraction 2*(sum_paths mul1*mulo*dim_o)
     // second counter: HBM bytes the reference's two-kernel form moves per edge (the [E,W] weights once,
     // gathered irreps, harmonics, two int64 indices); the fused kernel never materialises them
-    launch_acc_flops(n_edges, 2.0 * cw.K * ((double)cw.K + cw.W), 4.0 * (cw.W + cw.D_in + 9) + 16.0, m->flops_dev, st);
+    launch_acc_flops(n_edges, 2.0 * cw.K * ((double)cw.K + cw.W), 4.0 * (cw.W + cw.D_in + 9) + 16.0, fused_bytes(cw.D_in, cw.D_out), m->flops_dev, st);
   }
 }
 
@@ -824,13 +890,14 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     });
   }
   if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, 8 * C2_TRACE_CAP * sizeof(unsigned long long), st); a.trace = trace_dev; }
-  if (m->gemm_split == DBFR_GEMM_SPLIT_BF16) launch_conv2r(a, st);
+  if (m->gemm_split == DBFR_GEMM_SPLIT_F16) launch_conv2h(a, st);
+  else if (m->gemm_split == DBFR_GEMM_SPLIT_BF16) launch_conv2r(a, st);
   else if (m->gemm_split) launch_conv2s(a, st);
   else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);
   if (m->profile)
     for (int i = 0; i < n; ++i)
-      launch_acc_flops(descs[i].n_edges, 2.0 * 144 * (144.0 + Ws[i]), 4.0 * (Ws[i] + descs[i].w.D_in + 9) + 16.0, m->flops_dev, st);
+      launch_acc_flops(descs[i].n_edges, 2.0 * 144 * (144.0 + Ws[i]), 4.0 * (Ws[i] + descs[i].w.D_in + 9) + 16.0, fused_bytes(descs[i].w.D_in, descs[i].w.D_out), m->flops_dev, st);
 }
 
 static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, const dbfr_scores* out, Ws& w,
@@ -911,7 +978,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       if (m->profile == 1) (void)hipEventRecord(e1, st);
       if (m->profile)
         for (int i = 0; i < 4; ++i)
-          launch_acc_flops(c4[i].n_edges, 2.0 * 144 * (144.0 + m->layer[l][i].W), 4.0 * (m->layer[l][i].W + Di + 9) + 16.0, m->flops_dev, st);
+          launch_acc_flops(c4[i].n_edges, 2.0 * 144 * (144.0 + m->layer[l][i].W), 4.0 * (m->layer[l][i].W + Di + 9) + 16.0, fused_bytes(Di, Do), m->flops_dev, st);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
       for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
@@ -1223,13 +1290,20 @@ extern "C" int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_l
     if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) { m->conv_ms_acc += ms; m->conv_launches_acc++; }
   }
   m->ev_used = 0;
-  double fl[2] = {0, 0};
+  double fl[3] = {0, 0, 0};
   HIPCHECK(hipMemcpy(fl, m->flops_dev, sizeof fl, hipMemcpyDeviceToHost));
+  m->fused_bytes_last = fl[2];
   if (conv_ms) *conv_ms = m->conv_ms_acc;
   if (conv_launches) *conv_launches = m->conv_launches_acc;
   if (conv_flops) *conv_flops = fl[0];
   if (ref_form_bytes) *ref_form_bytes = fl[1];
-  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, 2 * sizeof(double))); }
+  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, 3 * sizeof(double))); }
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_profile_fused_bytes(const dbfr_model* m, double* fused_form_bytes) {
+  if (!m || !fused_form_bytes) return fail(DBFR_ERR_ARG, "null argument");
+  *fused_form_bytes = m->fused_bytes_last;
   return DBFR_OK;
 }
 

@@ -55,6 +55,7 @@ struct LNDesc {            // equivariant LayerNorm over the out irreps (tpscore
 struct RunDesc {
   uint32_t tile0_n;   // first tile | n_tiles << 20
   uint32_t meta;      // type | flags << 4 (bit0: first run of its channel group, bit1: last) | sh_off << 8 | x_step << 12
+                      // | (k_conv2 layouts) x phase << 20 | (k_conv2h) int8 k << 24: the run's W2h / b2h rows carry the factor 2^k
   uint32_t x_off4;    // byte g: x_off (floats) of lane group g at the run's first tile
   uint32_t o_off4;    // byte g: message column owned by lane group g
 };
@@ -81,6 +82,9 @@ struct ConvW2 {
   const float* W2q;   // [n_tiles][K/16][64][4]
   const float* b2q;   // [n_tiles*16]
   const void* W2s;    // [n_tiles] x 13824 B: W2q cut into three bf16 pieces for k_conv2s (conv2s.hip; layout: api.cpp pack_conv2)
+  const void* W1h;    // [9] x 9280 B: lin.0 (W1p's tiles, bias rows) in the W2h tile format with the one factor 2^k1, for k_conv2h's hidden layer
+  int k1;
+  const void* W2h;    // [n_tiles] x 9280 B: W2q x 2^k(run) cut into two fp16 pieces + the tile's 16 bias values x 2^k, for k_conv2h (conv2h.hip; k in RunDesc.meta bits 24..31)
   const RunDesc* runs;    // meta bit 20: run reads the second x layout; x offsets already mapped to the LDS row
   int part_run[4][9];     // part_run[si][p] = first run of part p when the conv is cut into 1 << si parts
 };

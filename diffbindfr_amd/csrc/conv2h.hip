@@ -1,0 +1,643 @@
+// Fused tensor-product convolution, split-fp16 GEMM: the radial MLP's 144 x W GEMM on v_mfma_f32_16x16x32_f16 with every fp32
+// operand cut into TWO fp16 pieces -- half the matrix instructions of k_conv2r (conv2r.hip: three bf16 pieces, six products).
+//
+// Arithmetic.  x = hi + lo + d with hi = fp16(x), lo = fp16(x - hi), both rounded to nearest even: 2 x 11 significand bits plus
+// the sign of lo leave |d| <= 2^-23 |x|.  A product w h is evaluated as hi_w lo_h + lo_w hi_h + hi_w hi_h (the dropped lo_w lo_h
+// is below 2^-22 |w h|), each term exact in the fp32 accumulator.  fp16 has five exponent bits, so both operands are first
+// multiplied by exact powers of two that put their largest magnitude into [2^14, 2^15):
+//   * W2: per RUN (the tiles of one tensor-product path of one channel group), at model creation (api.cpp pack_conv2); the
+//     bias rows carry the same factor 2^k, and 2^-k is folded into the run's harmonics (l = 2 matrix), i.e. it costs nothing
+//     per tile;
+//   * h = relu(W1 a + b1): per EDGE, in the kernel (largest of the edge's 144 activations); the bias is multiplied by the
+//     edge's factor where k_conv2r copied it into the accumulator, and the inverse goes into the message store.
+// The two small products of all five k-steps and the five large ones run in SEPARATE accumulators (small ones start from the
+// bias, large ones from 0) that are added once per tile -- where k_conv2r moved its accumulator into the previous-tile
+// registers: the large chain is rounded 5 times instead of 15, which is what puts the error below the fp32 instruction's
+// (tools/exp/split_f16.hip, profiles/r3_split_experiments.txt).
+//
+// Structure: k_conv2r's (persistent edge-owner waves, unit queue, tail split, wave-private x rows / harmonics, channel-owner
+// accumulation, previous tile's contraction hand-interleaved into the MFMA issue gaps), with a leaner LDS ring because a
+// tile is now 9 KiB of pieces and half as many MFMAs long:
+//   * TWO barriers per tile instead of three, the minimum for a one-tile ring (every slot is written once and read once per
+//     tile, and both orders need a barrier between them).  Slots of k-steps 0..2 ("A") are read during k-steps 4, 0, 1 and
+//     written during k-step 2; slots of k-step 3 and of the last 16 k ("B") are read during k-steps 2, 3 and written during
+//     k-step 0; barriers open k-steps 2 and 4;
+//   * a wave moves ONE 1-KiB share of A (16 bytes per lane) and ONE 512-byte share of B per tile -- 2 loads + 2 LDS writes per
+//     tile instead of 6 + 6.  A has seven shares: the six 1-KiB pieces and the tile's 16 bias values (64 bytes; the other
+//     lanes of that share are out of the buffer's range, get zeros and write them into padding); waves 6, 7 both move the bias
+//     share, and waves 6, 7 duplicate B shares 0, 1: same bytes to the same place, no branch;
+//   * a share is fetched TWO TILES before it is written.  The W2 pieces of a layer (4 convs x 4.4 MB) do not fit the 4-MiB L2
+//     of an XCD, most fetches come from the MALL, and with the distance a single staging register set allows (< 1 tile) the
+//     waves spent 17 % of their time waiting in front of the LDS writes (ablations in profiles/r3_split_experiments.txt).  Two
+//     tiles need two staging sets selected by tile parity, i.e. two copies of the tile code behind a uniform branch -- where
+//     hipcc's wait-count pass merges the two histories and waits for vmcnt(0).  So the staging registers are v[244:255], outside
+//     the compiler's allocation (amdgpu_num_vgpr(244)), loads and LDS writes are inline assembly, and the wait is written by
+//     hand: in steady state exactly three ring loads are younger than the one a write needs (`put` below).
+// The x32 -> x16 accumulator hazard of conv2r.hip does not arise: with two accumulator pairs every x16 MFMA's SrcC was written
+// at least four MFMAs earlier.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define CH_TILE_BYTES 9280          // [2 pieces][4 k-steps of 32][64 lanes][8 fp16] + [2 pieces][64 lanes][4 fp16] (the last 16 k) + 16 bias values
+#define CH_TAIL_OFF 8192
+#define CH_BIAS_OFF 9216
+#define CH_RING_BYTES 10240         // one tile; the bias share is 1 KiB wide in LDS (64 bytes of bias + the zeros of its idle lanes)
+
+// two fp32 values -> hi and lo words of packed fp16 pairs (low half = x0's piece), round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split2x2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f16x2 h = __builtin_convertvector((f32x2){x0, x1}, f16x2);
+  const f16x2 l = __builtin_convertvector((f32x2){x0 - (float)h[0], x1 - (float)h[1]}, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// element by element on purpose: as vector operations hipcc emits v_pk_mul_f32 / v_pk_add_f32, which cost more next to MFMAs than
+// the two plain instructions they replace (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+__device__ __forceinline__ void scale4(f32x4& o, const f32x4& v, float s) { o[0] = v[0] * s; o[1] = v[1] * s; o[2] = v[2] * s; o[3] = v[3] * s; }
+__device__ __forceinline__ void sum4(f32x4& o, const f32x4& a, const f32x4& b) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; o[3] = a[3] + b[3]; }
+
+// ---- ring staging (header comment): set P of the staging registers = A in v[244:247] / v[248:251], B in v[252:253] / v[254:255],
+// outside the compiler's allocation; loads, waits and LDS writes by hand
+template <int P> __device__ __forceinline__ void ch_fetchA(int voff, u32x4 rsrc, int soff) {
+  if (P == 0) asm volatile("buffer_load_dwordx4 v[244:247], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v244", "v245", "v246", "v247");
+  else asm volatile("buffer_load_dwordx4 v[248:251], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v248", "v249", "v250", "v251");
+}
+template <int P> __device__ __forceinline__ void ch_fetchB(int voff, u32x4 rsrc, int soff) {
+  if (P == 0) asm volatile("buffer_load_dwordx2 v[252:253], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v252", "v253");
+  else asm volatile("buffer_load_dwordx2 v[254:255], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v254", "v255");
+}
+// `put`: the share fetched two tiles ago goes into the ring.  Ring loads are issued in the fixed order B(P) A(P) B(!P) A(!P) B(P) ...
+// (slots 1 and 13 of every tile), they return in order, and a write comes just before the fetch that re-arms its set: exactly
+// three younger ring loads may still be out (VMCNT = 3).  Anything else in the queue -- message stores at the end of a channel
+// group, the x rows of the second output half -- is younger still and only makes the wait longer; the unit's prologue ends with
+// vmcnt(0) (VMCNT = 0: no wait here).
+template <int P, int VMCNT> __device__ __forceinline__ void ch_putA(unsigned lds_addr) {
+  if (VMCNT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if (P == 0) asm volatile("ds_write_b128 %0, v[244:247]" ::"v"(lds_addr) : "memory", "v244", "v245", "v246", "v247");
+  else asm volatile("ds_write_b128 %0, v[248:251]" ::"v"(lds_addr) : "memory", "v248", "v249", "v250", "v251");
+}
+template <int P> __device__ __forceinline__ void ch_putB(unsigned lds_addr) {
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if (P == 0) asm volatile("ds_write_b64 %0, v[252:253]" ::"v"(lds_addr) : "memory", "v252", "v253");
+  else asm volatile("ds_write_b64 %0, v[254:255]" ::"v"(lds_addr) : "memory", "v254", "v255");
+}
+
+#define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
+#define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
+
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling (8: loads only, 16: LDS writes only), 64 unit prologue only
+__global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) void k_conv2h(Conv2Args a) {
+  constexpr int K = 144, KT = 9;
+  constexpr int EPB = 32 * NW;                       // edges per block (unit)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_unit[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const char* ring = reinterpret_cast<const char*>(lds);          // [CH_RING_BYTES] first: inside the 16-bit offset of ds_read
+  float* xs = lds + CH_RING_BYTES / 4 + wave * C2_WAVE_FLOATS;    // [32][C2_XLD]
+  float* shs = xs + 32 * C2_XLD;                     // [32][10]
+  float* ms = shs + 32 * 10;                         // [32][8]
+  int* s_gth = reinterpret_cast<int*>(ms + 32 * 8);  // [32]
+
+  // developer (DBFR_CONV2_TRACE=<file>): shader clock / 100-MHz wall clock at the start and the end of workgroup 0 -> effective clock
+  if (a.trace && blockIdx.x == 0 && tid == 0) { a.trace[0] = __builtin_readcyclecounter(); a.trace[1] = __builtin_amdgcn_s_memrealtime(); }
+  // ---- the launch's unit list (every workgroup derives it from the device-side edge counts)
+  int nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0;
+  {
+    auto blocks = [&](int c) { return c < a.n_conv ? (min(*a.c[c].n_edges, a.c[c].max_edges) + EPB - 1) / EPB : 0; };
+    nb0 = blocks(0); nb1 = blocks(1); nb2 = blocks(2); nb3 = blocks(3);
+  }
+  const int N = nb0 + nb1 + nb2 + nb3;
+  const int n_wg = gridDim.x;
+  const int full = (N / n_wg) * n_wg, rem = N - full;
+  int si = 0;
+  if (rem > 0 && !a.no_split) { const int q = n_wg / rem; si = q >= 8 ? 3 : q >= 4 ? 2 : q >= 2 ? 1 : 0; }
+  const int total = full + (rem << si);
+
+  for (int it = 0;; ++it) {
+    if (tid == 0) s_unit[it & 1] = atomicAdd(a.queue, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing of the last unit still reads or arms the ring
+    __syncthreads();
+    const int u = s_unit[it & 1];
+    if (u >= total) break;
+    int blk, part = 0, psi = 0;
+    if (u < full) blk = u;
+    else { const int v = u - full; blk = full + (v >> si); part = v & ((1 << si) - 1); psi = si; }
+    int c = 0;
+    if (blk >= nb0) { blk -= nb0; c = 1; if (blk >= nb1) { blk -= nb1; c = 2; if (blk >= nb2) { blk -= nb2; c = 3; } } }
+    const Conv2Desc& d = a.c[c];
+    const int E = min(*d.n_edges, d.max_edges);
+    const int e0 = blk * EPB + 32 * wave;
+    // (a wave without edges in this block runs along on clamped edges and stores nothing: the ring barriers need all eight)
+    const int D_in = d.w.D_in, D_out = d.w.D_out;
+    const int vW = lane * 16, vB = g * 16;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int r_begin = d.w.part_run[psi][part], r_end = d.w.part_run[psi][part + 1];
+    int t_last = 0, t_first = 0;
+    if (r_begin < r_end) {
+      const RunDesc rl = d.w.runs[r_end - 1];
+      t_last = (rl.tile0_n & 0xfffff) + (rl.tile0_n >> 20) - 1;
+      t_first = d.w.runs[r_begin].tile0_n & 0xfffff;
+    }
+    // Filling the ring (header comment).  Share A = one of the six 1-KiB pieces (piece i, k-step s < 3) or the bias values; share B =
+    // one of the six 512-byte halves of k-step 3's two pieces and of the two last-16-k pieces.  Same layout in memory and in LDS.
+    const unsigned long long w2h = (unsigned long long)d.w.W2h;
+    const u32x4 rW = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w2h), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(w2h >> 32) & 0xffffu)),
+                      (unsigned)__builtin_amdgcn_readfirstlane(d.w.n_tiles * CH_TILE_BYTES), 0x00020000u};
+    const int shA = wv & 7, shB = wv % 6;
+    const int offA = shA < 6 ? ((shA / 3) * 4 + shA % 3) * 1024 : CH_BIAS_OFF;
+    const int offB = shB < 4 ? ((shB >> 1) * 4 + 3) * 1024 + (shB & 1) * 512 : CH_TAIL_OFF + (shB - 4) * 512;
+    const int vA = (shA < 6 || lane < 4) ? lane * 16 : 0x40000000;      // lanes 4..63 of the bias share: out of range, the load returns 0
+    const unsigned ring_lds = (unsigned)(size_t)ring;                 // LDS byte address of the ring (low half of the flat address)
+    const unsigned ldsA = ring_lds + offA + lane * 16, ldsB = ring_lds + offB + lane * 8;
+    // (plain functions, not lambdas: clang does not capture a variable that a generic lambda uses only as an asm operand)
+    auto fetchA = [&](auto pc, int tile) { if (!(ABL & (4 | 16))) ch_fetchA<decltype(pc)::value>(vA, rW, tile * CH_TILE_BYTES + offA); };
+    auto fetchB = [&](auto pc, int tile) { if (!(ABL & (4 | 16))) ch_fetchB<decltype(pc)::value>(lane * 8, rW, tile * CH_TILE_BYTES + offB); };
+    auto putA = [&](auto pc) { if (!(ABL & (4 | 8))) ch_putA<decltype(pc)::value, 3>(ldsA); };
+    auto putB = [&](auto pc) { if (!(ABL & (4 | 8))) ch_putB<decltype(pc)::value>(ldsB); };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    if (r_begin < r_end) {   // the part's first tiles travel while the hidden layer is computed: tile 0's A shares (through set 1), its B
+      fetchA(I1{}, t_first); fetchB(I0{}, t_first);                                    // shares, tile 1's A and B shares
+      fetchA(I0{}, min(t_first + 1, t_last)); fetchB(I1{}, min(t_first + 1, t_last));
+    }
+
+    // ---- my two edges (block b, column n), clamped; gather indices
+    int ev[2], gthv[2];
+    const float* r0[2]; const float* r1[2]; const float* r2[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int e = e0 + 16 * b + n;
+      ev[b] = min(e, E - 1);
+      gthv[b] = d.gth[ev[b]];
+      r0[b] = d.emb + (size_t)ev[b] * NS;
+      r1[b] = d.tab1 + (size_t)d.idx1[ev[b]] * d.ld1;
+      r2[b] = d.tab2 + (size_t)d.idx2[ev[b]] * d.ld2;
+    }
+    if (g == 0) { s_gth[n] = gthv[0]; s_gth[16 + n] = gthv[1]; }
+    if (lane < 32) {   // harmonics of the wave's 32 edges + the closed form of the 1 x 2 -> 1 coupling (so3_host.cpp)
+      const int e = min(e0 + lane, E - 1);
+      const float* sp = d.sh + (size_t)e * SH_LD;
+      float s[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { s[k] = sp[k]; shs[lane * 10 + k] = s[k]; }
+      const float r3 = 1.7320508075688772f;
+      float* m = ms + lane * 8;
+      m[0] = -s[6] - r3 * s[8]; m[1] = r3 * s[5]; m[2] = r3 * s[4]; m[3] = 2.f * s[6]; m[4] = r3 * s[7]; m[5] = -s[6] + r3 * s[8];
+    }
+    // ---- hidden layer h = relu(W1 a + b1) on the fp16 matrix instruction too (same two-piece / three-product / two-accumulator
+    // form as the W2 tiles below; on v_mfma_f32_16x16x4_f32 its 648 MFMAs of 32 cycles were 7 % of the kernel at W = 7776 and 17 %
+    // at W = 2880).  The radial-MLP input row a = [emb | tab1 | tab2] of the lane's edge goes straight into B-operand registers
+    // (k-step q of lane group g of 16-group s4 takes k = 16 s4 + 4 g + q, api.cpp pack_conv): scaled per edge by the power of
+    // two that puts max |a| into [2^14, 2^15) and cut into fp16 pieces.  W1 comes as nine 16-row tiles in the W2h tile format
+    // (api.cpp: W1h, ONE factor 2^k1 for the matrix, bias rows x 2^k1), fetched per wave through L1 (83 KB, L2 resident), both
+    // edge blocks per fragment.  D[row = hidden unit, col = edge] -> lane (g, n) ends up with H' = relu(acc) = h 2^(k1 + ja) for
+    // hidden units 16 m + 4 g + r, r = 0..3; no need to take the factor off: the edge's 144 values (36 in each of the four lanes
+    // n, n + 16, n + 32, n + 48) are scaled once more so that their maximum lies in [2^14, 2^15), cut into fp16 pieces and filed
+    // as slots 4 (m & 1) + r of k-step m >> 1 of the W2 tiles' B operand; se / ue carry the total factor and its inverse.
+    u32x4 Bh[2][2][4];                                 // h pieces: [edge block][hi, lo][k-step of 32] = 8 fp16 each, 64 VGPRs
+    u32x2 Bt[2][2];                                    // ... and of the last 16 k (v_mfma_f32_16x16x16_f16): 4 fp16 each, 8 VGPRs
+    float se[2], ue[2];                                // the edge's factor 2^j on h and its inverse
+    {
+      const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.W1h, 0, KT * CH_TILE_BYTES, 0x00020000);
+      u32x4 Ah[2][2][4];                               // a pieces, same filing as Bh
+      u32x2 At[2][2];
+      float sa[2];
+      int ja[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f32x4 Ba[KT];
+        float amx = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < KT; ++s4) {
+          const float* src = s4 < 3 ? r0[b] : s4 < 6 ? r1[b] : r2[b];
+          Ba[s4] = *reinterpret_cast<const f32x4*>(src + 16 * (s4 % 3) + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) amx = fmaxf(amx, fabsf(Ba[s4][q]));
+        }
+        amx = fmaxf(amx, __shfl_xor(amx, 16));
+        amx = fmaxf(amx, __shfl_xor(amx, 32));
+        ja[b] = max(-14, min(40, __builtin_amdgcn_frexp_expf(amx)));   // (inputs below 2^-14 are not blown up further: the bias is of order 1)
+        sa[b] = __builtin_amdgcn_ldexpf(1.f, 15 - ja[b]);
+#pragma unroll
+        for (int s4 = 0; s4 < KT; ++s4) {
+          unsigned hi0, lo0, hi1, lo1;
+          split2x2(Ba[s4][0] * sa[b], Ba[s4][1] * sa[b], hi0, lo0);
+          split2x2(Ba[s4][2] * sa[b], Ba[s4][3] * sa[b], hi1, lo1);
+          if (s4 < 8) {
+            Ah[b][0][s4 >> 1][2 * (s4 & 1)] = hi0; Ah[b][0][s4 >> 1][2 * (s4 & 1) + 1] = hi1;
+            Ah[b][1][s4 >> 1][2 * (s4 & 1)] = lo0; Ah[b][1][s4 >> 1][2 * (s4 & 1) + 1] = lo1;
+          } else {
+            At[b][0][0] = hi0; At[b][0][1] = hi1;
+            At[b][1][0] = lo0; At[b][1][1] = lo1;
+          }
+        }
+      }
+      // 9 row tiles x (4 k-steps of 32 + the last 16 k); fragments of k-step i + 2 requested behind the MFMAs of k-step i
+      constexpr int NST = KT * 4;                      // x32 steps, numbered m * 4 + s
+      u32x4 F[3][2];                                   // ring of three k-steps of (hi, lo) fragments
+      u32x2 Ft[2];                                     // the current tile's last-16-k fragments
+      f32x4 bb;                                        // ... and its bias values x 2^k1
+      auto ld_step = [&](int i, u32x4 (&f)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) f[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, (i >> 2) * CH_TILE_BYTES + (p * 4 + (i & 3)) * 1024, 0));
+      };
+      auto ld_tail = [&](int m) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) Ft[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rW1, lane * 8, m * CH_TILE_BYTES + CH_TAIL_OFF + p * 512, 0));
+        bb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vB, m * CH_TILE_BYTES + CH_BIAS_OFF, 0));
+      };
+      ld_step(0, F[0]); ld_step(1, F[1]); ld_tail(0);
+      float H[2][KT][4];
+      float mx[2] = {0.f, 0.f};
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#define AHB(b, p, s) __builtin_bit_cast(f16x8, Ah[b][p][s])
+#define FW(i, p) __builtin_bit_cast(f16x8, F[(i) % 3][p])
+#pragma unroll
+      for (int m = 0; m < KT; ++m) {
+        f32x4 aS[2], aB[2];
+        scale4(aS[0], bb, sa[0]); scale4(aS[1], bb, sa[1]);
+        aB[0] = zero; aB[1] = zero;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int i = m * 4 + s;
+          aS[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW(i, 0), AHB(0, 1, s), aS[0], 0, 0, 0);
+          aS[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW(i, 0), AHB(1, 1, s), aS[1], 0, 0, 0);
+          aS[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW(i, 1), AHB(0, 0, s), aS[0], 0, 0, 0);
+          aS[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW(i, 1), AHB(1, 0, s), aS[1], 0, 0, 0);
+          aB[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW(i, 0), AHB(0, 0, s), aB[0], 0, 0, 0);
+          aB[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW(i, 0), AHB(1, 0, s), aB[1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 2 < NST) ld_step(i + 2, F[(i + 2) % 3]);
+        }
+        {   // k = 128..143 (every accumulator was last written four MFMAs ago: no x32 -> x16 hazard, conv2r.hip)
+          const f16x4 fh = __builtin_bit_cast(f16x4, Ft[0]), fl = __builtin_bit_cast(f16x4, Ft[1]);
+          aS[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[0][1]), aS[0], 0, 0, 0);
+          aS[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[1][1]), aS[1], 0, 0, 0);
+          aS[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(fl, __builtin_bit_cast(f16x4, At[0][0]), aS[0], 0, 0, 0);
+          aS[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(fl, __builtin_bit_cast(f16x4, At[1][0]), aS[1], 0, 0, 0);
+          aB[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[0][0]), aB[0], 0, 0, 0);
+          aB[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[1][0]), aB[1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (m + 1 < KT) ld_tail(m + 1);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { H[b][m][r] = fmaxf(aS[b][r] + aB[b][r], 0.f); mx[b] = fmaxf(mx[b], H[b][m][r]); }
+      }
+#undef AHB
+#undef FW
+      const int k1 = d.w.k1;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float m2 = fmaxf(mx[b], __shfl_xor(mx[b], 16));
+        m2 = fmaxf(m2, __shfl_xor(m2, 32));
+        // H' = f 2^j, f in [0.5, 1)  ->  factor 2^(15 - j) on H' = 2^(15 - j + k1 + 15 - ja) on h; everything clamped so that the
+        // factors and their inverses stay normal fp32 numbers (an edge whose activations are all tiny keeps them as fp16
+        // subnormals or zeros: nothing to lose)
+        const int j = max(-100, min(100, __builtin_amdgcn_frexp_expf(m2)));
+        const float t = __builtin_amdgcn_ldexpf(1.f, 15 - j);
+        const int tot = max(-120, min(120, 15 - j + k1 + 15 - ja[b]));
+        se[b] = __builtin_amdgcn_ldexpf(1.f, tot);
+        ue[b] = __builtin_amdgcn_ldexpf(1.f, -tot);
+#pragma unroll
+        for (int m = 0; m < KT; ++m) {
+          unsigned hi0, lo0, hi1, lo1;
+          split2x2(H[b][m][0] * t, H[b][m][1] * t, hi0, lo0);
+          split2x2(H[b][m][2] * t, H[b][m][3] * t, hi1, lo1);
+          if (m < 8) {
+            Bh[b][0][m >> 1][2 * (m & 1)] = hi0; Bh[b][0][m >> 1][2 * (m & 1) + 1] = hi1;
+            Bh[b][1][m >> 1][2 * (m & 1)] = lo0; Bh[b][1][m >> 1][2 * (m & 1) + 1] = lo1;
+          } else {
+            Bt[b][0][0] = hi0; Bt[b][0][1] = hi1;
+            Bt[b][1][0] = lo0; Bt[b][1][1] = lo1;
+          }
+        }
+      }
+    }
+    // ---- x[gth] rows of the wave's 32 edges into its LDS region (columns [0, min(D_in, 120)))
+    __builtin_amdgcn_wave_barrier();
+    {   // lane L moves the 16-byte chunks (L >> 5), (L >> 5) + 2, ... of row L & 31: all loads out before the first store, no
+        // index arithmetic.  Chunks past the row's end repeat its last one: same bytes to the same place.
+      const int d4 = min(D_in, 120) >> 2;
+      const float* xsrc = d.x + (size_t)s_gth[lane & 31] * d.ldx;
+      float* xdst = xs + (lane & 31) * C2_XLD;
+      f32x4 v[15];
+#pragma unroll
+      for (int j = 0; j < 15; ++j) v[j] = *reinterpret_cast<const f32x4*>(xsrc + 4 * min(2 * j + (lane >> 5), d4 - 1));
+#pragma unroll
+      for (int j = 0; j < 15; ++j) *reinterpret_cast<f32x4*>(xdst + 4 * min(2 * j + (lane >> 5), d4 - 1)) = v[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    if (ABL & 64) {   // developer: the unit prologue alone
+      asm volatile("" ::"v"(Bh[0][0][0]), "v"(Bh[1][1][3]), "v"(Bt[1][1]));
+      continue;
+    }
+    // ---- the W2 row tiles of this part, run by run (channel-owner order, api.cpp pack_conv2)
+    float oacc[2][3];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
+    const float* xs_lane = xs + n * C2_XLD;          // + 16 b C2_XLD per edge block
+    const float* sh_lane = shs + n * 10;
+    f16x8 FA[2], FB[2];                                // W2 pieces (hi, lo) of two k-steps: 16 VGPRs
+    f16x4 FT[2];                                       // ... and of the last 16 k: 4
+    f32x4 bias_n;                                      // the NEXT tile's four bias values of this lane's rows (x 2^k of its run)
+    f32x4 accN[2];                                     // bias x the edge's factor: where the next tile's small-product chain starts
+    f32x4 accS[2], accB[2];                            // this tile's accumulators: small products (+ bias) | large products
+    f32x4 accp[2];                                     // the previous tile's result (accS + accB), being contracted
+    auto rd_step = [&](auto jc, f16x8 (&F)[2]) {
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) F[i] = *reinterpret_cast<const f16x8*>(ring + (i * 4 + j) * 1024 + vW);
+    };
+    auto ring_barrier = [&] {   // "my LDS reads and writes are done" + s_barrier
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#define HB(b, p, s) __builtin_bit_cast(f16x8, Bh[b][p][s])
+#define TB(b, p) __builtin_bit_cast(f16x4, Bt[b][p])
+#define M32(C, wp, b, hp, F, s) __builtin_amdgcn_mfma_f32_16x16x32_f16(F[wp], HB(b, hp, s), C, 0, 0, 0)
+#define M16(C, wp, b, hp) __builtin_amdgcn_mfma_f32_16x16x16f16(FT[wp], TB(b, hp), C, 0, 0, 0)
+#define SLOT(m) do { op(std::integral_constant<int, (m)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // one tile: 30 MFMAs = 5 k-steps x (hi_w lo_h, lo_w hi_h | hi_w hi_h) x 2 edge blocks; `op(m)` = what travels behind MFMA m.
+    // e0 / e1 / e2: the k-step's memory operations, behind its MFMAs 0 / 1 / 2
+    // Tile t of the part (parity P = (t - t_first) & 1) writes the shares staged in set P -- its own B shares, the next tile's A shares --
+    // and re-arms the set with those of two tiles on.
+    auto tile = [&](auto pc, int t, auto&& op) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      // k-step 0 (fragments FA): B shares of THIS tile into the ring, next tile's bias on its way, k-step 1's fragments requested
+      accS[0] = M32(accN[0], 0, 0, 1, FA, 0); putB(pc); SLOT(0);
+      accS[1] = M32(accN[1], 0, 1, 1, FA, 0); fetchB(pc, min(t + 2, t_last)); SLOT(1);
+      accS[0] = M32(accS[0], 1, 0, 0, FA, 0); rd_step(I1{}, FB); SLOT(2);
+      accS[1] = M32(accS[1], 1, 1, 0, FA, 0); SLOT(3);
+      accB[0] = M32(zero, 0, 0, 0, FA, 0); SLOT(4);
+      accB[1] = M32(zero, 0, 1, 0, FA, 0); SLOT(5);
+      // k-step 1 (FB): the next tile's B shares set out
+      accS[0] = M32(accS[0], 0, 0, 1, FB, 1); SLOT(6);
+      accS[1] = M32(accS[1], 0, 1, 1, FB, 1); SLOT(7);
+      accS[0] = M32(accS[0], 1, 0, 0, FB, 1); rd_step(I2{}, FA); SLOT(8);
+      accS[1] = M32(accS[1], 1, 1, 0, FB, 1); SLOT(9);
+      accB[0] = M32(accB[0], 0, 0, 0, FB, 1); SLOT(10);
+      accB[1] = M32(accB[1], 0, 1, 0, FB, 1); SLOT(11);
+      // k-step 2 (FA): everybody has read slots 0..2 -> the next tile's A shares go in
+      ring_barrier();
+      accS[0] = M32(accS[0], 0, 0, 1, FA, 2); putA(pc); SLOT(12);
+      accS[1] = M32(accS[1], 0, 1, 1, FA, 2); fetchA(pc, min(t + 3, t_last)); SLOT(13);
+      accS[0] = M32(accS[0], 1, 0, 0, FA, 2); rd_step(I3{}, FB); SLOT(14);
+      accS[1] = M32(accS[1], 1, 1, 0, FA, 2); SLOT(15);
+      accB[0] = M32(accB[0], 0, 0, 0, FA, 2); SLOT(16);
+      accB[1] = M32(accB[1], 0, 1, 0, FA, 2); SLOT(17);
+      // k-step 3 (FB): the A shares of the tile after next set out
+      accS[0] = M32(accS[0], 0, 0, 1, FB, 3); SLOT(18);
+      accS[1] = M32(accS[1], 0, 1, 1, FB, 3); SLOT(19);
+      accS[0] = M32(accS[0], 1, 0, 0, FB, 3);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) FT[i] = *reinterpret_cast<const f16x4*>(ring + CH_TAIL_OFF + i * 512 + lane * 8);
+      SLOT(20);
+      accS[1] = M32(accS[1], 1, 1, 0, FB, 3); SLOT(21);
+      accB[0] = M32(accB[0], 0, 0, 0, FB, 3); SLOT(22);
+      accB[1] = M32(accB[1], 0, 1, 0, FB, 3); SLOT(23);
+      // k = 128..143 on v_mfma_f32_16x16x16_f16; the next tile's slots 0..2 are complete: its first k-step's fragments.
+      // Block 0 finishes two MFMAs before the tile does, so its sum (slot 29) does not wait for the pipe.
+      ring_barrier();
+      accS[0] = M16(accS[0], 0, 0, 1); bias_n = *reinterpret_cast<const f32x4*>(ring + CH_BIAS_OFF + vB); SLOT(24);
+      accS[1] = M16(accS[1], 0, 1, 1); SLOT(25);
+      accS[0] = M16(accS[0], 1, 0, 0); rd_step(I0{}, FA); SLOT(26);
+      accB[0] = M16(accB[0], 0, 0, 0); SLOT(27);
+      accS[1] = M16(accS[1], 1, 1, 0); SLOT(28);
+      accB[1] = M16(accB[1], 0, 1, 0); SLOT(29);
+      sum4(accp[1], accS[1], accB[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#undef SLOT
+    int x_phase = 0;
+    int par = 0;                                       // parity of the next tile
+    if (r_begin < r_end) {                             // the part's first tile: A shares (+ bias) into the ring, its B shares wait in set 0
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // for the first k-step 0; the third tile's A shares set out
+      if (!(ABL & (4 | 8))) ch_putA<1, 0>(ldsA);
+      fetchA(I1{}, min(t_first + 2, t_last));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      rd_step(I0{}, FA);
+      bias_n = *reinterpret_cast<const f32x4*>(ring + CH_BIAS_OFF + vB);
+      scale4(accN[0], bias_n, se[0]); scale4(accN[1], bias_n, se[1]);
+    }
+    for (int r = r_begin; r < r_end; ++r) {
+      const RunDesc rd = d.w.runs[r];
+      const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
+      const int type = rd.meta & 15, flags = (rd.meta >> 4) & 3, sh_off = (rd.meta >> 8) & 15, x_step = (rd.meta >> 12) & 0xff;
+      const int xph = (rd.meta >> 20) & 1;
+      const float run_inv = __builtin_amdgcn_ldexpf(1.f, -((int)rd.meta >> 24));   // the run's W2h / b2h rows carry 2^k
+      const int xo = (rd.x_off4 >> (8 * g)) & 0xff, oo = (rd.o_off4 >> (8 * g)) & 0xff;
+      if (xph != x_phase) {   // second output half: the scalar slot [0,48) now holds the 48x0o inputs x[120:168]
+        __builtin_amdgcn_wave_barrier();
+        {
+          const float* xsrc = d.x + (size_t)s_gth[lane & 31] * d.ldx + 120;
+          float* xdst = xs + (lane & 31) * C2_XLD;
+          f32x4 v[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) v[j] = *reinterpret_cast<const f32x4*>(xsrc + 4 * (2 * j + (lane >> 5)));
+#pragma unroll
+          for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(xdst + 4 * (2 * j + (lane >> 5))) = v[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        x_phase = xph;
+      }
+      if (flags & 1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) oacc[b][0] = oacc[b][1] = oacc[b][2] = 0.f;
+      }
+      auto run = [&](auto type_c) {
+        constexpr int TYPE = decltype(type_c)::value;
+        constexpr bool VIN = !(TYPE == PT_SS || TYPE == PT_SV);
+        constexpr bool VOUT = !(TYPE == PT_SS || TYPE == PT_VVS);
+        constexpr int NSV = (TYPE == PT_SS || TYPE == PT_VS) ? 1 : (TYPE == PT_VTV ? 0 : 3);
+        // the run's harmonics (PT_VTV: the symmetric traceless matrix of the l = 2 ones) x 2^-k, once per run
+        float S[2][NSV ? NSV : 1];
+        float Mv[2][TYPE == PT_VTV ? 6 : 1];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (TYPE != PT_VTV) {
+            const float* sp = sh_lane + 160 * b + sh_off;
+#pragma unroll
+            for (int k = 0; k < NSV; ++k) S[b][k] = sp[k] * run_inv;
+          } else {
+            const float* mp = ms + (16 * b + n) * 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Mv[b][k] = mp[k] * run_inv;
+          }
+        }
+        // the contraction of one edge block of the PREVIOUS tile (accp) as micro-operations: K = 0 the first LDS read, K >= 1
+        // one FMA each (K beyond the type's count: nothing).  State lives in cx* / cz* between the operations.
+        f32x4 cxa, cxb, cxc;
+        float cz0, cz1, cz2;
+        auto cop = [&](auto bc, auto kc, const float* xp) {
+          constexpr int b = decltype(bc)::value;
+          constexpr int K = decltype(kc)::value;
+          if (ABL & 1) { if (K == 1) asm volatile("" ::"v"(accp[b])); return; }
+          const f32x4 v = accp[b];
+          const f32x4* x4 = reinterpret_cast<const f32x4*>(xp + 16 * b * C2_XLD);   // [u0..u0+3][3] = 12 consecutive floats (VIN)
+          if (VIN && K == 2) cxb = x4[1];            // (each quad requested a few operations ahead of its first use)
+          if (VIN && K == 6) cxc = x4[2];
+          if (K == 0) cxa = x4[0];
+          if (!VIN) {
+            if (K == 1) cz0 = v[0] * cxa[0];
+            if (K == 2) cz0 += v[1] * cxa[1];
+            if (K == 3) cz0 += v[2] * cxa[2];
+            if (K == 4) cz0 += v[3] * cxa[3];
+            if (K == 5) oacc[b][0] += cz0 * S[b][0];
+            if (TYPE == PT_SV) {
+              if (K == 6) oacc[b][1] += cz0 * S[b][1];
+              if (K == 7) oacc[b][2] += cz0 * S[b][2];
+            }
+          } else {
+            if (K == 1) cz0 = v[0] * cxa[0];
+            if (K == 2) cz1 = v[0] * cxa[1];
+            if (K == 3) cz2 = v[0] * cxa[2];
+            if (K == 4) cz0 += v[1] * cxa[3];
+            if (K == 5) cz1 += v[1] * cxb[0];
+            if (K == 6) cz2 += v[1] * cxb[1];
+            if (K == 7) cz0 += v[2] * cxb[2];
+            if (K == 8) cz1 += v[2] * cxb[3];
+            if (K == 9) cz2 += v[2] * cxc[0];
+            if (K == 10) cz0 += v[3] * cxc[1];
+            if (K == 11) cz1 += v[3] * cxc[2];
+            if (K == 12) cz2 += v[3] * cxc[3];
+            if (TYPE == PT_VS) {
+              if (K == 13) oacc[b][0] += cz0 * S[b][0];
+              if (K == 14) oacc[b][1] += cz1 * S[b][0];
+              if (K == 15) oacc[b][2] += cz2 * S[b][0];
+            } else if (TYPE == PT_VVS) {
+              if (K == 13) oacc[b][0] += cz0 * S[b][0];
+              if (K == 14) oacc[b][0] += cz1 * S[b][1];
+              if (K == 15) oacc[b][0] += cz2 * S[b][2];
+            } else if (TYPE == PT_VVV) {
+              if (K == 13) oacc[b][0] += cz1 * S[b][2];
+              if (K == 14) oacc[b][1] += cz2 * S[b][0];
+              if (K == 15) oacc[b][2] += cz0 * S[b][1];
+              if (K == 16) oacc[b][0] -= cz2 * S[b][1];
+              if (K == 17) oacc[b][1] -= cz0 * S[b][2];
+              if (K == 18) oacc[b][2] -= cz1 * S[b][0];
+            } else {   // PT_VTV: rows (m0 m1 m2 | m1 m3 m4 | m2 m4 m5)
+              if (K == 13) oacc[b][0] += Mv[b][0] * cz0;
+              if (K == 14) oacc[b][1] += Mv[b][1] * cz0;
+              if (K == 15) oacc[b][2] += Mv[b][2] * cz0;
+              if (K == 16) oacc[b][0] += Mv[b][1] * cz1;
+              if (K == 17) oacc[b][1] += Mv[b][3] * cz1;
+              if (K == 18) oacc[b][2] += Mv[b][4] * cz1;
+              if (K == 19) oacc[b][0] += Mv[b][2] * cz2;
+              if (K == 20) oacc[b][1] += Mv[b][4] * cz2;
+              if (K == 21) oacc[b][2] += Mv[b][5] * cz2;
+            }
+          }
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        // what travels behind MFMA m of a tile.  Previous tile: block 0's contraction in slots 0 (read) and 3..13 (two operations
+        // each), block 1's in 12 and 15..25.  This tile: the next tile's chain start (bias x edge factor) in 27 / 28, block 0's sum
+        // in 29 (block 1's closes the tile)
+        auto travel = [&](auto mc, const float* xp) {
+          constexpr int m = decltype(mc)::value;
+          if constexpr (m == 0) cop(B0{}, std::integral_constant<int, 0>{}, xp);
+          if constexpr (m >= 3 && m <= 13) { cop(B0{}, std::integral_constant<int, 2 * (m - 3) + 1>{}, xp); cop(B0{}, std::integral_constant<int, 2 * (m - 3) + 2>{}, xp); }
+          if constexpr (m == 12) cop(B1{}, std::integral_constant<int, 0>{}, xp);
+          if constexpr (m >= 15 && m <= 25) { cop(B1{}, std::integral_constant<int, 2 * (m - 15) + 1>{}, xp); cop(B1{}, std::integral_constant<int, 2 * (m - 15) + 2>{}, xp); }
+          if constexpr (m == 27) scale4(accN[0], bias_n, se[0]);
+          if constexpr (m == 28) scale4(accN[1], bias_n, se[1]);
+          if constexpr (m == 29) sum4(accp[0], accS[0], accB[0]);
+        };
+        // tile i carries the contraction of tile i - 1; the run's first tile carries one of zeros (same code, no second copy
+        // of the loop body for the register allocator to fit)
+        const float* xp = xs_lane + xo;
+        accp[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accp[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < nt; ++i) {
+          if (par) tile(I1{}, tile0 + i, [&](auto mc) { travel(mc, xp); });
+          else tile(I0{}, tile0 + i, [&](auto mc) { travel(mc, xp); });
+          par ^= 1;
+          if (i) xp += x_step;
+        }
+        // the run's last tile is contracted in the open (its successor belongs to another path type)
+        __builtin_amdgcn_sched_barrier(0);
+#define COPS(b) cop(b, std::integral_constant<int, 0>{}, xp); cop(b, std::integral_constant<int, 1>{}, xp); cop(b, std::integral_constant<int, 2>{}, xp); \
+        cop(b, std::integral_constant<int, 3>{}, xp); cop(b, std::integral_constant<int, 4>{}, xp); cop(b, std::integral_constant<int, 5>{}, xp); \
+        cop(b, std::integral_constant<int, 6>{}, xp); cop(b, std::integral_constant<int, 7>{}, xp); cop(b, std::integral_constant<int, 8>{}, xp); \
+        cop(b, std::integral_constant<int, 9>{}, xp); cop(b, std::integral_constant<int, 10>{}, xp); cop(b, std::integral_constant<int, 11>{}, xp); \
+        cop(b, std::integral_constant<int, 12>{}, xp); cop(b, std::integral_constant<int, 13>{}, xp); cop(b, std::integral_constant<int, 14>{}, xp); \
+        cop(b, std::integral_constant<int, 15>{}, xp); cop(b, std::integral_constant<int, 16>{}, xp); cop(b, std::integral_constant<int, 17>{}, xp); \
+        cop(b, std::integral_constant<int, 18>{}, xp); cop(b, std::integral_constant<int, 19>{}, xp); cop(b, std::integral_constant<int, 20>{}, xp); \
+        cop(b, std::integral_constant<int, 21>{}, xp); cop(b, std::integral_constant<int, 22>{}, xp);
+        COPS(B0{}) COPS(B1{})
+#undef COPS
+        if (flags & 2) {   // last run of the channel group: this lane owns msg[e][oo .. oo + (VOUT ? 3 : 1)); the edge's factor comes off
+          if (oo < D_out) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              if (e0 + 16 * b + n < E) {
+                float* op = d.msg + (size_t)(e0 + 16 * b + n) * D_out + oo;
+                op[0] = oacc[b][0] * ue[b];
+                if (VOUT) { op[1] = oacc[b][1] * ue[b]; op[2] = oacc[b][2] * ue[b]; }
+              }
+          }
+        }
+      };
+      switch (type) {
+        case PT_SS: run(std::integral_constant<int, PT_SS>{}); break;
+        case PT_SV: run(std::integral_constant<int, PT_SV>{}); break;
+        case PT_VS: run(std::integral_constant<int, PT_VS>{}); break;
+        case PT_VVS: run(std::integral_constant<int, PT_VVS>{}); break;
+        case PT_VVV: run(std::integral_constant<int, PT_VVV>{}); break;
+        default: run(std::integral_constant<int, PT_VTV>{}); break;
+      }
+    }
+#undef M32
+#undef M16
+#undef HB
+#undef TB
+  }
+  if (a.trace && blockIdx.x == 0 && tid == 0) { a.trace[2] = __builtin_readcyclecounter(); a.trace[3] = __builtin_amdgcn_s_memrealtime(); }
+  // ---- the last workgroup to leave re-arms the queue for the next launch
+  if (tid == 0) {
+    const int dn = atomicAdd(a.queue + 1, 1);
+    if (dn == n_wg - 1) { a.queue[0] = 0; a.queue[1] = 0; __threadfence(); }
+  }
+}
+
+void launch_conv2h(const Conv2Args& a, hipStream_t st) {
+  static int n_cu = 0;
+  static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
+  static int abl = getenv("DBFR_CONV2H_ABL") ? atoi(getenv("DBFR_CONV2H_ABL")) : 0;   // developer ablations (wrong results)
+  constexpr int NW = 8;
+  const size_t lds = CH_RING_BYTES + (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
+  Conv2Args b = a;
+  b.skew = 0;
+  b.run_barrier = 0;
+  b.no_split = no_split;
+#define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                         hipLaunchKernelGGL((k_conv2h<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
+  V(1) V(2) V(3) V(4) V(7) V(8) V(16) V(64)
+#undef V
+  // (set on every launch: the attribute is per device, and a process may drive several)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_conv2h<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+}

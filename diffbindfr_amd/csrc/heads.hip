@@ -654,11 +654,12 @@ void launch_fill(float* p, float v, int n, hipStream_t st) {
 }
 __global__ void k_set_int(int* p, int v) { *p = v; }
 void launch_set_int(int* p, int v, hipStream_t st) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, p, v); }
-__global__ void k_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter) {
+__global__ void k_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double fused_bytes_per_edge, double* counter) {
   // atomics: in profile mode 2 the four convs of a layer run on four streams
   atomicAdd(&counter[0], flops_per_edge * (double)*n_edges);
   atomicAdd(&counter[1], bytes_per_edge * (double)*n_edges);
+  atomicAdd(&counter[2], fused_bytes_per_edge * (double)*n_edges);
 }
-void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double* counter, hipStream_t st) {
-  hipLaunchKernelGGL(k_acc_flops, dim3(1), dim3(1), 0, st, n_edges, flops_per_edge, bytes_per_edge, counter);
+void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double fused_bytes_per_edge, double* counter, hipStream_t st) {
+  hipLaunchKernelGGL(k_acc_flops, dim3(1), dim3(1), 0, st, n_edges, flops_per_edge, bytes_per_edge, fused_bytes_per_edge, counter);
 }

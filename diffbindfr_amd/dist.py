@@ -8,6 +8,7 @@ pickled-uint8 all_gather of druglib/core/runner/engine/test_utils.py:96-145.  He
 records are fixed-size float tensors, so one ``all_gather_into_tensor`` suffices.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -27,6 +28,11 @@ def init(backend=None):
         # DBFR_DIST_BACKEND=gloo: developer override to walk the multi-rank path on a box with fewer GPUs than ranks
         backend = backend or os.environ.get("DBFR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if rank == 0:       # one line, so that an RCCL start-up failure can be told from a sampler failure in the driver's log
+            ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            print(f"[dbfr.dist] backend={backend} (nccl = RCCL on ROCm) world={world} devices_visible={ndev} "
+                  f"master={os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
     return rank, world, local
 
 
@@ -124,7 +130,43 @@ def shard_jobs(jobs, poses, world):
     return shard_lpt([j.cost * p for j, p in zip(jobs, reps)], world), reps
 
 
-def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_max=10.0, gather=True, on_batch=None):
+def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
+    """Bring the flat record buffers of all ranks together in bounded windows.
+
+    ``local``: this rank's 1-D float buffer (device or pinned host); ``n_all[r]``: floats in use on rank r (every rank derives all
+    of them from the job table, so no size exchange is needed and idle ranks walk the same windows).  ``mode``: "all" (every
+    rank receives everything: ``all_gather_into_tensor``) or "root" (rank 0 only: ``gather``).  At most ``window`` floats per
+    rank travel per collective, staged through ``stage_dev`` (the rank's GPU for RCCL, the host for gloo), so the device
+    memory the gather needs is ``(world + 1) * window * 4`` bytes whatever the size of the job table.
+    Returns list[world] of buffers like ``local`` (None for ranks this rank does not receive)."""
+    n_valid, n_max = int(n_all[rank]), int(max(n_all))
+    recv = mode == "all" or rank == 0
+    like = dict(dtype=local.dtype, device=local.device, pin_memory=local.device.type == "cpu" and torch.cuda.is_available())
+    out = [torch.empty(int(n_all[r]), **like) if recv and r != rank else None for r in range(world)]
+    out[rank] = local[:n_valid]
+    for w0 in range(0, n_max, window):
+        w = min(window, n_max - w0)
+        send = torch.zeros(w, dtype=local.dtype, device=stage_dev)
+        k = max(0, min(w, n_valid - w0))
+        if k:
+            send[:k] = local[w0:w0 + k].to(stage_dev, non_blocking=True)
+        if mode == "all":
+            buf = torch.empty(world * w, dtype=local.dtype, device=stage_dev)
+            dist.all_gather_into_tensor(buf, send)
+            parts = buf.view(world, w)
+        else:
+            parts = [torch.empty(w, dtype=local.dtype, device=stage_dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(send, parts, dst=0)
+        if recv:
+            for r in range(world):
+                k = max(0, min(w, int(n_all[r]) - w0))
+                if r != rank and k:
+                    out[r][w0:w0 + k] = parts[r][:k].to(out[r].device)
+    return out
+
+
+def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_max=10.0, gather=True, on_batch=None,
+                store="device", window_bytes=256 << 20, release=True):
     """The multi-GPU product entry: a job list in, poses out in job order.
 
         jobs    list of ``assemble.ComplexRecord`` -- the (protein, ligand) pair table of the reference
@@ -132,55 +174,77 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
                 ``PocketRecord``; target fishing (config 4): they share ONE ``LigandRecord``; the shared half is
                 replicated on every rank and uploaded once per device.
         poses   poses per job (int or list)
+        gather  True / "all": every rank returns every job's poses (one ``all_gather_into_tensor`` per window);
+                "root": only rank 0 does (``gather`` to rank 0 -- a forward screen's 10 k jobs x 40 poses are 1.8 GB: no
+                reason to land them on all eight GPUs); False: no collective, every rank returns its own jobs.
+        store   "device": the pose records stay in HBM; "host": every batch's records go to pinned host memory as the batch
+                finishes and the gather is staged through a ``window_bytes`` device buffer -- HBM use is then bounded by one
+                batch + the window, whatever the size of the job table.
+        release drop a record half's device copy (``_Half.release``) after the last batch of this rank that uses it.
 
     Every rank holds the whole (cheap, host-side) job table, takes its LPT share, runs it in batches of <= ``batch_poses``
-    poses through ``sample_complexes`` (per-job random streams => the result does not depend on the sharding), writes
-    fixed-size pose records [ligand N_l,max x 3 | atom14 N_r,max x 14 x 3] and ONE ``all_gather_into_tensor`` brings them to
-    every rank (RCCL over xGMI; the reference's counterpart is the pickled all_gather of
-    druglib/core/runner/engine/test_utils.py:96-145).  No collective on the data path before that.
-    Returns list[len(jobs)] of (lig [P, N_l, 3], atom14 [P, N_r, 14, 3]) device tensors in job order (None when
-    ``gather=False`` on ranks that did not run the job)."""
+    poses through ``run_complexes``.  Every JOB draws from its own generator ``job_seed(seed, job)``; a job cut into several
+    batches draws its whole tape each time and uses its rows (``pose_ranges``), so the result depends neither on the
+    sharding nor on ``batch_poses``.  Records are RAGGED: job j contributes ``poses_j x (3 N_l,j + 42 N_r,j)`` floats to its
+    rank's flat buffer (no padding to the largest complex).  No collective on the data path before the final gather (RCCL
+    over xGMI; the reference's counterpart is the pickled all_gather of druglib/core/runner/engine/test_utils.py:96-145).
+    Returns list[len(jobs)] of (lig [P, N_l, 3], atom14 [P, N_r, 14, 3]) in job order (None for jobs this rank does not hold)."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     dev = torch.device(device)
+    assert store in ("device", "host") and gather in (True, False, "all", "root")
+    mode = "all" if gather is True else gather
     shards, reps = shard_jobs(jobs, poses, world)
-    max_nl = max(j.n_l for j in jobs)
-    max_nr = max(j.n_r for j in jobs)
-    R = 3 * max_nl + 42 * max_nr
-    # record rows of a rank: its jobs in shard order, poses consecutive
-    row0 = [{} for _ in range(world)]
-    n_rows = [0] * world
+    width = [3 * j.n_l + 42 * j.n_r for j in jobs]
+    # flat record buffer of a rank: its jobs in shard order, poses consecutive
+    off = [{} for _ in range(world)]
+    n_flt = [0] * world
     for r in range(world):
         for j in shards[r]:
-            row0[r][j] = n_rows[r]
-            n_rows[r] += reps[j]
-    n_max = max(n_rows)
-    local = torch.zeros(max(n_max, 1), R, device=dev)
-    for bi, batch in enumerate(plan_batches([(j, reps[j]) for j in shards[rank]], batch_poses)):
+            off[r][j] = n_flt[r]
+            n_flt[r] += reps[j] * width[j]
+    on_host = store == "host" or dev.type == "cpu"
+    local = (torch.empty(max(n_flt[rank], 1), pin_memory=dev.type == "cuda") if on_host
+             else torch.empty(max(n_flt[rank], 1), device=dev))
+    batches = plan_batches([(j, reps[j]) for j in shards[rank]], batch_poses)
+    last_use = {}
+    for bi, batch in enumerate(batches):
+        for j, _, _ in batch:
+            last_use[id(jobs[j].lig)] = last_use[id(jobs[j].pocket)] = bi
+    for bi, batch in enumerate(batches):
         recs = [jobs[j] for j, _, _ in batch]
         pb, lig, a14 = sampler.run_complexes(recs, [n for _, _, n in batch], device=dev, tr_sigma_max=tr_sigma_max,
-                                             seeds=[sampler.job_seed(seed, j, p0) for j, p0, _ in batch])
+                                             seeds=[sampler.job_seed(seed, j) for j, _, _ in batch],
+                                             pose_ranges=[(p0, reps[j]) for j, p0, _ in batch])
         lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
         g = 0
         for j, p0, n in batch:          # the n poses of a job are consecutive, equal-sized graphs: two strided copies per job
             nl, nr = jobs[j].n_l, jobs[j].n_r
-            rows = local[row0[rank][j] + p0: row0[rank][j] + p0 + n]
-            rows[:, :3 * nl] = lig[-1, lp[g]:lp[g + n]].reshape(n, 3 * nl)
-            rows[:, 3 * max_nl: 3 * max_nl + 42 * nr] = a14[-1, rp[g]:rp[g + n]].reshape(n, 42 * nr)
+            rows = local[off[rank][j] + p0 * width[j]: off[rank][j] + (p0 + n) * width[j]].view(n, width[j])
+            rows[:, :3 * nl].copy_(lig[-1, lp[g]:lp[g + n]].reshape(n, 3 * nl), non_blocking=True)
+            rows[:, 3 * nl:].copy_(a14[-1, rp[g]:rp[g + n]].reshape(n, 42 * nr), non_blocking=True)
             g += n
+        if on_host and dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()      # the batch's tensors are recycled by the next batch
+        if release:
+            for j, _, _ in batch:
+                for half in (jobs[j].lig, jobs[j].pocket):
+                    if last_use.get(id(half)) == bi:
+                        half.release()
         if on_batch is not None:
             on_batch(bi, sum(n for _, _, n in batch))
-    if world > 1 and gather:
-        allr = gather_records(local, world).view(world, max(n_max, 1), R)
+    if world > 1 and mode:
+        gloo = dist.get_backend() == "gloo"
+        stage = torch.device("cpu") if gloo else dev
+        bufs = _gather_windows(local, n_flt, world, rank, mode, max(1, int(window_bytes) // 4), stage)
     else:
-        allr = local.view(1, max(n_max, 1), R) if world == 1 else None
+        bufs = [local if r == rank else None for r in range(world)]
     res = [None] * len(jobs)
     for r in range(world):
-        if allr is None and r != rank:
+        if bufs[r] is None:
             continue
-        src = allr[r] if allr is not None else local
         for j in shards[r]:
-            rows = src[row0[r][j]: row0[r][j] + reps[j]]
             nl, nr = jobs[j].n_l, jobs[j].n_r
-            res[j] = (rows[:, :3 * nl].reshape(reps[j], nl, 3), rows[:, 3 * max_nl: 3 * max_nl + 42 * nr].reshape(reps[j], nr, 14, 3))
+            rows = bufs[r][off[r][j]: off[r][j] + reps[j] * width[j]].view(reps[j], width[j])
+            res[j] = (rows[:, :3 * nl].reshape(reps[j], nl, 3), rows[:, 3 * nl:].reshape(reps[j], nr, 14, 3))
     return res

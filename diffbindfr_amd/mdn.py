@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import lib as L
+from .registry import ENERGY
 
 GT_LAYERS, GVP_LAYERS = 6, 3
 
@@ -141,9 +142,11 @@ def pocket_features(aatype, atom14_pos, res_ptr=None, topk=30):
     return out
 
 
+@ENERGY.register_module(name=["KarmaDockHIP"])
 class KarmaDockHIP(nn.Module):
-    def __init__(self):
+    def __init__(self, cfg=None, **kwargs):
         super().__init__()
+        self.cfg = cfg
         for k, shp in param_shapes().items():
             buf = k.endswith(("running_mean", "running_var"))
             _put(self, k, torch.ones(shp) if k.endswith(("running_var", "norm.weight")) else torch.zeros(shp), buf)
@@ -305,3 +308,69 @@ class KarmaDockHIP(nn.Module):
     def forward(self, data):
         """KarmaDock.forward (KarmaDock_sc.py:58-70)."""
         return self.score(batch_from_hetero(data) if not isinstance(data, dict) or "ligand" in data else data)
+
+
+# ------------------------------------------------------------------------------------------------ the Scorer entry
+def collate_flat(items):
+    """Concatenate flat per-pair dicts (``batch_from_hetero`` layout, one graph each or already batched) into one batch --
+    what the reference's PyG DataLoader does with the HeteroData samples (engines.py:270-277): node tensors stacked, edge
+    indices shifted by the node offsets, ``*_batch`` renumbered."""
+    out = {k: [] for k in items[0]}
+    lo = po = g = 0
+    for it in items:
+        nl, nr = int(it["lig_pos"].shape[0]), int(it["pro_node_s"].shape[0])
+        lb = torch.as_tensor(it.get("lig_batch", torch.zeros(nl, dtype=torch.long))).long()
+        pb = torch.as_tensor(it.get("pro_batch", torch.zeros(nr, dtype=torch.long))).long()
+        for k, v in it.items():
+            v = torch.as_tensor(v)
+            if k == "lig_edge_index":
+                v = v.long() + lo
+            elif k == "pro_edge_index":
+                v = v.long() + po
+            elif k == "lig_batch":
+                v = lb + g
+            elif k == "pro_batch":
+                v = pb + g
+            out[k].append(v)
+        if "lig_batch" not in it:
+            out.setdefault("lig_batch", []).append(lb + g)
+        if "pro_batch" not in it:
+            out.setdefault("pro_batch", []).append(pb + g)
+        lo += nl; po += nr
+        g += int(lb.max()) + 1 if nl else 1
+    return {k: torch.cat(v, 1 if k.endswith("edge_index") else 0) for k, v in out.items() if v}
+
+
+def Scorer(test_dataset, model_weight=None, output_path="mdn_score.csv", batch_size=16, device_id=0, logger=None, model=None):
+    """Drop-in shape of DiffBindFR/common/engines.py:230-302: score every (pocket, ligand pose) sample of ``test_dataset`` with
+    the MDN network and write ``test_dataset.pair_frame['mdn_score']`` to ``output_path``.
+
+    ``test_dataset``: indexable, ``len()``; item i is the featurised sample of pair i -- the reference's HeteroData (anything
+    ``batch_from_hetero`` reads) or the flat dict -- and ``pair_frame`` a pandas frame with one row per item (optional).
+    ``model_weight``: a state_dict, a path ``torch.load`` reads, or None (keep ``model``'s weights); keys carrying
+    DataParallel's ``module.`` prefix are accepted, unknown keys ignored (``strict=False`` like engines.py:263-268).
+    Batches of ``batch_size`` samples are collated here (``collate_flat``) and go through ONE ``dbfr_mdn_forward`` each.
+    Returns the list of scores (the reference returns None after writing the file)."""
+    dev = torch.device(f"cuda:{device_id}" if not isinstance(device_id, torch.device) else device_id)
+    model = model or KarmaDockHIP()
+    if model_weight is not None:
+        sd = model_weight if isinstance(model_weight, dict) else torch.load(str(model_weight), map_location="cpu")
+        sd = sd.get("model_state_dict", sd) if isinstance(sd, dict) else sd
+        model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}, strict=False)
+    if logger is not None:
+        logger.info("Load scoring model...")
+    scores = []
+    n = len(test_dataset)
+    for i0 in range(0, n, batch_size):
+        items = [test_dataset[i] for i in range(i0, min(n, i0 + batch_size))]
+        flat = [it if isinstance(it, dict) and "ligand" not in it else batch_from_hetero(it) for it in items]
+        d = {k: v.to(dev) for k, v in collate_flat(flat).items()}
+        scores.extend(model.score(d).cpu().numpy().tolist())
+    frame = getattr(test_dataset, "pair_frame", None)
+    if frame is not None:
+        frame["mdn_score"] = scores
+        if output_path is not None:
+            frame.to_csv(str(output_path), index=False)
+    if logger is not None:
+        logger.info("Model Scoring is Done!")
+    return scores

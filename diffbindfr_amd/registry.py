@@ -68,6 +68,7 @@ class Registry:
 
 
 INTERACTION = Registry("interaction")
+ENERGY = Registry("energy")
 MLDOCK_BUILDER = Registry("mldock model builder")
 
 
@@ -76,13 +77,19 @@ def build_interaction(cfg):
     return INTERACTION.build(cfg)
 
 
+def build_energy(cfg):
+    """druglib/models/builder.py:36-38 (the registry the reference's ``scoring_model=`` goes through; it registers nothing
+    there itself -- its MDN scorer lives in DiffBindFR/scoring and is driven by common/engines.py:Scorer)."""
+    return ENERGY.build(cfg)
+
+
 def register_into_druglib():
     """Best effort: plug into the reference's registries when it is importable."""
     try:
-        from druglib.models.builder import INTERACTION as REF_I, MLDOCK_BUILDER as REF_M  # noqa
+        from druglib.models.builder import INTERACTION as REF_I, MLDOCK_BUILDER as REF_M, ENERGY as REF_E  # noqa
     except Exception:
         return False
-    for reg, ref in ((INTERACTION, REF_I), (MLDOCK_BUILDER, REF_M)):
+    for reg, ref in ((INTERACTION, REF_I), (MLDOCK_BUILDER, REF_M), (ENERGY, REF_E)):
         for n, cls in reg.module_dict.items():
             if ref.get(n) is not cls:
                 ref.register_module(name=n, overwrite=ref.get(n) is not None, module=cls)

@@ -15,7 +15,7 @@ from torch import nn
 from . import lib as L
 from . import schedule
 from .packing import PackedBatch, _get, _has
-from .registry import MLDOCK_BUILDER, build_interaction
+from .registry import MLDOCK_BUILDER, build_energy, build_interaction
 from .score_model import TensorProductModelHIP, cfg_get
 
 
@@ -42,9 +42,19 @@ class DiffBindFRHIP(nn.Module):
     def __init__(self, diffusion_model=None, scoring_model=None, train_cfg=None, test_cfg=None, pretrained=None,
                  init_cfg=None, **kwargs):
         super().__init__()
-        if scoring_model is not None:
-            raise NotImplementedError("the scoring model is outside this path (SURVEY.md section 8 f4)")
-        if isinstance(diffusion_model, nn.Module):
+        if scoring_model is not None:          # scFlex.py:43-46: built through the ENERGY registry (``mdn.KarmaDockHIP`` is registered there)
+            if isinstance(scoring_model, nn.Module):
+                self.scoring_model = scoring_model
+            else:
+                from . import mdn  # noqa: F401  (registers KarmaDockHIP)
+                sm = dict(scoring_model)
+                if sm.get("type") in (None, "KarmaDock"):
+                    sm["type"] = "KarmaDockHIP"
+                self.scoring_model_cfg = sm.get("cfg")
+                self.scoring_model = build_energy(sm)
+        if diffusion_model is None:
+            pass                                   # scFlex.py:39: a scorer-only model is legal
+        elif isinstance(diffusion_model, nn.Module):
             self.diffusion_model = diffusion_model
         else:
             dm = dict(diffusion_model)
@@ -124,9 +134,11 @@ class DiffBindFRHIP(nn.Module):
         x ^= x >> 31
         return x & (2 ** 63 - 1)
 
-    def draw_tapes(self, records, poses, seeds, dev, tr_sigma_max=10.0):
-        """Initialisation tape (``assemble.draw_init_tape`` layout) and SDE noise tape of a complex-major batch, drawn
-        complex by complex on the device from ``torch.Generator(seed_c)``."""
+    def draw_tapes(self, records, poses, seeds, dev, tr_sigma_max=10.0, pose_ranges=None):
+        """Initialisation tape (``assemble.draw_init_tape_dims`` layout) and SDE noise tape of a complex-major batch, drawn
+        complex by complex on the device from ``torch.Generator(seed_c)``.  ``pose_ranges[c] = (p0, P_total)``: the batch
+        holds poses ``p0 .. p0 + poses[c]`` of a job of ``P_total`` poses -- the job's WHOLE tape is drawn and the rows of
+        these poses are cut out, so a job's poses do not depend on how the driver cut it into batches."""
         from . import assemble
         recs_, _ = self.schedule()
         T = len(recs_)
@@ -134,15 +146,19 @@ class DiffBindFRHIP(nn.Module):
         init = {k: [] for k in ("tor", "rot", "tr", "sc")}
         z = {k: [] for k in ("tr", "rot", "tor", "sc")}
         gen = torch.Generator(device=dev)
-        for r, P, s in zip(records, reps, seeds):
+        for c, (r, P, s) in enumerate(zip(records, reps, seeds)):
+            p0, Pt = (0, P) if pose_ranges is None else pose_ranges[c]
+            assert 0 <= p0 and p0 + P <= Pt
             gen.manual_seed(int(s))
-            t = assemble.draw_init_tape_dims(P, P * r.n_tor, P * r.n_r, dev, tr_sigma_max, gen)
-            for k in init:
-                init[k].append(t[k])
-            z["tr"].append(torch.randn(T, P, 3, device=dev, generator=gen))
-            z["rot"].append(torch.randn(T, P, 3, device=dev, generator=gen))
-            z["tor"].append(torch.randn(T, P * r.n_tor, device=dev, generator=gen))
-            z["sc"].append(torch.randn(T, P * r.n_sc, device=dev, generator=gen))
+            t = assemble.draw_init_tape_dims(Pt, Pt * r.n_tor, Pt * r.n_r, dev, tr_sigma_max, gen)
+            init["tor"].append(t["tor"][p0 * r.n_tor:(p0 + P) * r.n_tor])
+            init["rot"].append(t["rot"][p0:p0 + P])
+            init["tr"].append(t["tr"][p0:p0 + P])
+            init["sc"].append(t["sc"][p0 * r.n_r:(p0 + P) * r.n_r])
+            z["tr"].append(torch.randn(T, Pt, 3, device=dev, generator=gen)[:, p0:p0 + P])
+            z["rot"].append(torch.randn(T, Pt, 3, device=dev, generator=gen)[:, p0:p0 + P])
+            z["tor"].append(torch.randn(T, Pt * r.n_tor, device=dev, generator=gen)[:, p0 * r.n_tor:(p0 + P) * r.n_tor])
+            z["sc"].append(torch.randn(T, Pt * r.n_sc, device=dev, generator=gen)[:, p0 * r.n_sc:(p0 + P) * r.n_sc])
         init = {k: torch.cat(v, 0) for k, v in init.items()}
         z = {k: torch.cat(v, 1) for k, v in z.items()}
         for k in ("tor", "sc"):
@@ -154,7 +170,7 @@ class DiffBindFRHIP(nn.Module):
             if r_.noise_free:
                 for v in z.values():
                     v[s_].zero_()
-        return init, {k: v.contiguous() for k, v in z.items()}
+        return {k: v.contiguous() for k, v in init.items()}, {k: v.contiguous() for k, v in z.items()}
 
     @torch.no_grad()
     def sample_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0,
@@ -172,9 +188,10 @@ class DiffBindFRHIP(nn.Module):
 
     @torch.no_grad()
     def run_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0, job_ids=None,
-                      seeds=None):
+                      seeds=None, pose_ranges=None):
         """``sample_complexes`` without the per-graph split: (packed batch, lig [T,NL,3], atom14 [T,NR,14,3]) on the device;
-        graphs are complex-major, so the poses of complex c are rows ``pb.lig_ptr_host[g0] .. [g0 + poses_c]``."""
+        graphs are complex-major, so the poses of complex c are rows ``pb.lig_ptr_host[g0] .. [g0 + poses_c]``.
+        ``pose_ranges``: see ``draw_tapes`` (a job cut into several batches by ``dist.run_sharded``)."""
         from . import assemble
         dev = torch.device(device)
         recs = [r if isinstance(r, assemble.ComplexRecord) else assemble.ComplexRecord(r) for r in records]
@@ -185,7 +202,7 @@ class DiffBindFRHIP(nn.Module):
             seeds = [self.job_seed(seed, j) for j in job_ids]
         with torch.cuda.device(dev):
             pb = assemble.assemble(recs, poses, dev)
-            init, z = self.draw_tapes(recs, poses, seeds, dev, tr_sigma_max)
+            init, z = self.draw_tapes(recs, poses, seeds, dev, tr_sigma_max, pose_ranges)
             assemble.init_poses(self.diffusion_model, pb, init)
             lig, a14 = self.sample_packed(pb, z, visualize=visualize)
         return pb, lig, a14

@@ -102,6 +102,9 @@ def conv_paths(kind):
     return wn.value, [list(tab[10 * i:10 * i + 10]) for i in range(n)]
 
 
+GEMM_MODES = {"f32": 0, "split": 1, "split_l1": 2, "split_f16": 3}     # include/dbfr.h: DBFR_GEMM_*
+
+
 @INTERACTION.register_module(name=["TensorProductModelHIP"])
 class TensorProductModelHIP(nn.Module):
     def __init__(self, cfg):
@@ -112,7 +115,7 @@ class TensorProductModelHIP(nn.Module):
         assert not g("use_second_order_repr", False), "use_second_order_repr=True is not supported"
         self.no_sc_torsion = bool(g("no_sc_torsion", False))
         # which matrix instruction carries the radial MLP's big GEMM: None = the library's default (or $DBFR_GEMM),
-        # "f32" = v_mfma_f32_16x16x4_f32, "split" = three bf16 pieces per fp32 operand on v_mfma_f32_16x16x32_bf16, "split_l1" = the same without the LDS ring (include/dbfr.h)
+        # "f32" = v_mfma_f32_16x16x4_f32, "split" = three bf16 pieces per fp32 operand on v_mfma_f32_16x16x32_bf16, "split_l1" = the same without the LDS ring, "split_f16" = two fp16 pieces / three products on v_mfma_f32_16x16x32_f16 (include/dbfr.h)
         self.gemm = g("gemm", None)
         ns, nv = int(g("ns", 48)), int(g("nv", 12))
         se, de = int(g("sigma_embed_dim", 32)), int(g("distance_embed_dim", 32))
@@ -227,20 +230,20 @@ class TensorProductModelHIP(nn.Module):
         with torch.cuda.device(idx):            # the library allocates on the current device
             L.check(lib.dbfr_model_create(C.byref(self.mcfg), arr, len(sd), C.byref(h)))
         if self.gemm is not None:
-            L.check(lib.dbfr_model_set_gemm(h, {"f32": 0, "split": 1, "split_l1": 2}[self.gemm]))
+            L.check(lib.dbfr_model_set_gemm(h, GEMM_MODES[self.gemm]))
         self._handles[idx] = (fp, h)
         return h
 
     def set_gemm(self, mode):
         """Switch the GEMM mode ("f32" | "split" | None = library default at the next re-pack) of this model on every device."""
-        assert mode in (None, "f32", "split", "split_l1")
+        assert mode in (None,) + tuple(GEMM_MODES)
         self.gemm = mode
         if mode is not None:
             for _, h in self._handles.values():
-                L.check(L.load().dbfr_model_set_gemm(h, {"f32": 0, "split": 1, "split_l1": 2}[mode]))
+                L.check(L.load().dbfr_model_set_gemm(h, GEMM_MODES[mode]))
 
     def gemm_mode(self, device=None):
-        return ("f32", "split", "split_l1")[L.load().dbfr_model_get_gemm(self.handle(device))]
+        return {v: k for k, v in GEMM_MODES.items()}[L.load().dbfr_model_get_gemm(self.handle(device))]
 
     def workspace(self, batch, device):
         lib = L.load()

@@ -397,13 +397,20 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
  *                            tolerances), 2.4x less matrix-pipe time; serves every batch size.  Kernel k_conv2r
  *                            (csrc/conv2r.hip): the W2 pieces reach the waves through an LDS ring, one copy per tile per CU;
  *   DBFR_GEMM_SPLIT_BF16_L1  the same arithmetic with every wave fetching its W2 pieces through the vector L1 (k_conv2s,
- *                            csrc/conv2s.hip): the simpler kernel, ~10 % slower, kept for comparison.
- * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_l1) says otherwise.
+ *                            csrc/conv2s.hip): the simpler kernel, ~10 % slower, kept for comparison;
+ *   DBFR_GEMM_SPLIT_F16      every operand cut into TWO fp16 pieces (hi = fp16(x), lo = fp16(x - hi): 23 of fp32's 24 significand
+ *                            bits) after an exact power-of-two scaling that keeps the pieces inside fp16's exponent range (W2: per
+ *                            tensor-product run, at model creation; activations: per edge, in the kernel), three partial products
+ *                            hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x32_f16, the two small ones and the large one in separate
+ *                            fp32 accumulators: half the matrix instructions of SPLIT_BF16.  Kernel k_conv2h (csrc/conv2h.hip);
+ *                            accuracy table: profiles/r3_split_experiments.txt.
+ * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_l1 | split_f16) says otherwise.
  * A workspace is laid out for the mode it was sized in: set the mode before dbfr_workspace_bytes.                       */
 #define DBFR_GEMM_F32 0
 #define DBFR_GEMM_SPLIT_BF16 1
 #define DBFR_GEMM_SPLIT_BF16_L1 2
-#define DBFR_GEMM_DEFAULT DBFR_GEMM_SPLIT_BF16
+#define DBFR_GEMM_SPLIT_F16 3
+#define DBFR_GEMM_DEFAULT DBFR_GEMM_SPLIT_F16
 int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
 int dbfr_model_get_gemm(const dbfr_model* model);
 
@@ -430,6 +437,9 @@ int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* 
 int dbfr_profile_enable(dbfr_model* m, int32_t on);
 int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, double* conv_flops,
                       double* ref_form_bytes, int32_t reset);
+/* HBM bytes the FUSED conv has to move for the launches the last dbfr_profile_read reported (read before its reset):
+ * 4 (48 + 9 + 3 + 48 + 48 + D_in + D_out) per edge = edge record, two gathered radial-MLP rows, gathered input row, message. */
+int dbfr_profile_fused_bytes(const dbfr_model* m, double* fused_form_bytes);
 
 /* Test hook: names (';'-separated) / byte offsets / sizes of the library's internal
  * buffers inside the workspace for this batch shape.  Returns the entry count.       */

@@ -83,12 +83,13 @@ class _StandInSampler:
     from diffbindfr_amd.sampler import DiffBindFRHIP as _D
     job_seed = staticmethod(_D.job_seed)
 
-    def run_complexes(self, records, poses, device, tr_sigma_max, seeds):
+    def run_complexes(self, records, poses, device, tr_sigma_max, seeds, pose_ranges=None):
         lig, a14, lp, rp = [], [], [0], [0]
-        for r, n, s in zip(records, poses, seeds):
-            g = torch.Generator().manual_seed(s)
-            lig.append(torch.randn(n * r.n_l, 3, generator=g))
-            a14.append(torch.randn(n * r.n_r, 14, 3, generator=g))
+        for c, (r, n, s) in enumerate(zip(records, poses, seeds)):
+            p0, pt = (0, n) if pose_ranges is None else pose_ranges[c]
+            g = torch.Generator().manual_seed(s)          # the job's WHOLE tape, then the rows of this chunk (like draw_tapes)
+            lig.append(torch.randn(pt, r.n_l, 3, generator=g)[p0:p0 + n].reshape(-1, 3))
+            a14.append(torch.randn(pt, r.n_r, 14, 3, generator=g)[p0:p0 + n].reshape(-1, 14, 3))
             for _ in range(n):
                 lp.append(lp[-1] + r.n_l)
                 rp.append(rp[-1] + r.n_r)
@@ -104,37 +105,113 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, q):
+# the job tables of the multi-rank CPU tests: (config, jobs, poses per job, batch size)
+_CASES = {
+    "w2": (3, 5, [3, 2, 9, 1, 2], 4),                      # job 2 is larger than a batch
+    "idle": (3, 5, [3, 2, 9, 1, 2], 4),                    # world 8, five jobs: three ranks have nothing to do
+    "ragged17": (2, 17, [1 + (7 * j) % 5 for j in range(17)], 6),   # 17 jobs of unequal size and pose count
+    "big": (4, 3, [2, 23, 1], 5),                          # one job of 23 poses in batches of 5
+}
+
+
+def _gloo_worker(rank, world, port, q, case, kw):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     ddist.init(backend="gloo")
-    raw, jobs = make_jobs(3, 5, 60, 10)
-    res = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 9, 1, 2], seed=11, device="cpu", batch_poses=4)
-    q.put((rank, [(l.numpy(), a.numpy()) for l, a in res]))
+    cfg, n_jobs, poses, bp = _CASES[case]
+    raw, jobs = make_jobs(cfg, n_jobs, 60, 10)
+    res = ddist.run_sharded(_StandInSampler(), jobs, poses, seed=11, device="cpu", batch_poses=bp, **kw)
+    q.put((rank, [None if r is None else (r[0].numpy(), r[1].numpy()) for r in res]))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_run_sharded_over_gloo_world2_equals_one_rank():
+def _run_world(world, case, **kw):
     import torch.multiprocessing as mp
-    raw, jobs = make_jobs(3, 5, 60, 10)
-    # job 2 has more poses than a batch holds: it is cut into chunks (0,4) (4,4) (8,1), each with its own random stream
-    one = ddist.run_sharded(_StandInSampler(), jobs, [3, 2, 9, 1, 2], seed=11, device="cpu", batch_poses=4)
-    assert [tuple(l.shape) for l, _ in one] == [(p, j.n_l, 3) for p, j in zip([3, 2, 9, 1, 2], jobs)]
-    assert not torch.equal(one[2][0][0], one[2][0][4])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q, case, kw)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=180) for _ in procs), key=lambda x: x[0])
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
     for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    for _, res in got:                      # every rank holds every job's poses, in job order, bit for bit
-        for (l, a), (l1, a1) in zip(res, one):
-            assert np.array_equal(l, l1.numpy()) and np.array_equal(a, a1.numpy())
+        p.join(120)
+        assert p.exitcode == 0            # nobody deadlocked, idle ranks included
+    return [g[1] for g in got]
+
+
+def _one_rank(case, batch_poses=None):
+    cfg, n_jobs, poses, bp = _CASES[case]
+    raw, jobs = make_jobs(cfg, n_jobs, 60, 10)
+    return jobs, poses, ddist.run_sharded(_StandInSampler(), jobs, poses, seed=11, device="cpu", batch_poses=batch_poses or bp)
+
+
+def _same(res, one):
+    return all(np.array_equal(l, l1.numpy()) and np.array_equal(a, a1.numpy()) for (l, a), (l1, a1) in zip(res, one))
+
+
+def test_run_sharded_over_gloo_world2_equals_one_rank():
+    jobs, poses, one = _one_rank("w2")
+    # job 2 has more poses than a batch holds: it is cut into chunks (0,4) (4,4) (8,1) that take their rows of the job's one tape
+    assert [tuple(l.shape) for l, _ in one] == [(p, j.n_l, 3) for p, j in zip(poses, jobs)]
+    assert not torch.equal(one[2][0][0], one[2][0][4])
+    for res in _run_world(2, "w2"):         # every rank holds every job's poses, in job order, bit for bit
+        assert _same(res, one)
+
+
+def test_result_does_not_depend_on_the_batch_size():
+    """a job cut into several batches used to seed every chunk separately, which made `batch_poses` part of the seed."""
+    _, _, a = _one_rank("big", batch_poses=5)
+    _, _, b = _one_rank("big", batch_poses=7)
+    _, _, c = _one_rank("big", batch_poses=64)
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[0], z[0]) and torch.equal(x[1], z[1]) for x, y, z in zip(a, b, c))
+
+
+@pytest.mark.parametrize("case", ["idle", "ragged17", "big"])
+def test_run_sharded_world8(case):
+    """World 8 over gloo through the real run_sharded: five jobs (three idle ranks), 17 jobs of unequal pose counts, one job larger
+    than a batch -- job order, bitwise equality with one rank, no deadlock of the ranks without work."""
+    jobs, poses, one = _one_rank(case)
+    shards, _ = ddist.shard_jobs(jobs, poses, 8)
+    if case == "idle":
+        assert sum(1 for s in shards if not s) == 3
+    for res in _run_world(8, case):
+        assert _same(res, one)
+
+
+def test_gather_to_root_and_windows_and_host_store():
+    """gather='root': rank 0 alone receives every job (dist.gather), the others keep their own; a window of 64 floats forces many
+    collectives per gather; store='host' keeps the records in host memory.  All bitwise equal to the one-rank result."""
+    jobs, poses, one = _one_rank("ragged17")
+    shards, _ = ddist.shard_jobs(jobs, poses, 4)
+    got = _run_world(4, "ragged17", gather="root", window_bytes=256, store="host")
+    assert _same(got[0], one)
+    for r in range(1, 4):
+        mine = set(shards[r])
+        for j, x in enumerate(got[r]):
+            assert (x is not None) == (j in mine)
+            if x is not None:
+                assert np.array_equal(x[0], one[j][0].numpy()) and np.array_equal(x[1], one[j][1].numpy())
+    for res in _run_world(3, "ragged17", gather="all", window_bytes=512):
+        assert _same(res, one)
+
+
+def test_record_halves_are_released_after_their_last_batch():
+    cfg, n_jobs, poses, bp = _CASES["w2"]
+    raw, jobs = make_jobs(cfg, n_jobs, 60, 10)          # cfg 3: one shared pocket
+    seen = []
+
+    class Spy(_StandInSampler):
+        def run_complexes(self, records, poses, device, tr_sigma_max, seeds, pose_ranges=None):
+            for r in records:
+                r.lig.dev("cpu"), r.pocket.dev("cpu")
+            seen.append(len(jobs[0].pocket.__dict__.get("_dev", {})))
+            return super().run_complexes(records, poses, device, tr_sigma_max, seeds, pose_ranges)
+    ddist.run_sharded(Spy(), jobs, poses, seed=1, device="cpu", batch_poses=bp)
+    assert all(s == 1 for s in seen)                       # the shared pocket stays resident while batches still need it ...
+    assert "_dev" not in jobs[0].pocket.__dict__           # ... and is dropped after the last one
+    assert all("_dev" not in j.lig.__dict__ for j in jobs)
 
 
 # ------------------------------------------------------------------------------------------------ GPU

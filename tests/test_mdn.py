@@ -208,3 +208,72 @@ def test_gpu_score_poses_of_one_complex_vs_oracle():
                  pro_batch=torch.zeros(len(aa), dtype=torch.long))
         ref, _, _ = oms.forward(P_, d)
         assert abs(float(got[p]) - float(ref[0])) <= 2e-4 * max(1.0, abs(float(ref[0]))), (p, got[p], ref[0])
+
+
+# ------------------------------------------------------------------------------------------------ Scorer entry / registry (row f4 glue)
+def test_collate_flat_equals_a_batch_built_at_once():
+    """``mdn.collate_flat`` (the PyG DataLoader's job in engines.py:270-277): per-pair flat dicts -> one batch with shifted edge
+    indices and renumbered graph ids; equal to generating the batch at once, and the oracle scores it the same."""
+    from diffbindfr_amd import mdn
+    from tests.test_mdn_inputs import mdn_inputs
+    sizes = [(9, 40), (15, 52), (4, 31)]
+    whole = mdn_inputs(np.random.default_rng(3), sizes, coincident=False)
+    lb, pb = whole["lig_batch"], whole["pro_batch"]
+    items = []
+    for g in range(len(sizes)):
+        lm, pm = lb == g, pb == g
+        l0, p0 = int(torch.nonzero(lm)[0]), int(torch.nonzero(pm)[0])
+        le = lm[whole["lig_edge_index"][0]]
+        pe = pm[whole["pro_edge_index"][0]]
+        it = {k: whole[k][lm] for k in ("lig_node_s", "lig_pos")}
+        it.update({k: whole[k][pm] for k in ("pro_node_s", "pro_node_v", "pro_seq", "pro_xyz_full")})
+        it.update(lig_edge_s=whole["lig_edge_s"][le], lig_edge_index=whole["lig_edge_index"][:, le] - l0,
+                  pro_edge_s=whole["pro_edge_s"][pe], pro_edge_v=whole["pro_edge_v"][pe], pro_edge_index=whole["pro_edge_index"][:, pe] - p0)
+        items.append(it)
+    got = mdn.collate_flat(items)
+    assert set(got) == set(whole)
+    for k in whole:
+        assert torch.equal(got[k], whole[k]), k
+
+
+def test_scoring_model_goes_through_the_energy_registry():
+    """scFlex.py:43-46: ``DiffBindFR(scoring_model=cfg)`` builds it with ``build_energy``; here ENERGY holds KarmaDockHIP
+    ('KarmaDock' as a type name is mapped onto it)."""
+    import diffbindfr_amd as dba
+    from diffbindfr_amd import mdn, registry
+    assert registry.ENERGY.get("KarmaDockHIP") is mdn.KarmaDockHIP
+    for cfg in ({"type": "KarmaDockHIP"}, {"type": "KarmaDock", "cfg": {"x": 1}}):
+        m = dba.DiffBindFRHIP(diffusion_model=None, scoring_model=cfg)
+        assert isinstance(m.scoring_model, mdn.KarmaDockHIP) and not hasattr(m, "diffusion_model")
+    both = dba.DiffBindFRHIP(diffusion_model={"type": "TensorProductModel", "cfg": {}}, scoring_model={"type": "KarmaDockHIP"})
+    assert isinstance(both.scoring_model, mdn.KarmaDockHIP) and isinstance(both.diffusion_model, dba.TensorProductModelHIP)
+    with pytest.raises(KeyError):
+        dba.DiffBindFRHIP(diffusion_model=None, scoring_model={"type": "NoSuchScorer"})
+
+
+@pytest.mark.gpu
+def test_gpu_scorer_entry_writes_the_pair_frame(tmp_path):
+    """``mdn.Scorer`` (engines.py:230-302): samples one by one -> batches of `batch_size` -> mdn_score column + csv; the scores
+    equal the oracle's on the same samples, whatever the batch size, and DataParallel's `module.` key prefix is accepted."""
+    import pandas as pd
+    from diffbindfr_amd import mdn
+    from tests.test_mdn_inputs import mdn_inputs
+    dev = torch.device("cuda:0")
+    P = oms.init_params(seed=11)
+    rng = np.random.default_rng(8)
+    items = [mdn_inputs(rng, [s], coincident=False) for s in ((9, 40), (15, 52), (4, 31), (21, 75), (12, 60))]
+    ref = torch.cat([oms.forward(P, it)[0] for it in items])
+
+    class DS(list):
+        pass
+    out = []
+    for bs in (2, 16):
+        ds = DS(items)
+        ds.pair_frame = pd.DataFrame({"pair": list(range(len(items)))})
+        csv = tmp_path / f"mdn_{bs}.csv"
+        s = mdn.Scorer(ds, model_weight={"module." + k: v for k, v in P.items()}, output_path=csv, batch_size=bs, device_id=0)
+        assert rel_err(torch.tensor(s), ref) < 1e-4
+        back = pd.read_csv(csv)
+        assert list(back.columns) == ["pair", "mdn_score"] and np.allclose(back["mdn_score"], s)
+        out.append(s)
+    assert np.allclose(out[0], out[1], rtol=1e-5)
