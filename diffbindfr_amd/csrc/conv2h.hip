@@ -26,13 +26,12 @@
 //     tile instead of 6 + 6.  A has seven shares: the six 1-KiB pieces and the tile's 16 bias values (64 bytes; the other
 //     lanes of that share are out of the buffer's range, get zeros and write them into padding); waves 6, 7 both move the bias
 //     share, and waves 6, 7 duplicate B shares 0, 1: same bytes to the same place, no branch;
-//   * a share is fetched TWO TILES before it is written.  The W2 pieces of a layer (4 convs x 4.4 MB) do not fit the 4-MiB L2
-//     of an XCD, most fetches come from the MALL, and with the distance a single staging register set allows (< 1 tile) the
-//     waves spent 17 % of their time waiting in front of the LDS writes (ablations in profiles/r3_split_experiments.txt).  Two
-//     tiles need two staging sets selected by tile parity, i.e. two copies of the tile code behind a uniform branch -- where
-//     hipcc's wait-count pass merges the two histories and waits for vmcnt(0).  So the staging registers are v[244:255], outside
-//     the compiler's allocation (amdgpu_num_vgpr(244)), loads and LDS writes are inline assembly, and the wait is written by
-//     hand: in steady state exactly three ring loads are younger than the one a write needs (`put` below).
+//   * a share is re-fetched right behind its write, i.e. it travels for almost a whole tile (~ 0.8 us) before it is needed.  (Tried:
+//     two staging sets by tile parity = a distance of two tiles.  The uniform branch between the two tile bodies makes hipcc's
+//     wait-count pass wait for vmcnt(0) in front of every write, and with the staging registers taken out of the compiler's hands --
+//     v[244:255] behind amdgpu_num_vgpr(244), loads / waits / writes in inline assembly -- the kernel was correct but 1-2 % SLOWER
+//     than this form, and the reservation turned out not to be binding: another instantiation of the same template used v244 / v245
+//     as temporaries.  The W2 pieces are L2 hits 92 % of the time, profiles/r3_pmc_k_conv2h.json.)
 // The x32 -> x16 accumulator hazard of conv2r.hip does not arise: with two accumulator pairs every x16 MFMA's SrcC was written
 // at least four MFMAs earlier.
 #include <cstdio>
@@ -67,37 +66,11 @@ __device__ __forceinline__ void split2x2(float x0, float x1, unsigned& hi, unsig
 __device__ __forceinline__ void scale4(f32x4& o, const f32x4& v, float s) { o[0] = v[0] * s; o[1] = v[1] * s; o[2] = v[2] * s; o[3] = v[3] * s; }
 __device__ __forceinline__ void sum4(f32x4& o, const f32x4& a, const f32x4& b) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; o[3] = a[3] + b[3]; }
 
-// ---- ring staging (header comment): set P of the staging registers = A in v[244:247] / v[248:251], B in v[252:253] / v[254:255],
-// outside the compiler's allocation; loads, waits and LDS writes by hand
-template <int P> __device__ __forceinline__ void ch_fetchA(int voff, u32x4 rsrc, int soff) {
-  if (P == 0) asm volatile("buffer_load_dwordx4 v[244:247], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v244", "v245", "v246", "v247");
-  else asm volatile("buffer_load_dwordx4 v[248:251], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v248", "v249", "v250", "v251");
-}
-template <int P> __device__ __forceinline__ void ch_fetchB(int voff, u32x4 rsrc, int soff) {
-  if (P == 0) asm volatile("buffer_load_dwordx2 v[252:253], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v252", "v253");
-  else asm volatile("buffer_load_dwordx2 v[254:255], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory", "v254", "v255");
-}
-// `put`: the share fetched two tiles ago goes into the ring.  Ring loads are issued in the fixed order B(P) A(P) B(!P) A(!P) B(P) ...
-// (slots 1 and 13 of every tile), they return in order, and a write comes just before the fetch that re-arms its set: exactly
-// three younger ring loads may still be out (VMCNT = 3).  Anything else in the queue -- message stores at the end of a channel
-// group, the x rows of the second output half -- is younger still and only makes the wait longer; the unit's prologue ends with
-// vmcnt(0) (VMCNT = 0: no wait here).
-template <int P, int VMCNT> __device__ __forceinline__ void ch_putA(unsigned lds_addr) {
-  if (VMCNT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if (P == 0) asm volatile("ds_write_b128 %0, v[244:247]" ::"v"(lds_addr) : "memory", "v244", "v245", "v246", "v247");
-  else asm volatile("ds_write_b128 %0, v[248:251]" ::"v"(lds_addr) : "memory", "v248", "v249", "v250", "v251");
-}
-template <int P> __device__ __forceinline__ void ch_putB(unsigned lds_addr) {
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if (P == 0) asm volatile("ds_write_b64 %0, v[252:253]" ::"v"(lds_addr) : "memory", "v252", "v253");
-  else asm volatile("ds_write_b64 %0, v[254:255]" ::"v"(lds_addr) : "memory", "v254", "v255");
-}
-
 #define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
 #define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
 
-template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling (8: loads only, 16: LDS writes only), 64 unit prologue only
-__global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) void k_conv2h(Conv2Args a) {
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling (8: loads only, 16: LDS writes only), 64 unit prologue only; 256 (right results): ring writes right behind the barriers (slots 0 / 12 instead of 9 / 21)
+__global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
   constexpr int K = 144, KT = 9;
   constexpr int EPB = 32 * NW;                       // edges per block (unit)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -152,25 +125,22 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) v
     }
     // Filling the ring (header comment).  Share A = one of the six 1-KiB pieces (piece i, k-step s < 3) or the bias values; share B =
     // one of the six 512-byte halves of k-step 3's two pieces and of the two last-16-k pieces.  Same layout in memory and in LDS.
-    const unsigned long long w2h = (unsigned long long)d.w.W2h;
-    const u32x4 rW = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w2h), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(w2h >> 32) & 0xffffu)),
-                      (unsigned)__builtin_amdgcn_readfirstlane(d.w.n_tiles * CH_TILE_BYTES), 0x00020000u};
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.W2h, 0, d.w.n_tiles * CH_TILE_BYTES, 0x00020000);
     const int shA = wv & 7, shB = wv % 6;
     const int offA = shA < 6 ? ((shA / 3) * 4 + shA % 3) * 1024 : CH_BIAS_OFF;
     const int offB = shB < 4 ? ((shB >> 1) * 4 + 3) * 1024 + (shB & 1) * 512 : CH_TAIL_OFF + (shB - 4) * 512;
     const int vA = (shA < 6 || lane < 4) ? lane * 16 : 0x40000000;      // lanes 4..63 of the bias share: out of range, the load returns 0
-    const unsigned ring_lds = (unsigned)(size_t)ring;                 // LDS byte address of the ring (low half of the flat address)
-    const unsigned ldsA = ring_lds + offA + lane * 16, ldsB = ring_lds + offB + lane * 8;
-    // (plain functions, not lambdas: clang does not capture a variable that a generic lambda uses only as an asm operand)
-    auto fetchA = [&](auto pc, int tile) { if (!(ABL & (4 | 16))) ch_fetchA<decltype(pc)::value>(vA, rW, tile * CH_TILE_BYTES + offA); };
-    auto fetchB = [&](auto pc, int tile) { if (!(ABL & (4 | 16))) ch_fetchB<decltype(pc)::value>(lane * 8, rW, tile * CH_TILE_BYTES + offB); };
-    auto putA = [&](auto pc) { if (!(ABL & (4 | 8))) ch_putA<decltype(pc)::value, 3>(ldsA); };
-    auto putB = [&](auto pc) { if (!(ABL & (4 | 8))) ch_putB<decltype(pc)::value>(ldsB); };
+    char* ringw = const_cast<char*>(ring);
+    u32x4 stgA = {0u, 0u, 0u, 0u};                     // staging registers: a share is fetched right behind the write of its predecessor
+    u32x2 stgB = {0u, 0u};
+    auto fetchA = [&](int tile) { if (!(ABL & (4 | 16))) stgA = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, vA, tile * CH_TILE_BYTES + offA, 0)); };
+    auto fetchB = [&](int tile) { if (!(ABL & (4 | 16))) stgB = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rW, lane * 8, tile * CH_TILE_BYTES + offB, 0)); };
+    auto putA = [&] { if (!(ABL & (4 | 8))) *reinterpret_cast<u32x4*>(ringw + offA + vW) = stgA; };
+    auto putB = [&] { if (!(ABL & (4 | 8))) *reinterpret_cast<u32x2*>(ringw + offB + lane * 8) = stgB; };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    if (r_begin < r_end) {   // the part's first tiles travel while the hidden layer is computed: tile 0's A shares (through set 1), its B
-      fetchA(I1{}, t_first); fetchB(I0{}, t_first);                                    // shares, tile 1's A and B shares
-      fetchA(I0{}, min(t_first + 1, t_last)); fetchB(I1{}, min(t_first + 1, t_last));
+    if (r_begin < r_end) {   // the part's first tile travels while the hidden layer is computed
+      fetchA(t_first); fetchB(t_first);
     }
 
     // ---- my two edges (block b, column n), clamped; gather indices
@@ -376,13 +346,13 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) v
 #define SLOT(m) do { op(std::integral_constant<int, (m)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
     // one tile: 30 MFMAs = 5 k-steps x (hi_w lo_h, lo_w hi_h | hi_w hi_h) x 2 edge blocks; `op(m)` = what travels behind MFMA m.
     // e0 / e1 / e2: the k-step's memory operations, behind its MFMAs 0 / 1 / 2
-    // Tile t of the part (parity P = (t - t_first) & 1) writes the shares staged in set P -- its own B shares, the next tile's A shares --
-    // and re-arms the set with those of two tiles on.
-    auto tile = [&](auto pc, int t, auto&& op) {
+    // Tile t writes the staged shares -- its own B shares, the next tile's A shares -- late in their windows (k-steps 1 and 3: right
+    // behind a barrier all eight waves would write at once, in front of everybody's fragment reads: -3 %) and re-arms the registers.
+    auto tile = [&](int t, auto&& op) {
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       // k-step 0 (fragments FA): B shares of THIS tile into the ring, next tile's bias on its way, k-step 1's fragments requested
-      accS[0] = M32(accN[0], 0, 0, 1, FA, 0); putB(pc); SLOT(0);
-      accS[1] = M32(accN[1], 0, 1, 1, FA, 0); fetchB(pc, min(t + 2, t_last)); SLOT(1);
+      accS[0] = M32(accN[0], 0, 0, 1, FA, 0); if (ABL & 256) putB(); SLOT(0);
+      accS[1] = M32(accN[1], 0, 1, 1, FA, 0); if (ABL & 256) fetchB(min(t + 1, t_last)); SLOT(1);
       accS[0] = M32(accS[0], 1, 0, 0, FA, 0); rd_step(I1{}, FB); SLOT(2);
       accS[1] = M32(accS[1], 1, 1, 0, FA, 0); SLOT(3);
       accB[0] = M32(zero, 0, 0, 0, FA, 0); SLOT(4);
@@ -391,13 +361,13 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) v
       accS[0] = M32(accS[0], 0, 0, 1, FB, 1); SLOT(6);
       accS[1] = M32(accS[1], 0, 1, 1, FB, 1); SLOT(7);
       accS[0] = M32(accS[0], 1, 0, 0, FB, 1); rd_step(I2{}, FA); SLOT(8);
-      accS[1] = M32(accS[1], 1, 1, 0, FB, 1); SLOT(9);
-      accB[0] = M32(accB[0], 0, 0, 0, FB, 1); SLOT(10);
+      accS[1] = M32(accS[1], 1, 1, 0, FB, 1); if (!(ABL & 256)) putB(); SLOT(9);
+      accB[0] = M32(accB[0], 0, 0, 0, FB, 1); if (!(ABL & 256)) fetchB(min(t + 1, t_last)); SLOT(10);
       accB[1] = M32(accB[1], 0, 1, 0, FB, 1); SLOT(11);
       // k-step 2 (FA): everybody has read slots 0..2 -> the next tile's A shares go in
       ring_barrier();
-      accS[0] = M32(accS[0], 0, 0, 1, FA, 2); putA(pc); SLOT(12);
-      accS[1] = M32(accS[1], 0, 1, 1, FA, 2); fetchA(pc, min(t + 3, t_last)); SLOT(13);
+      accS[0] = M32(accS[0], 0, 0, 1, FA, 2); if (ABL & 256) putA(); SLOT(12);
+      accS[1] = M32(accS[1], 0, 1, 1, FA, 2); if (ABL & 256) fetchA(min(t + 2, t_last)); SLOT(13);
       accS[0] = M32(accS[0], 1, 0, 0, FA, 2); rd_step(I3{}, FB); SLOT(14);
       accS[1] = M32(accS[1], 1, 1, 0, FA, 2); SLOT(15);
       accB[0] = M32(accB[0], 0, 0, 0, FA, 2); SLOT(16);
@@ -409,8 +379,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) v
 #pragma unroll
       for (int i = 0; i < 2; ++i) FT[i] = *reinterpret_cast<const f16x4*>(ring + CH_TAIL_OFF + i * 512 + lane * 8);
       SLOT(20);
-      accS[1] = M32(accS[1], 1, 1, 0, FB, 3); SLOT(21);
-      accB[0] = M32(accB[0], 0, 0, 0, FB, 3); SLOT(22);
+      accS[1] = M32(accS[1], 1, 1, 0, FB, 3); if (!(ABL & 256)) putA(); SLOT(21);
+      accB[0] = M32(accB[0], 0, 0, 0, FB, 3); if (!(ABL & 256)) fetchA(min(t + 2, t_last)); SLOT(22);
       accB[1] = M32(accB[1], 0, 1, 0, FB, 3); SLOT(23);
       // k = 128..143 on v_mfma_f32_16x16x16_f16; the next tile's slots 0..2 are complete: its first k-step's fragments.
       // Block 0 finishes two MFMAs before the tile does, so its sum (slot 29) does not wait for the pipe.
@@ -426,11 +396,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) v
     };
 #undef SLOT
     int x_phase = 0;
-    int par = 0;                                       // parity of the next tile
-    if (r_begin < r_end) {                             // the part's first tile: A shares (+ bias) into the ring, its B shares wait in set 0
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // for the first k-step 0; the third tile's A shares set out
-      if (!(ABL & (4 | 8))) ch_putA<1, 0>(ldsA);
-      fetchA(I1{}, min(t_first + 2, t_last));
+    if (r_begin < r_end) {                             // the part's first tile: A shares (+ bias) into the ring, its B shares wait in their
+      putA();                                          // staging registers for the first k-step 1; the second tile's A shares set out
+      fetchA(min(t_first + 1, t_last));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       rd_step(I0{}, FA);
@@ -566,9 +534,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_num_vgpr(244))) v
         const float* xp = xs_lane + xo;
         accp[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accp[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < nt; ++i) {
-          if (par) tile(I1{}, tile0 + i, [&](auto mc) { travel(mc, xp); });
-          else tile(I0{}, tile0 + i, [&](auto mc) { travel(mc, xp); });
-          par ^= 1;
+          tile(tile0 + i, [&](auto mc) { travel(mc, xp); });
           if (i) xp += x_step;
         }
         // the run's last tile is contracted in the open (its successor belongs to another path type)
@@ -635,7 +601,7 @@ void launch_conv2h(const Conv2Args& a, hipStream_t st) {
   b.no_split = no_split;
 #define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                          hipLaunchKernelGGL((k_conv2h<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
-  V(1) V(2) V(3) V(4) V(7) V(8) V(16) V(64)
+  V(1) V(2) V(3) V(4) V(7) V(8) V(16) V(64) V(256)
 #undef V
   // (set on every launch: the attribute is per device, and a process may drive several)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

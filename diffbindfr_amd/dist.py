@@ -166,7 +166,7 @@ def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
 
 
 def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_max=10.0, gather=True, on_batch=None,
-                store="device", window_bytes=256 << 20, release=True):
+                store="device", window_bytes=256 << 20, release=True, tapes=None):
     """The multi-GPU product entry: a job list in, poses out in job order.
 
         jobs    list of ``assemble.ComplexRecord`` -- the (protein, ligand) pair table of the reference
@@ -181,6 +181,7 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
                 finishes and the gather is staged through a ``window_bytes`` device buffer -- HBM use is then bounded by one
                 batch + the window, whatever the size of the job table.
         release drop a record half's device copy (``_Half.release``) after the last batch of this rank that uses it.
+        tapes   {job index: (init tape, noise tape)} of recorded random numbers used instead of drawing (``draw_tapes``).
 
     Every rank holds the whole (cheap, host-side) job table, takes its LPT share, runs it in batches of <= ``batch_poses``
     poses through ``run_complexes``.  Every JOB draws from its own generator ``job_seed(seed, job)``; a job cut into several
@@ -215,7 +216,8 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
         recs = [jobs[j] for j, _, _ in batch]
         pb, lig, a14 = sampler.run_complexes(recs, [n for _, _, n in batch], device=dev, tr_sigma_max=tr_sigma_max,
                                              seeds=[sampler.job_seed(seed, j) for j, _, _ in batch],
-                                             pose_ranges=[(p0, reps[j]) for j, p0, _ in batch])
+                                             pose_ranges=[(p0, reps[j]) for j, p0, _ in batch],
+                                             **({} if tapes is None else {"tapes": [tapes.get(j) for j, _, _ in batch]}))
         lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
         g = 0
         for j, p0, n in batch:          # the n poses of a job are consecutive, equal-sized graphs: two strided copies per job

@@ -134,11 +134,14 @@ class DiffBindFRHIP(nn.Module):
         x ^= x >> 31
         return x & (2 ** 63 - 1)
 
-    def draw_tapes(self, records, poses, seeds, dev, tr_sigma_max=10.0, pose_ranges=None):
+    def draw_tapes(self, records, poses, seeds, dev, tr_sigma_max=10.0, pose_ranges=None, tapes=None):
         """Initialisation tape (``assemble.draw_init_tape_dims`` layout) and SDE noise tape of a complex-major batch, drawn
         complex by complex on the device from ``torch.Generator(seed_c)``.  ``pose_ranges[c] = (p0, P_total)``: the batch
         holds poses ``p0 .. p0 + poses[c]`` of a job of ``P_total`` poses -- the job's WHOLE tape is drawn and the rows of
-        these poses are cut out, so a job's poses do not depend on how the driver cut it into batches."""
+        these poses are cut out, so a job's poses do not depend on how the driver cut it into batches.
+        ``tapes[c] = (init, z)`` (or None): RECORDED tapes of job c used instead of drawing -- ``init`` as
+        ``assemble.draw_init_tape_dims(P_total, ...)`` returns it (tor [P n_tor], rot [P,3,3], tr [P,3], sc [P n_r,4]), ``z`` =
+        dict(tr [T,P,3], rot [T,P,3], tor [T,P n_tor], sc [T,P n_sc]); replays a run (tests: the reference's own trajectories)."""
         from . import assemble
         recs_, _ = self.schedule()
         T = len(recs_)
@@ -149,16 +152,23 @@ class DiffBindFRHIP(nn.Module):
         for c, (r, P, s) in enumerate(zip(records, reps, seeds)):
             p0, Pt = (0, P) if pose_ranges is None else pose_ranges[c]
             assert 0 <= p0 and p0 + P <= Pt
-            gen.manual_seed(int(s))
-            t = assemble.draw_init_tape_dims(Pt, Pt * r.n_tor, Pt * r.n_r, dev, tr_sigma_max, gen)
+            if tapes is not None and tapes[c] is not None:
+                f = lambda x, *shape: torch.as_tensor(x).to(device=dev, dtype=torch.float32).reshape(*shape)
+                t = {k: f(tapes[c][0][k], *shp) for k, shp in (("tor", (Pt * r.n_tor,)), ("rot", (Pt, 3, 3)), ("tr", (Pt, 3)), ("sc", (Pt * r.n_r, 4)))}
+                zz = {k: f(tapes[c][1][k], T, *shp) for k, shp in (("tr", (Pt, 3)), ("rot", (Pt, 3)), ("tor", (Pt * r.n_tor,)), ("sc", (Pt * r.n_sc,)))}
+            else:
+                gen.manual_seed(int(s))
+                t = assemble.draw_init_tape_dims(Pt, Pt * r.n_tor, Pt * r.n_r, dev, tr_sigma_max, gen)
+                zz = dict(tr=torch.randn(T, Pt, 3, device=dev, generator=gen), rot=torch.randn(T, Pt, 3, device=dev, generator=gen),
+                          tor=torch.randn(T, Pt * r.n_tor, device=dev, generator=gen), sc=torch.randn(T, Pt * r.n_sc, device=dev, generator=gen))
             init["tor"].append(t["tor"][p0 * r.n_tor:(p0 + P) * r.n_tor])
             init["rot"].append(t["rot"][p0:p0 + P])
             init["tr"].append(t["tr"][p0:p0 + P])
             init["sc"].append(t["sc"][p0 * r.n_r:(p0 + P) * r.n_r])
-            z["tr"].append(torch.randn(T, Pt, 3, device=dev, generator=gen)[:, p0:p0 + P])
-            z["rot"].append(torch.randn(T, Pt, 3, device=dev, generator=gen)[:, p0:p0 + P])
-            z["tor"].append(torch.randn(T, Pt * r.n_tor, device=dev, generator=gen)[:, p0 * r.n_tor:(p0 + P) * r.n_tor])
-            z["sc"].append(torch.randn(T, Pt * r.n_sc, device=dev, generator=gen)[:, p0 * r.n_sc:(p0 + P) * r.n_sc])
+            z["tr"].append(zz["tr"][:, p0:p0 + P])
+            z["rot"].append(zz["rot"][:, p0:p0 + P])
+            z["tor"].append(zz["tor"][:, p0 * r.n_tor:(p0 + P) * r.n_tor])
+            z["sc"].append(zz["sc"][:, p0 * r.n_sc:(p0 + P) * r.n_sc])
         init = {k: torch.cat(v, 0) for k, v in init.items()}
         z = {k: torch.cat(v, 1) for k, v in z.items()}
         for k in ("tor", "sc"):
@@ -188,10 +198,10 @@ class DiffBindFRHIP(nn.Module):
 
     @torch.no_grad()
     def run_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0, job_ids=None,
-                      seeds=None, pose_ranges=None):
+                      seeds=None, pose_ranges=None, tapes=None):
         """``sample_complexes`` without the per-graph split: (packed batch, lig [T,NL,3], atom14 [T,NR,14,3]) on the device;
         graphs are complex-major, so the poses of complex c are rows ``pb.lig_ptr_host[g0] .. [g0 + poses_c]``.
-        ``pose_ranges``: see ``draw_tapes`` (a job cut into several batches by ``dist.run_sharded``)."""
+        ``pose_ranges`` / ``tapes``: see ``draw_tapes`` (a job cut into several batches by ``dist.run_sharded``; recorded tapes)."""
         from . import assemble
         dev = torch.device(device)
         recs = [r if isinstance(r, assemble.ComplexRecord) else assemble.ComplexRecord(r) for r in records]
@@ -202,7 +212,7 @@ class DiffBindFRHIP(nn.Module):
             seeds = [self.job_seed(seed, j) for j in job_ids]
         with torch.cuda.device(dev):
             pb = assemble.assemble(recs, poses, dev)
-            init, z = self.draw_tapes(recs, poses, seeds, dev, tr_sigma_max, pose_ranges)
+            init, z = self.draw_tapes(recs, poses, seeds, dev, tr_sigma_max, pose_ranges, tapes)
             assemble.init_poses(self.diffusion_model, pb, init)
             lig, a14 = self.sample_packed(pb, z, visualize=visualize)
         return pb, lig, a14

@@ -630,6 +630,191 @@ def golden_real_trajectory():
     print("  real_3dbs_traj.npz:", os.path.getsize(os.path.join(HERE, "real_3dbs_traj.npz")) // 1024, "KiB")
 
 
+# --------------------------------------------------------------------------- 8b. the reference's own multi-complex examples
+def _protein_superset(pdb, ref_xyz, pocket_cut=12.0, keep_cut=16.0):
+    """One example receptor: (seq, atom14 pos, atom14 mask) of its 12 A pocket exactly as golden_real_complex selects it (any heavy atom
+    within 12 A of any heavy atom of the pocket-defining ligand), and the atom37 arrays of every residue within `keep_cut` A -- the
+    input the PRODUCT's own selection (pocket.pockets_from_proteins) starts from, a superset of the pocket."""
+    pc = ns.pc
+    seq, pos, msk, aa37, p37, m37 = [], [], [], [], [], []
+    for key, rn, atoms in _parse_pdb_residues(pdb):
+        if rn not in pc.restype_3to1:
+            continue
+        P = np.array(list(atoms.values()))
+        dmin = np.linalg.norm(P[:, None] - ref_xyz[None], axis=-1).min()
+        if dmin >= keep_cut:
+            continue
+        aa = pc.restype_order[pc.restype_3to1[rn]]
+        row, mrow = np.zeros((37, 3), np.float32), np.zeros(37, bool)
+        for nm, xyz in atoms.items():
+            if nm in pc.atom_order:
+                row[pc.atom_order[nm]] = xyz
+                mrow[pc.atom_order[nm]] = True
+        aa37.append(aa); p37.append(row); m37.append(mrow)
+        if dmin >= pocket_cut:
+            continue
+        names = pc.restype_name_to_atom14_names[rn]
+        seq.append(aa)
+        pos.append([atoms.get(nm, [0.0, 0.0, 0.0]) if nm else [0.0, 0.0, 0.0] for nm in names])
+        msk.append([bool(nm) and nm in atoms for nm in names])
+    return (np.asarray(seq), np.asarray(pos, np.float64), np.asarray(msk)), (np.asarray(aa37), np.asarray(p37), np.asarray(m37))
+
+
+def _ref_pocket_half(seq, pos, msk, pp, du):
+    """Pocket half of a per-complex record through the reference's own functions (as golden_real_trajectory): templates, chi
+    masks / edges, PocketFeaturizer, Decentration.  Returns (record dict, pocket centre)."""
+    N = len(seq)
+    ideal = T["atom14_mask"][seq][..., None].astype(np.float32)
+    tpl = ns.prot_math.extract_chi_and_template(seq, pos.copy(), ideal, return_radian=True)
+    seq_t, msk_t = torch.from_numpy(seq), torch.from_numpy(msk)
+    te, cm = du.build_torsion_edges(seq_t, msk_t)
+    fake = types.SimpleNamespace(num_res=lambda: N, atom_mask=np.zeros((N, 37)), residue_prop={})
+    feat = pp.PocketFeaturizer()(dict(atom14_mask=msk_t, sequence=seq_t, pocket=fake))["pocket_node_feature"]
+    data = dict(atom14_position=torch.from_numpy(pos).float(), atom14_mask=msk_t, sequence=seq_t,
+                backbone_transl=torch.from_numpy(npy(tpl["backbone_transl"])).float(), lig_pos=torch.zeros(1, 3))
+    data = pp.Decentration()(data)
+    return dict(sequence=seq_t, atom14_mask=msk_t, backbone_transl=data["backbone_transl"],
+                backbone_rots=torch.from_numpy(npy(tpl["backbone_rots"])).float(),
+                default_frame=torch.from_numpy(npy(tpl["default_frame"])).float(),
+                rigid_group_positions=torch.from_numpy(npy(tpl["rigid_group_positions"])).float(),
+                torsion_angle=torch.from_numpy(npy(tpl["torsion_angle"])).float(),
+                torsion_edge_index=te[..., 1, :], sc_torsion_edge_mask=cm, pocket_node_feature=feat)
+
+
+def _ligand_half_from_sdf(path, du, seed):
+    """Real geometry / bond graph / torsions (the reference's find_torsion) of one example ligand; seeded synthetic node and
+    bond features (the RDKit featuriser is outside this path, as in tests/test_real_complex.py)."""
+    xyz, bonds = _parse_sdf_heavy(path)
+    n_l = xyz.shape[0]
+    directed = sorted([(a, b) for a, b in bonds] + [(b, a) for a, b in bonds], key=lambda e: e[0] * n_l + e[1])
+    ei = np.asarray(directed, np.int64).T
+    fake = types.SimpleNamespace(bond_prop=dict(bond_label=np.zeros(ei.shape[1], int)), edge_index=ei, numatoms=n_l, atomtype=np.zeros(n_l, int))
+    tor, rot = du.find_torsion(fake)
+    rng = np.random.default_rng(seed)
+    node = np.clip(rng.standard_normal((n_l, 27)), -3, 3).astype(np.float32)
+    und, feat = {}, np.zeros((ei.shape[1], 10), np.float32)
+    for k, (u, v) in enumerate(ei.T.tolist()):
+        key = (min(u, v), max(u, v))
+        if key not in und:
+            und[key] = (int(rng.integers(0, 4)), rng.integers(0, 2, 4))
+        feat[k, und[key][0]] = 1.0
+        feat[k, 6:] = und[key][1]
+    return dict(lig_node=torch.from_numpy(node), lig_pos=torch.from_numpy(xyz).float(), lig_edge_index=torch.from_numpy(ei),
+                lig_edge_feat=torch.from_numpy(feat), tor_edge_mask=torch.from_numpy(np.asarray(tor)).long(),
+                rot_node_mask=torch.from_numpy(np.asarray(rot)))
+
+
+def _reference_trajectories(recs, seed, what):
+    """One pose per record (seeded init tape through the pinned LigInit / SCProtInit restatement), all poses in ONE batch through the
+    reference's own DiffBindFR.sample() for 20 steps; the oracle must reproduce it.  Returns (tapes, noise, traj_lig, final_atom14, ptrs)."""
+    import time
+    from oracle import pose_init as opi
+    Tt = {k: (torch.from_numpy(np.asarray(v)) if k == "atom14_to_group" else v) for k, v in T.items()}
+    rng = np.random.default_rng(seed)
+    poses, tapes = [], []
+    for rec in recs:
+        fixed = opi.sc_fixer(copy.deepcopy(rec), T)
+        n_tor, N = int(rec["tor_edge_mask"].sum()), int(rec["sequence"].shape[0])
+        tape = dict(tor=rng.uniform(-np.pi, np.pi, n_tor), rot=synthetic._rand_rot(rng),
+                    tr=torch.from_numpy(rng.normal(0, 3.0, (1, 3))).float(), sc=rng.uniform(-np.pi, np.pi, (N, 4)))
+        tapes.append(tape)
+        poses.append(opi.init_pose(fixed, tape, Tt))
+    d = types.SimpleNamespace(**opi.collate(poses))
+    d.batch = d.lig_node_batch
+    G = len(recs)
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=1)
+    model = ns.tpscore.TensorProductModel(ref_model_cfg()).eval()
+    model.load_state_dict(params, strict=True)
+    scfg = schedule.default_sample_cfg()
+    go = sys.modules["druglib.utils.geometry_utils"]
+    go.so3 = types.SimpleNamespace(score_norm=schedule.so3_score_norm)
+    go.torus = types.SimpleNamespace(score_norm=lambda s: schedule.torus_score_norm(s, 0))
+    ref_sampler = ns.scflex.DiffBindFR(diffusion_model=None, test_cfg=ED(sample_cfg=ED(vars(scfg))))
+    ref_sampler.diffusion_model_cfg = ED(no_sc_torsion=False)
+    ref_sampler.diffusion_model = model
+    rd = ED({k: (v.clone() if torch.is_tensor(v) else v) for k, v in vars(d).items() if k != "rot_node_mask"})
+    rd.metastore = {"rot_node_mask": [m.clone() for m in d.rot_node_mask]}
+    torch.manual_seed(seed)
+    t0 = time.time()
+    res = ref_sampler.sample(rd, visualize=True)
+    print(f"  reference sample(): {G} poses x {scfg.actual_steps} steps ({what}) in {time.time() - t0:.0f}s")
+    lig_ref = torch.cat([r[0] for r in res], dim=1)
+    a14_ref = torch.cat([r[1] for r in res], dim=1)
+    n_tor_tot, n_sc = int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum())
+    noise = sampler.draw_noise(scfg.actual_steps, G, n_tor_tot, n_sc, seed=seed)
+    lig_o, a14_o = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise, torch.from_numpy(T["atom14_to_group"]).long(),
+                                  torus_seed=0, visualize=True)
+    close(lig_o, lig_ref, 1e-4, f"{what} sample(): ligand trajectories (20 steps)")
+    close(a14_o, a14_ref, 1e-4, f"{what} sample(): atom14 trajectories (20 steps)")
+    return tapes, noise, lig_ref, a14_ref[-1], params
+
+
+def golden_examples():
+    """The reference's own multi-complex examples (README.md:86-127) as fixtures: examples/forward = the 3DBS receptor with all 15
+    SDF ligands (BASELINE config 3 in miniature: one shared pocket), examples/reverse = 2 ligands x 3 receptors (config 4: shared
+    ligands), one pose each, all 20 steps through the reference's own sample().  The fixtures hold the RAW inputs of the product
+    path (protein atom37 arrays around the site, the pocket-defining crystal ligand, ligand graphs), the tapes and the reference
+    trajectories: tests/golden/real_forward15_traj.npz, real_reverse_traj.npz."""
+    print("[examples/forward and examples/reverse: 20-step reference trajectories]")
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    if "druglib.datasets.builder" not in sys.modules or not hasattr(sys.modules["druglib.datasets.builder"], "PIPELINES"):
+        dsb = types.ModuleType("druglib.datasets.builder")
+        dsb.PIPELINES = ns.builder.INTERACTION.__class__("pipeline")
+        sys.modules["druglib.datasets.builder"] = dsb
+    obj = sys.modules["druglib.utils.obj"]
+    obj.Ligand3D = object
+    obj.make_torsion_mask = ns.prot_math.make_torsion_mask
+    du = ref_shims._load("druglib.datasets.Docking.utils", "datasets/Docking/utils.py")
+    pp = ref_shims._load("druglib.datasets.Docking.pocket_pipeline", "datasets/Docking/pocket_pipeline.py")
+    ex = os.path.join(ref_shims.REF, "examples")
+
+    def save(name, prots, ligs, pairs, tapes, noise, lig_traj, a14_final, params):
+        out = dict(n_prot=np.asarray(len(prots)), n_lig=np.asarray(len(ligs)), pairs=np.asarray(pairs, np.int64),
+                   params_seed=np.asarray(1), params_sha256=np.asarray(params_digest(params)),
+                   noise_tr=npy(noise.tr), noise_rot=npy(noise.rot), noise_tor=npy(noise.tor), noise_sc=npy(noise.sc),
+                   traj_lig=npy(lig_traj).astype(np.float32), final_atom14=npy(a14_final).astype(np.float32))
+        for i, (nm, cry, sup) in enumerate(prots):
+            out.update({f"prot{i}_name": np.asarray(nm), f"prot{i}_ref_lig_pos": cry.astype(np.float32), f"prot{i}_aatype": sup[0],
+                        f"prot{i}_atom37_pos": sup[1].astype(np.float32), f"prot{i}_atom37_mask": sup[2]})
+        for i, (nm, lg) in enumerate(ligs):
+            out[f"lig{i}_name"] = np.asarray(nm)
+            out.update({f"lig{i}_{k}": npy(v) for k, v in lg.items()})
+        for g, t in enumerate(tapes):
+            out.update({f"tape{g}_tor": np.asarray(t["tor"]), f"tape{g}_rot": np.asarray(t["rot"]), f"tape{g}_tr": npy(t["tr"]),
+                        f"tape{g}_sc": np.asarray(t["sc"])})
+        path = os.path.join(HERE, name)
+        np.savez_compressed(path, **out)
+        print(f"  {name}: {os.path.getsize(path) // 1024} KiB, {len(pairs)} pairs")
+
+    # ---- forward: one receptor, 15 ligands
+    cry, _ = _parse_sdf_heavy(os.path.join(ex, "forward", "3dbs_protein_crystal.sdf"))
+    (seq, pos, msk), sup = _protein_superset(os.path.join(ex, "forward", "3dbs_protein.pdb"), cry)
+    assert len(seq) == 105 and int(msk.sum()) == 866
+    pk = _ref_pocket_half(seq, pos, msk, pp, du)
+    files = sorted(os.listdir(os.path.join(ex, "forward", "mols")))
+    assert len(files) == 15
+    ligs = [(f[:-4], _ligand_half_from_sdf(os.path.join(ex, "forward", "mols", f), du, 100 + i)) for i, f in enumerate(files)]
+    recs = [dict(pk, **lg) for _, lg in ligs]
+    tapes, noise, lt, a14, params = _reference_trajectories(recs, 4321, "examples/forward (3DBS x 15 ligands)")
+    save("real_forward15_traj.npz", [("3dbs", cry, sup)], ligs, [(0, i) for i in range(15)], tapes, noise, lt, a14, params)
+
+    # ---- reverse: 2 ligands x 3 receptors (pairs ligand-major, as dataframe.py builds the table)
+    prots, pks = [], []
+    for nm in ("2src", "3mhw", "3pp0"):
+        c, _ = _parse_sdf_heavy(os.path.join(ex, "reverse", "receptors", f"{nm}_protein_crystal.sdf"))
+        (seq, pos, msk), sup = _protein_superset(os.path.join(ex, "reverse", "receptors", f"{nm}_protein.pdb"), c)
+        print(f"  {nm}: pocket {len(seq)} residues / {int(msk.sum())} atoms, superset {len(sup[0])} residues")
+        prots.append((nm, c, sup))
+        pks.append(_ref_pocket_half(seq, pos, msk, pp, du))
+    ligs = [(f"ligand_{i + 1}", _ligand_half_from_sdf(os.path.join(ex, "reverse", f"ligand_{i + 1}.sdf"), du, 200 + i)) for i in range(2)]
+    pairs = [(p, l) for l in range(2) for p in range(3)]
+    recs = [dict(pks[p], **ligs[l][1]) for p, l in pairs]
+    tapes, noise, lt, a14, params = _reference_trajectories(recs, 8765, "examples/reverse (2 ligands x 3 receptors)")
+    save("real_reverse_traj.npz", prots, ligs, pairs, tapes, noise, lt, a14, params)
+
+
+
 # --------------------------------------------------------------------------- 8. output side (SURVEY 8(f) row f3)
 def _parse_sdf_elements(path):
     L = open(path).read().split("\n")
@@ -1173,7 +1358,10 @@ def golden_boundary():
 
 
 if __name__ == "__main__":
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    if sys.argv[1:] == ["examples"]:          # the two example fixtures alone (15 + 6 poses through the reference's sample(): minutes)
+        golden_examples()
+        sys.exit(0)
     golden_geometry()
     golden_embeddings()
     golden_schedule()
@@ -1182,6 +1370,7 @@ if __name__ == "__main__":
     golden_pocket()
     golden_real_complex()
     golden_real_trajectory()
+    golden_examples()
     golden_export()
     golden_pocket_select()
     golden_chi_differ()

@@ -1,8 +1,7 @@
 mkdir -p gpurun_out/r3
 cd $GRAFT_REPO_ROOT
-SKIP_B=1 timeout 200 tools/exp/split_f16 > gpurun_out/r3/split_f16_v2.txt 2>&1
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/r3/test_full_1.txt
-cat gpurun_out/r3/test_full_1.txt
-timeout 900 python bench.py > gpurun_out/r3/bench_default_1.json 2> gpurun_out/r3/bench_default_1.err
-tail -c 3000 gpurun_out/r3/bench_default_1.json
-tail -5 gpurun_out/r3/bench_default_1.err
+for rep in 1 2; do for abl in 0 256; do DBFR_CONV2H_ABL=$abl DBFR_GEMM=split_f16 DBFR_CONV2=1 timeout 120 python tools/conv_bench.py --layer 3 --fam 2 --edges 650000 --reps 10 2>&1 | tail -1 | sed "s/^/abl $abl: /"; done; done > gpurun_out/r3/conv_bench_7.txt 2>&1
+DBFR_GEMM=split_f16 DBFR_CONV2=1 timeout 120 python tools/conv_bench.py --layer 0 --fam 2 --edges 650000 --reps 10 2>&1 | tail -1 >> gpurun_out/r3/conv_bench_7.txt
+cat gpurun_out/r3/conv_bench_7.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "split or gemm or fixture or fused" 2>&1 | tail -5 > gpurun_out/r3/test_8.txt
+cat gpurun_out/r3/test_8.txt

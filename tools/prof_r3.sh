@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-3 measurement artefacts in one GPU-box call (copied by hand into profiles/ afterwards):
+#   rocprofv3 kernel stats of the default command, PMC passes (counters only, one pass per group) for the conv kernel k_conv2h,
+#   cfg 5 at its stated size (64 jobs x 40 poses): bench line, kernel stats, PMC passes.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r3prof
+mkdir -p $OUT
+WHAT=${1:-all}
+pmc() {   # pmc <tag> <bench args...>
+  local tag=$1; shift
+  local i=0
+  for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+             "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" \
+             "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS" \
+             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"; do
+    i=$((i+1))
+    timeout 400 rocprofv3 --pmc $grp --output-format csv -d $OUT/${tag}_p$i -o p -- python $R/bench.py "$@" > $OUT/${tag}_p$i.log 2>&1 || echo "$tag pass $i failed"
+  done
+  python $R/tools/pmc_summary.py "$OUT/${tag}_p*/*counter_collection.csv" | head -120 > $OUT/${tag}_pmc_summary.txt
+  python $R/tools/pmc_to_json.py $OUT/${tag}_pmc_summary.txt k_conv2h $OUT/${tag}_pmc_k_conv2h.json
+  rm -rf $OUT/${tag}_p[0-9]
+}
+stats() {  # stats <tag> <bench args...>
+  local tag=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_stats -o s -- python $R/bench.py "$@" > $OUT/${tag}_stats.log 2>&1
+  cp $OUT/${tag}_stats/*kernel_stats.csv $OUT/${tag}_kernel_stats.csv 2>/dev/null
+  rm -rf $OUT/${tag}_stats
+  head -8 $OUT/${tag}_kernel_stats.csv
+}
+Q="--no-cpu-baseline --no-latency --no-native"
+if [ $WHAT = all ] || [ $WHAT = cfg2 ]; then
+  stats cfg2 --steps 2 --warmup 1 $Q
+  pmc cfg2 --steps 1 --warmup 0 --batch-poses 640 --no-profile $Q
+fi
+if [ $WHAT = all ] || [ $WHAT = cfg5 ]; then
+  cd $R; timeout 900 python bench.py --config 5 --steps 4 --warmup 1 --batch-poses 640 --no-latency --no-native --cpu-batched-steps 0 > $OUT/bench_cfg5_64x40.json 2> $OUT/bench_cfg5_64x40.err; cd /tmp
+  tail -c 600 $OUT/bench_cfg5_64x40.err
+  stats cfg5 --config 5 --steps 1 --warmup 1 --batch-poses 640 $Q
+  pmc cfg5 --config 5 --steps 1 --warmup 0 --batch-poses 640 --no-profile $Q
+fi
+ls $OUT
