@@ -69,7 +69,7 @@ __device__ __forceinline__ void sum4(f32x4& o, const f32x4& a, const f32x4& b) {
 #define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
 #define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
 
-template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling (8: loads only, 16: LDS writes only), 64 unit prologue only; 256 (right results): ring writes right behind the barriers (slots 0 / 12 instead of 9 / 21)
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling (8: loads only, 16: LDS writes only), 32 no per-tile fetch (the unit's first shares are written again and again: real data, no loads), 512 every fetch from tiles 0..7 (always L2 hits), 64 unit prologue only; 256 (right results): ring writes right behind the barriers (slots 0 / 12 instead of 9 / 21)
 __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
   constexpr int K = 144, KT = 9;
   constexpr int EPB = 32 * NW;                       // edges per block (unit)
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
     char* ringw = const_cast<char*>(ring);
     u32x4 stgA = {0u, 0u, 0u, 0u};                     // staging registers: a share is fetched right behind the write of its predecessor
     u32x2 stgB = {0u, 0u};
-    auto fetchA = [&](int tile) { if (!(ABL & (4 | 16))) stgA = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, vA, tile * CH_TILE_BYTES + offA, 0)); };
-    auto fetchB = [&](int tile) { if (!(ABL & (4 | 16))) stgB = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rW, lane * 8, tile * CH_TILE_BYTES + offB, 0)); };
+    auto fetchA = [&](int tile) { if (!(ABL & (4 | 16))) stgA = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, vA, ((ABL & 512) ? (tile & 7) : tile) * CH_TILE_BYTES + offA, 0)); };
+    auto fetchB = [&](int tile) { if (!(ABL & (4 | 16))) stgB = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rW, lane * 8, ((ABL & 512) ? (tile & 7) : tile) * CH_TILE_BYTES + offB, 0)); };
     auto putA = [&] { if (!(ABL & (4 | 8))) *reinterpret_cast<u32x4*>(ringw + offA + vW) = stgA; };
     auto putB = [&] { if (!(ABL & (4 | 8))) *reinterpret_cast<u32x2*>(ringw + offB + lane * 8) = stgB; };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       accS[1] = M32(accS[1], 0, 1, 1, FB, 1); SLOT(7);
       accS[0] = M32(accS[0], 1, 0, 0, FB, 1); rd_step(I2{}, FA); SLOT(8);
       accS[1] = M32(accS[1], 1, 1, 0, FB, 1); if (!(ABL & 256)) putB(); SLOT(9);
-      accB[0] = M32(accB[0], 0, 0, 0, FB, 1); if (!(ABL & 256)) fetchB(min(t + 1, t_last)); SLOT(10);
+      accB[0] = M32(accB[0], 0, 0, 0, FB, 1); if (!(ABL & (256 | 32))) fetchB(min(t + 1, t_last)); SLOT(10);
       accB[1] = M32(accB[1], 0, 1, 0, FB, 1); SLOT(11);
       // k-step 2 (FA): everybody has read slots 0..2 -> the next tile's A shares go in
       ring_barrier();
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       for (int i = 0; i < 2; ++i) FT[i] = *reinterpret_cast<const f16x4*>(ring + CH_TAIL_OFF + i * 512 + lane * 8);
       SLOT(20);
       accS[1] = M32(accS[1], 1, 1, 0, FB, 3); if (!(ABL & 256)) putA(); SLOT(21);
-      accB[0] = M32(accB[0], 0, 0, 0, FB, 3); if (!(ABL & 256)) fetchA(min(t + 2, t_last)); SLOT(22);
+      accB[0] = M32(accB[0], 0, 0, 0, FB, 3); if (!(ABL & (256 | 32))) fetchA(min(t + 2, t_last)); SLOT(22);
       accB[1] = M32(accB[1], 0, 1, 0, FB, 3); SLOT(23);
       // k = 128..143 on v_mfma_f32_16x16x16_f16; the next tile's slots 0..2 are complete: its first k-step's fragments.
       // Block 0 finishes two MFMAs before the tile does, so its sum (slot 29) does not wait for the pipe.
@@ -601,7 +601,7 @@ void launch_conv2h(const Conv2Args& a, hipStream_t st) {
   b.no_split = no_split;
 #define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                          hipLaunchKernelGGL((k_conv2h<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
-  V(1) V(2) V(3) V(4) V(7) V(8) V(16) V(64) V(256)
+  V(1) V(2) V(3) V(4) V(7) V(8) V(16) V(32) V(64) V(256) V(512)
 #undef V
   // (set on every launch: the attribute is per device, and a process may drive several)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -358,11 +358,11 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
   A.lds_nl = (A.b.max_nl + 63) & ~63;
   A.lds_na = (A.b.max_na + 63) & ~63;
   const size_t lds = lds_bytes(A.lds_nl, A.lds_na);
-  static size_t granted = 64 * 1024;   // above the default 64 KB a kernel has to be told once
-  if (lds > granted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    granted = 160 * 1024 - 64;
+  if (lds > 64 * 1024) {   // above the default 64 KB a kernel has to be told -- per DEVICE, and a process may drive several: no
+    // "done once" flag; the call is cheap next to a launch that stages a > 4 k-atom pocket
+    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e0 != hipSuccess || e1 != hipSuccess) dbfr_set_error(std::string("k_edges: hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
   }
   A.n_chunk = (A.b.max_na + 255) / 256;      // must match plan() in api.cpp (g_cnt / g_base hold G * n_chunk entries)
   hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);

@@ -127,8 +127,12 @@ class SdfTemplate:
 
     ``from_molblock`` takes the ligand's input SD record and, like the reference's loader (RDKit ``RemoveHs``: the model
     ligand holds heavy atoms only), drops explicit hydrogens: atoms renumbered, bonds to hydrogens removed, the atom lists
-    of ``M  CHG`` / ``M  ISO`` / ``M  RAD`` lines remapped.  Atom order = the order the sampler's poses use (heavy atoms in
-    file order).  Byte parity with RDKit's ``SDWriter`` is not pinned offline (RDKit absent)."""
+    of ``M  CHG`` / ``M  ISO`` / ``M  RAD`` lines remapped.  Only the FIRST record of a multi-record SD file is used (everything
+    behind its ``$$$$`` is dropped); property lines that carry atom numbers in other layouts -- ``A  nnn`` / ``V  nnn`` (and the
+    text line that follows an alias), ``G  `` , ``M  ALS`` / ``M  RGP`` / ``M  SAL`` / ``M  SBL`` / ``M  SPA`` / ``M  APO`` /
+    ``M  AAL`` ... -- are dropped when hydrogens were removed (their numbers would be stale) and kept verbatim otherwise; data
+    items (``> <tag>`` blocks) are kept.  Atom order = the order the sampler's poses use (heavy atoms in file order).  Byte
+    parity with RDKit's ``SDWriter`` is not pinned offline (RDKit absent)."""
 
     def __init__(self, header, atom_tails, trailer):
         self.header, self.atom_tails, self.trailer = header, list(atom_tails), trailer
@@ -142,6 +146,8 @@ class SdfTemplate:
         na, nb = int(lines[3][0:3]), int(lines[3][3:6])
         atoms, bonds = lines[4:4 + na], lines[4 + na:4 + na + nb]
         rest = lines[4 + na + nb:]
+        if "$$$$" in rest:                                                      # first record only
+            rest = rest[:rest.index("$$$$") + 1]
         sym = [a[31:34].strip() for a in atoms]
         keep = [i for i in range(na) if not (remove_hs and sym[i] == "H")]
         ren = {old: new + 1 for new, old in enumerate(keep)}                    # 0-based old -> 1-based new
@@ -150,14 +156,24 @@ class SdfTemplate:
             i, j = int(b[0:3]) - 1, int(b[3:6]) - 1
             if i in ren and j in ren:
                 out_bonds.append(f"{ren[i]:3d}{ren[j]:3d}{b[6:]}")
-        props = []
+        renumbered = len(keep) != na
+        props, skip_next, in_data = [], False, False
         for l in rest:
-            if l[:6] in ("M  CHG", "M  ISO", "M  RAD"):
+            if skip_next:                                                       # the text line of a dropped `A  nnn` alias
+                skip_next = False
+                continue
+            if l.startswith(">"):
+                in_data = True
+            if in_data:
+                props.append(l)
+            elif l[:6] in ("M  CHG", "M  ISO", "M  RAD"):
                 n = int(l[6:9])
                 ent = [(int(l[9 + 8 * k:13 + 8 * k]) - 1, l[13 + 8 * k:17 + 8 * k]) for k in range(n)]
                 ent = [(ren[a], v) for a, v in ent if a in ren]
                 if ent:
                     props.append(f"{l[:6]}{len(ent):3d}" + "".join(f"{a:4d}{v}" for a, v in ent))
+            elif renumbered and (l[:3] in ("A  ", "V  ", "G  ") or (l[:3] == "M  " and l[:6] != "M  END")):
+                skip_next = l[:3] == "A  "                                      # atom-indexed in a layout not remapped here: stale -> dropped
             else:
                 props.append(l)
         while props and props[-1] == "":

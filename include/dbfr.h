@@ -385,7 +385,7 @@ int dbfr_mdn_pocket_features(int32_t n_graph, int32_t n_res, const int32_t* res_
 /* Synchronises the stream and returns the device-side status word of the last
  * dbfr_score / dbfr_sample issued with this workspace (DBFR_OK, DBFR_ERR_CAPACITY,
  * DBFR_ERR_NUMERIC).  counters (may be NULL) receives [8] int64: edges of the last
- * step in the order {lig, atom, cross, center, tor, sc_tor, 0, 0}.                */
+ * step in the order {lig, atom, cross lig<-atom, center, tor, sc_tor, cross atom<-lig, 0}. */
 int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 
 /* Which matrix instruction carries the 144 x W GEMM of the radial MLP (97-99 % of the arithmetic) in the K=144 convs.

@@ -447,6 +447,25 @@ def test_sdf_template_writes_heavy_atom_poses(tmp_path):
     assert keep_h.n_atoms == 10 and "M  CHG  2   1   1   6  -1" in keep_h.trailer
 
 
+def test_sdf_template_first_record_only_and_stale_atom_lines_dropped():
+    """a multi-record SD file must not leak its later molecules into every pose's lig_final.sdf, and property lines that
+    carry atom numbers in layouts the renumbering does not rewrite (`A  nnn` aliases + their text line, `V  nnn`, `M  RGP` ...) must
+    not survive with stale numbers once hydrogens were dropped (kept verbatim when nothing was renumbered)."""
+    lines = _MOLBLOCK.split("\n")
+    end = lines.index("M  END")
+    extra = ["A    4", "carboxyl O", "V    9 a hydrogen value", "M  RGP  1   2   1"]
+    two = "\n".join(lines[:end] + extra + lines[end:]) + "\nsecond molecule\n  x\n\n  1  0  0  0  0  0  0  0  0  0999 V2000\n" \
+        "    0.0000    0.0000    0.0000 C   0  0\nM  END\n$$$$\n"
+    t = ligand.SdfTemplate.from_molblock(two)
+    assert t.n_atoms == 5
+    tr = t.trailer.split("\n")
+    assert not any(l.startswith(("A  ", "V  ", "M  RGP")) or l == "carboxyl O" for l in tr)
+    assert "second molecule" not in t.trailer and t.trailer.count("$$$$") == 1 and t.trailer.endswith("$$$$\n")
+    assert "M  CHG  2   1   1   5  -1" in tr and ">  <ID>" in tr           # remapped charges and the data item survive
+    keep = ligand.SdfTemplate.from_molblock(two, remove_hs=False)            # nothing renumbered: the lines stay as they are
+    assert all(x in keep.trailer.split("\n") for x in extra) and "second molecule" not in keep.trailer
+
+
 def test_chi_differ_matches_the_reference_fixture():
     """tests/golden/chi_differ.npz: what the reference's own `chi_differ` (metrics/angbin.py:48-103) returned for the 3DBS
     poses of export.npz, its `atom37_to_torsion_angles` being the openfold copy the reference vendors

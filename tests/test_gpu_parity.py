@@ -565,3 +565,32 @@ def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, 
     # the two-piece fp16 form (k_conv2h): separate accumulators for the small and the large products => closer to float64 than the
     # fp32 instruction both in the largest and in the rms deviation (tools/exp/split_f16.hip: 0.6 x on the bare GEMM)
     assert err["split_f16"] <= err["f32"] and rms["split_f16"] <= rms["f32"], (err, rms)
+
+
+def test_cfg5_shape_trajectory_matches_the_oracle_fixture(dev):
+    """BASELINE configs[4] at its own shape (~600 pocket atoms / ~80 ligand atoms): tests/golden/cfg5_traj.npz holds one complex x one
+    pose taken through all 20 steps by the ORACLE (tests/golden/make_oracle_fixtures.py, generated offline on host cores).  The HIP
+    sampler must follow the ligand trajectory and end on the same side chains within 1e-3 A, in every GEMM mode."""
+    import os
+    from tests.helpers import GOLDEN
+    path = os.path.join(GOLDEN, "cfg5_traj.npz")
+    if not os.path.exists(path):
+        pytest.skip("cfg5_traj.npz not generated (tests/golden/make_oracle_fixtures.py)")
+    d, z = load_golden_batch(path)
+    assert int(d.rec_atm_pos.shape[0]) >= 500 and int(d.lig_pos.shape[0]) >= 60
+    params = sm.init_params(sm.default_cfg(), seed=int(z["params_seed"]))
+    model = dba.TensorProductModelHIP({}).to(dev)
+    model.load_state_dict(params, strict=True)
+    samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
+    noise = {k: torch.from_numpy(z[f"noise_{k}"]).to(dev).contiguous() for k in ("tr", "rot", "tor", "sc")}
+    noise = {k: (v if v.shape[1] else torch.zeros(v.shape[0], 1, device=dev)) for k, v in noise.items()}
+    for mode in ("split_f16", "split", "f32"):
+        model.set_gemm(mode)
+        pb = PackedBatch(namespace_to(d, dev), dev)
+        lig, a14 = samp.sample_packed(pb, noise, visualize=True)
+        dl = (lig.cpu() - torch.from_numpy(z["traj_lig"])).norm(dim=-1)
+        assert float(dl.max()) < POSE_ATOL, (mode, float(dl.max()))
+        assert (a14[0].cpu() - torch.from_numpy(z["atom14_step0"])).norm(dim=-1).max() < POSE_ATOL, mode
+        assert (a14[-1].cpu() - torch.from_numpy(z["final_atom14"])).norm(dim=-1).max() < POSE_ATOL, mode
+    model.set_gemm(DEFAULT_GEMM)
+    model.release()
