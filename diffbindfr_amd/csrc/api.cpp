@@ -366,8 +366,9 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
 // bits + the sign of lo = 23 of fp32's 24.  fp16 has five exponent bits, so 2^k puts the largest |v| of these tiles into
 // [2^14, 2^15): pieces of every value within 2^-17 of that maximum stay exact to 22 bits (fp16 subnormals reach down to 2^-24 and
 // the matrix pipe keeps them -- tools/exp/split_f16.hip part D), smaller ones keep an absolute error of 2^-40 of the maximum.
-// Per tile: [2 pieces][4 k-steps of 32][64][8] -- step s = fp32 k-steps 2s and 2s+1 of the same lane -- then [2 pieces][64][4]
-// for the last 16 k, then the tile's 16 bias values (fp32) x 2^k = 9280 B.
+// Per tile: [2 pieces][4 k-steps of 32][64][8] -- step s = fp32 k-steps 2s and 2s+1 of the same lane -- then [64 lanes][hi 4 | lo 4]
+// for the last 16 k (one 16-byte fragment per lane: the A operand of the x32 MFMA that carries both small products of those 16 k,
+// its first half the A operand of the x16 MFMA of the large one), then the tile's 16 bias values (fp32) x 2^k = 9280 B.
 #define CH_TILE_BYTES_HOST 9280
 static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int nt, uint16_t* out) {
   constexpr int KT = 9;
@@ -391,7 +392,7 @@ static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int
           const uint16_t pc[2] = {h16(v), h16(v - (float)hi)};
           for (int i = 0; i < 2; ++i) {
             if (s4 < 8) out[t * tile_h + ((size_t)(i * 4 + (s4 >> 1)) * 64 + lane) * 8 + 4 * (s4 & 1) + q] = pc[i];
-            else out[t * tile_h + tail_off + ((size_t)i * 64 + lane) * 4 + q] = pc[i];
+            else out[t * tile_h + tail_off + (size_t)lane * 8 + 4 * i + q] = pc[i];
           }
         }
   }

@@ -177,12 +177,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
     // n, n + 16, n + 32, n + 48) are scaled once more so that their maximum lies in [2^14, 2^15), cut into fp16 pieces and filed
     // as slots 4 (m & 1) + r of k-step m >> 1 of the W2 tiles' B operand; se / ue carry the total factor and its inverse.
     u32x4 Bh[2][2][4];                                 // h pieces: [edge block][hi, lo][k-step of 32] = 8 fp16 each, 64 VGPRs
-    u32x2 Bt[2][2];                                    // ... and of the last 16 k (v_mfma_f32_16x16x16_f16): 4 fp16 each, 8 VGPRs
+    u32x4 Btc[2];                                      // ... and of the last 16 k: [lo (4 fp16) | hi (4 fp16)] -- the B operand of the ONE x32 MFMA that
+                                                       // carries both small products of these 16 k; its upper half is the x16 MFMA's B operand
     float se[2], ue[2];                                // the edge's factor 2^j on h and its inverse
     {
       const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.w.W1h, 0, KT * CH_TILE_BYTES, 0x00020000);
       u32x4 Ah[2][2][4];                               // a pieces, same filing as Bh
-      u32x2 At[2][2];
+      u32x4 Atc[2];                                    // ... of the last 16 k: [lo | hi] (see Btc)
       float sa[2];
       int ja[2];
 #pragma unroll
@@ -209,23 +210,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
             Ah[b][0][s4 >> 1][2 * (s4 & 1)] = hi0; Ah[b][0][s4 >> 1][2 * (s4 & 1) + 1] = hi1;
             Ah[b][1][s4 >> 1][2 * (s4 & 1)] = lo0; Ah[b][1][s4 >> 1][2 * (s4 & 1) + 1] = lo1;
           } else {
-            At[b][0][0] = hi0; At[b][0][1] = hi1;
-            At[b][1][0] = lo0; At[b][1][1] = lo1;
+            Atc[b] = (u32x4){lo0, lo1, hi0, hi1};
           }
         }
       }
       // 9 row tiles x (4 k-steps of 32 + the last 16 k); fragments of k-step i + 2 requested behind the MFMAs of k-step i
       constexpr int NST = KT * 4;                      // x32 steps, numbered m * 4 + s
       u32x4 F[3][2];                                   // ring of three k-steps of (hi, lo) fragments
-      u32x2 Ft[2];                                     // the current tile's last-16-k fragments
+      u32x4 Ft;                                        // the current tile's last-16-k fragments [hi | lo]
       f32x4 bb;                                        // ... and its bias values x 2^k1
       auto ld_step = [&](int i, u32x4 (&f)[2]) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) f[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, (i >> 2) * CH_TILE_BYTES + (p * 4 + (i & 3)) * 1024, 0));
       };
       auto ld_tail = [&](int m) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) Ft[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rW1, lane * 8, m * CH_TILE_BYTES + CH_TAIL_OFF + p * 512, 0));
+        Ft = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + CH_TAIL_OFF, 0));
         bb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vB, m * CH_TILE_BYTES + CH_BIAS_OFF, 0));
       };
       ld_step(0, F[0]); ld_step(1, F[1]); ld_tail(0);
@@ -251,14 +250,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
           __builtin_amdgcn_sched_barrier(0);
           if (i + 2 < NST) ld_step(i + 2, F[(i + 2) % 3]);
         }
-        {   // k = 128..143 (every accumulator was last written four MFMAs ago: no x32 -> x16 hazard, conv2r.hip)
-          const f16x4 fh = __builtin_bit_cast(f16x4, Ft[0]), fl = __builtin_bit_cast(f16x4, Ft[1]);
-          aS[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[0][1]), aS[0], 0, 0, 0);
-          aS[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[1][1]), aS[1], 0, 0, 0);
-          aS[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(fl, __builtin_bit_cast(f16x4, At[0][0]), aS[0], 0, 0, 0);
-          aS[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(fl, __builtin_bit_cast(f16x4, At[1][0]), aS[1], 0, 0, 0);
-          aB[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[0][0]), aB[0], 0, 0, 0);
-          aB[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, At[1][0]), aB[1], 0, 0, 0);
+        {   // k = 128..143: both small products in ONE x32 MFMA (A = [hi_w | lo_w], B = [lo_a | hi_a]: the 32 k slots of the instruction
+            // are the 16 k's twice), the large one on the x16 instruction (its SrcC was last written three MFMAs ago: no x32 -> x16 hazard)
+          const f16x8 fw = __builtin_bit_cast(f16x8, Ft);
+          const f16x4 fh = __builtin_bit_cast(f16x4, (u32x2){Ft[0], Ft[1]});
+          aS[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw, __builtin_bit_cast(f16x8, Atc[0]), aS[0], 0, 0, 0);
+          aS[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw, __builtin_bit_cast(f16x8, Atc[1]), aS[1], 0, 0, 0);
+          aB[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, (u32x2){Atc[0][2], Atc[0][3]}), aB[0], 0, 0, 0);
+          aB[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(fh, __builtin_bit_cast(f16x4, (u32x2){Atc[1][2], Atc[1][3]}), aB[1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (m + 1 < KT) ld_tail(m + 1);
         }
@@ -291,8 +290,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
             Bh[b][0][m >> 1][2 * (m & 1)] = hi0; Bh[b][0][m >> 1][2 * (m & 1) + 1] = hi1;
             Bh[b][1][m >> 1][2 * (m & 1)] = lo0; Bh[b][1][m >> 1][2 * (m & 1) + 1] = lo1;
           } else {
-            Bt[b][0][0] = hi0; Bt[b][0][1] = hi1;
-            Bt[b][1][0] = lo0; Bt[b][1][1] = lo1;
+            Btc[b] = (u32x4){lo0, lo1, hi0, hi1};
           }
         }
       }
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
     __builtin_amdgcn_wave_barrier();
 
     if (ABL & 64) {   // developer: the unit prologue alone
-      asm volatile("" ::"v"(Bh[0][0][0]), "v"(Bh[1][1][3]), "v"(Bt[1][1]));
+      asm volatile("" ::"v"(Bh[0][0][0]), "v"(Bh[1][1][3]), "v"(Btc[1]));
       continue;
     }
     // ---- the W2 row tiles of this part, run by run (channel-owner order, api.cpp pack_conv2)
@@ -323,7 +321,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
     const float* xs_lane = xs + n * C2_XLD;          // + 16 b C2_XLD per edge block
     const float* sh_lane = shs + n * 10;
     f16x8 FA[2], FB[2];                                // W2 pieces (hi, lo) of two k-steps: 16 VGPRs
-    f16x4 FT[2];                                       // ... and of the last 16 k: 4
+    f16x8 FT;                                          // ... and of the last 16 k [hi | lo]: 4
     f32x4 bias_n;                                      // the NEXT tile's four bias values of this lane's rows (x 2^k of its run)
     f32x4 accN[2];                                     // bias x the edge's factor: where the next tile's small-product chain starts
     f32x4 accS[2], accB[2];                            // this tile's accumulators: small products (+ bias) | large products
@@ -340,11 +338,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       __builtin_amdgcn_sched_barrier(0);
     };
 #define HB(b, p, s) __builtin_bit_cast(f16x8, Bh[b][p][s])
-#define TB(b, p) __builtin_bit_cast(f16x4, Bt[b][p])
 #define M32(C, wp, b, hp, F, s) __builtin_amdgcn_mfma_f32_16x16x32_f16(F[wp], HB(b, hp, s), C, 0, 0, 0)
-#define M16(C, wp, b, hp) __builtin_amdgcn_mfma_f32_16x16x16f16(FT[wp], TB(b, hp), C, 0, 0, 0)
+// the last 16 k: both small products in one x32 MFMA (A = [hi_w | lo_w], B = [lo_h | hi_h]), the large one on the x16 instruction
+#define MT32(C, b) __builtin_amdgcn_mfma_f32_16x16x32_f16(FT, __builtin_bit_cast(f16x8, Btc[b]), C, 0, 0, 0)
+#define MT16(C, b) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(FT, FT, 0, 1, 2, 3), __builtin_bit_cast(f16x4, (u32x2){Btc[b][2], Btc[b][3]}), C, 0, 0, 0)
 #define SLOT(m) do { op(std::integral_constant<int, (m)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
-    // one tile: 30 MFMAs = 5 k-steps x (hi_w lo_h, lo_w hi_h | hi_w hi_h) x 2 edge blocks; `op(m)` = what travels behind MFMA m.
+    // one tile: 28 MFMAs = 4 k-steps of 32 x (hi_w lo_h, lo_w hi_h | hi_w hi_h) + the last 16 k (both small products in one x32 MFMA | the
+    // large one on the x16 instruction), x 2 edge blocks; `op(m)` = what travels behind MFMA m.
     // e0 / e1 / e2: the k-step's memory operations, behind its MFMAs 0 / 1 / 2
     // Tile t writes the staged shares -- its own B shares, the next tile's A shares -- late in their windows (k-steps 1 and 3: right
     // behind a barrier all eight waves would write at once, in front of everybody's fragment reads: -3 %) and re-arms the registers.
@@ -375,22 +375,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       // k-step 3 (FB): the A shares of the tile after next set out
       accS[0] = M32(accS[0], 0, 0, 1, FB, 3); SLOT(18);
       accS[1] = M32(accS[1], 0, 1, 1, FB, 3); SLOT(19);
-      accS[0] = M32(accS[0], 1, 0, 0, FB, 3);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) FT[i] = *reinterpret_cast<const f16x4*>(ring + CH_TAIL_OFF + i * 512 + lane * 8);
-      SLOT(20);
+      accS[0] = M32(accS[0], 1, 0, 0, FB, 3); FT = *reinterpret_cast<const f16x8*>(ring + CH_TAIL_OFF + vW); SLOT(20);
       accS[1] = M32(accS[1], 1, 1, 0, FB, 3); if (!(ABL & 256)) putA(); SLOT(21);
       accB[0] = M32(accB[0], 0, 0, 0, FB, 3); if (!(ABL & (256 | 32))) fetchA(min(t + 2, t_last)); SLOT(22);
       accB[1] = M32(accB[1], 0, 1, 0, FB, 3); SLOT(23);
-      // k = 128..143 on v_mfma_f32_16x16x16_f16; the next tile's slots 0..2 are complete: its first k-step's fragments.
-      // Block 0 finishes two MFMAs before the tile does, so its sum (slot 29) does not wait for the pipe.
+      // k = 128..143: one x32 MFMA (both small products) + one x16 MFMA (the large one) per block; the next tile's slots 0..2 are
+      // complete: its first k-step's fragments.  Block 0 finishes two MFMAs before the tile does, so its sum (slot 27) does not wait
+      // for the pipe.  (x16 SrcC last written by an x32 MFMA three MFMAs earlier: no hazard, header comment.)
       ring_barrier();
-      accS[0] = M16(accS[0], 0, 0, 1); bias_n = *reinterpret_cast<const f32x4*>(ring + CH_BIAS_OFF + vB); SLOT(24);
-      accS[1] = M16(accS[1], 0, 1, 1); SLOT(25);
-      accS[0] = M16(accS[0], 1, 0, 0); rd_step(I0{}, FA); SLOT(26);
-      accB[0] = M16(accB[0], 0, 0, 0); SLOT(27);
-      accS[1] = M16(accS[1], 1, 1, 0); SLOT(28);
-      accB[1] = M16(accB[1], 0, 1, 0); SLOT(29);
+      accS[0] = MT32(accS[0], 0); bias_n = *reinterpret_cast<const f32x4*>(ring + CH_BIAS_OFF + vB); SLOT(24);
+      accB[0] = MT16(accB[0], 0); rd_step(I0{}, FA); SLOT(25);
+      accS[1] = MT32(accS[1], 1); SLOT(26);
+      accB[1] = MT16(accB[1], 1); SLOT(27);
       sum4(accp[1], accS[1], accB[1]);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -517,17 +513,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
         // what travels behind MFMA m of a tile.  Previous tile: block 0's contraction in slots 0 (read) and 3..13 (two operations
-        // each), block 1's in 12 and 15..25.  This tile: the next tile's chain start (bias x edge factor) in 27 / 28, block 0's sum
-        // in 29 (block 1's closes the tile)
+        // each), block 1's in 12 and 15..25.  This tile: the next tile's chain start (bias x edge factor) in 26 / 27, block 0's sum
+        // in 27 (block 1's closes the tile)
         auto travel = [&](auto mc, const float* xp) {
           constexpr int m = decltype(mc)::value;
           if constexpr (m == 0) cop(B0{}, std::integral_constant<int, 0>{}, xp);
           if constexpr (m >= 3 && m <= 13) { cop(B0{}, std::integral_constant<int, 2 * (m - 3) + 1>{}, xp); cop(B0{}, std::integral_constant<int, 2 * (m - 3) + 2>{}, xp); }
           if constexpr (m == 12) cop(B1{}, std::integral_constant<int, 0>{}, xp);
           if constexpr (m >= 15 && m <= 25) { cop(B1{}, std::integral_constant<int, 2 * (m - 15) + 1>{}, xp); cop(B1{}, std::integral_constant<int, 2 * (m - 15) + 2>{}, xp); }
-          if constexpr (m == 27) scale4(accN[0], bias_n, se[0]);
-          if constexpr (m == 28) scale4(accN[1], bias_n, se[1]);
-          if constexpr (m == 29) sum4(accp[0], accS[0], accB[0]);
+          if constexpr (m == 26) scale4(accN[0], bias_n, se[0]);
+          if constexpr (m == 27) { scale4(accN[1], bias_n, se[1]); sum4(accp[0], accS[0], accB[0]); }
         };
         // tile i carries the contraction of tile i - 1; the run's first tile carries one of zeros (same code, no second copy
         // of the loop body for the register allocator to fit)
@@ -571,7 +566,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       }
     }
 #undef M32
-#undef M16
+#undef MT32
+#undef MT16
 #undef HB
 #undef TB
   }

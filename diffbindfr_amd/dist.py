@@ -149,7 +149,7 @@ def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
         send = torch.zeros(w, dtype=local.dtype, device=stage_dev)
         k = max(0, min(w, n_valid - w0))
         if k:
-            send[:k] = local[w0:w0 + k].to(stage_dev, non_blocking=True)
+            send[:k] = local[w0:w0 + k].to(stage_dev)          # blocking on purpose: a host-staged (gloo) collective reads it next
         if mode == "all":
             buf = torch.empty(world * w, dtype=local.dtype, device=stage_dev)
             dist.all_gather_into_tensor(buf, send)

@@ -769,11 +769,32 @@ def golden_examples():
     pp = ref_shims._load("druglib.datasets.Docking.pocket_pipeline", "datasets/Docking/pocket_pipeline.py")
     ex = os.path.join(ref_shims.REF, "examples")
 
-    def save(name, prots, ligs, pairs, tapes, noise, lig_traj, a14_final, params):
+    HALF_KEYS = ("sequence", "atom14_mask", "backbone_transl", "backbone_rots", "default_frame", "rigid_group_positions", "torsion_angle",
+                 "torsion_edge_index", "sc_torsion_edge_mask", "pocket_node_feature")
+
+    def halves_of(prots_pk):
+        """prot{i}_half_<key>: the pocket half the REFERENCE's pipeline built (what the frozen trajectories started from)."""
+        return {f"prot{i}_half_{k}": npy(pk[k]) for i, pk in enumerate(prots_pk) for k in HALF_KEYS}
+
+    if os.environ.get("GOLDEN_EXAMPLES_HALVES_ONLY"):      # add the reference pocket halves to existing fixtures without re-running sample()
+        for name, sub, names in (("real_forward15_traj.npz", "forward", ["3dbs"]), ("real_reverse_traj.npz", os.path.join("reverse", "receptors"), ["2src", "3mhw", "3pp0"])):
+            z = dict(np.load(os.path.join(HERE, name)))
+            pks = []
+            for nm in names:
+                c, _ = _parse_sdf_heavy(os.path.join(ex, sub, f"{nm}_protein_crystal.sdf"))
+                (seq, pos, msk), _sup = _protein_superset(os.path.join(ex, sub, f"{nm}_protein.pdb"), c)
+                pks.append(_ref_pocket_half(seq, pos, msk, pp, du))
+            z.update(halves_of(pks))
+            np.savez_compressed(os.path.join(HERE, name), **z)
+            print(f"  {name}: reference pocket halves added, {os.path.getsize(os.path.join(HERE, name)) // 1024} KiB")
+        return
+
+    def save(name, prots, ligs, pairs, tapes, noise, lig_traj, a14_final, params, prots_pk):
         out = dict(n_prot=np.asarray(len(prots)), n_lig=np.asarray(len(ligs)), pairs=np.asarray(pairs, np.int64),
                    params_seed=np.asarray(1), params_sha256=np.asarray(params_digest(params)),
                    noise_tr=npy(noise.tr), noise_rot=npy(noise.rot), noise_tor=npy(noise.tor), noise_sc=npy(noise.sc),
                    traj_lig=npy(lig_traj).astype(np.float32), final_atom14=npy(a14_final).astype(np.float32))
+        out.update(halves_of(prots_pk))
         for i, (nm, cry, sup) in enumerate(prots):
             out.update({f"prot{i}_name": np.asarray(nm), f"prot{i}_ref_lig_pos": cry.astype(np.float32), f"prot{i}_aatype": sup[0],
                         f"prot{i}_atom37_pos": sup[1].astype(np.float32), f"prot{i}_atom37_mask": sup[2]})
@@ -797,7 +818,7 @@ def golden_examples():
     ligs = [(f[:-4], _ligand_half_from_sdf(os.path.join(ex, "forward", "mols", f), du, 100 + i)) for i, f in enumerate(files)]
     recs = [dict(pk, **lg) for _, lg in ligs]
     tapes, noise, lt, a14, params = _reference_trajectories(recs, 4321, "examples/forward (3DBS x 15 ligands)")
-    save("real_forward15_traj.npz", [("3dbs", cry, sup)], ligs, [(0, i) for i in range(15)], tapes, noise, lt, a14, params)
+    save("real_forward15_traj.npz", [("3dbs", cry, sup)], ligs, [(0, i) for i in range(15)], tapes, noise, lt, a14, params, [pk])
 
     # ---- reverse: 2 ligands x 3 receptors (pairs ligand-major, as dataframe.py builds the table)
     prots, pks = [], []
@@ -811,7 +832,7 @@ def golden_examples():
     pairs = [(p, l) for l in range(2) for p in range(3)]
     recs = [dict(pks[p], **ligs[l][1]) for p, l in pairs]
     tapes, noise, lt, a14, params = _reference_trajectories(recs, 8765, "examples/reverse (2 ligands x 3 receptors)")
-    save("real_reverse_traj.npz", prots, ligs, pairs, tapes, noise, lt, a14, params)
+    save("real_reverse_traj.npz", prots, ligs, pairs, tapes, noise, lt, a14, params, pks)
 
 
 

@@ -1,5 +1,2 @@
-mkdir -p gpurun_out/r3
 cd $GRAFT_REPO_ROOT
-timeout 900 python tests/golden/make_oracle_fixtures.py gpurun_out/r3 2>&1 | grep -v Warning | tail -3
-cp gpurun_out/r3/cfg5_traj.npz tests/golden/
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cfg5_shape" 2>&1 | tail -5
+timeout 1800 python -m pytest tests/test_jobs.py tests/test_examples.py tests/test_mdn.py tests/test_export.py tests/test_pocket.py tests/test_pose_init.py tests/test_real_complex.py -x -q -m gpu 2>&1 | tail -6 | cut -c1-300
