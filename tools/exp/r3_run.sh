@@ -1,2 +1,10 @@
+mkdir -p gpurun_out/r3
 cd $GRAFT_REPO_ROOT
-timeout 1800 python -m pytest tests/test_jobs.py tests/test_examples.py tests/test_mdn.py tests/test_export.py tests/test_pocket.py tests/test_pose_init.py tests/test_real_complex.py -x -q -m gpu 2>&1 | tail -6 | cut -c1-300
+for m in split_f16 split f32; do
+  (DBFR_GEMM=$m DBFR_CONV2=1 python tools/conv_bench.py --layer 3 --fam 2 --edges 650000 --reps 5000 > gpurun_out/r3/power_$m.txt 2>&1 &)
+  sleep 11
+  echo "mode $m"
+  for i in 1 2 3 4 5 6 7 8; do rocm-smi --showpower --showclocks 2>&1 | grep -i "power (W)\|sclk" | sed 's/GPU\[0\]\t\t: //' | tr '\n' ' '; echo; sleep 1; done
+  sleep 25
+  tail -1 gpurun_out/r3/power_$m.txt | cut -c1-90
+done

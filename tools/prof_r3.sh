@@ -29,6 +29,24 @@ stats() {  # stats <tag> <bench args...>
   head -8 $OUT/${tag}_kernel_stats.csv
 }
 Q="--no-cpu-baseline --no-latency --no-native"
+if [ $WHAT = all ] || [ $WHAT = lines ]; then
+  cd $R
+  timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  for c in 3 4; do timeout 300 python bench.py --config $c --steps 2 $Q > $OUT/bench_cfg$c.json 2>/dev/null; done
+  timeout 300 python bench.py --config 2 --steps 2 --scaling strong $Q > $OUT/bench_strong1.json 2>/dev/null
+  timeout 300 python bench.py --config 1 --batch-poses 4 --steps 1 --no-native --no-latency > $OUT/bench_cfg1_1x4.json 2>/dev/null
+  # the N>1 path on one GPU: 2 ranks share cuda:0, records staged through the host for the gloo gather
+  DBFR_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
+    bench.py --gpus 2 --steps 1 --warmup 0 --batch-poses 320 --no-profile > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err
+  for m in split f32; do DBFR_GEMM=$m timeout 400 python bench.py --steps 2 $Q > $OUT/bench_gemm_$m.json 2>/dev/null; done
+  for f in $OUT/bench_*.json; do echo $f; python -c "
+import json,sys
+try:
+    d=json.loads(open('$f').read().strip().splitlines()[-1]); r=d.get('roofline') or {}; print(d['value'], d['n_gpus'], d['scaling'], r.get('fp32_equivalent_tflops'), r.get('frac'), (d.get('cpu_baseline') or {}).get('value'), (d.get('cpu_baseline') or {}).get('parity'))
+except Exception as e: print('bad', e)
+"; done
+  cd /tmp
+fi
 if [ $WHAT = all ] || [ $WHAT = cfg2 ]; then
   stats cfg2 --steps 2 --warmup 1 $Q
   pmc cfg2 --steps 1 --warmup 0 --batch-poses 640 --no-profile $Q
