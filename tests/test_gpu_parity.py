@@ -594,3 +594,29 @@ def test_cfg5_shape_trajectory_matches_the_oracle_fixture(dev):
         assert (a14[-1].cpu() - torch.from_numpy(z["final_atom14"])).norm(dim=-1).max() < POSE_ATOL, mode
     model.set_gemm(DEFAULT_GEMM)
     model.release()
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1e3, "ragged"])
+def test_split_f16_scales_its_operands_per_edge(setup, dev, scale):
+    """k_conv2h brings its operands into fp16's exponent range with exact powers of two chosen PER EDGE (radial-MLP inputs and hidden
+    activations) -- so radial-MLP inputs 1e-4 or 1e3 times their usual size, or edges whose inputs differ by eight decades inside one
+    wave, must cost no accuracy against the fp32 instruction (unscaled, the pieces would underflow / overflow: tools/exp/split_f16.hip)."""
+    mcfg, p, model = setup
+    lib, h = L.load(), model.handle(dev)
+    layer, fam, E = 3, 2, 9000
+    c = _random_conv_inputs(dev, layer, E)
+    if scale == "ragged":        # every edge its own magnitude: 10^-4 .. 10^4 (emb is per edge; the gathered rows follow their nodes)
+        g = torch.Generator(device=dev).manual_seed(5)
+        c["emb"] = c["emb"] * torch.pow(10.0, 8 * torch.rand(E, 1, device=dev, generator=g) - 4)
+        c["xt"] = c["xt"] * torch.pow(10.0, 8 * torch.rand(c["xt"].shape[0], 1, device=dev, generator=g) - 4)
+    else:
+        c["emb"], c["xt"] = c["emb"] * scale, c["xt"] * scale
+        c["x"] = c["x"] * scale                                  # (x also feeds the radial MLP as its third input block)
+    with gemm(model, "f32"):
+        ref = _run_conv_hook(lib.dbfr_test_conv, h, layer, fam, c, E, dev)
+    with gemm(model, "split_f16"):
+        a = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E, dev)
+    assert torch.isfinite(a).all() and torch.isfinite(ref).all()
+    # per edge: messages of differently scaled edges differ by orders of magnitude, so the error is taken relative to each edge's own size
+    err = (a - ref).abs().amax(dim=1) / ref.abs().amax(dim=1).clamp_min(1e-30)
+    assert float(err.max()) < 5e-6, float(err.max())
