@@ -588,8 +588,9 @@ __device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, i
     const int mul = ln.mul[bk], dim = ln.dim[bk], off = ln.off[bk];
     const int nel = mul * dim;
     float mean[3] = {0.f, 0.f, 0.f};
+    const bool d3 = dim == 3;              // irreps are scalars or vectors: a constant divisor instead of a runtime division
     for (int i = lane; i < nel; i += 64) {
-      int comp = i % dim;
+      int comp = d3 ? i % 3 : 0;
       float v = bw[off + i];
       if (comp == 0) mean[0] += v; else if (comp == 1) mean[1] += v; else mean[2] += v;
     }
@@ -600,7 +601,7 @@ __device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, i
     }
     float sq = 0.f;
     for (int i = lane; i < nel; i += 64) {
-      int u = i / dim, comp = i - u * dim;
+      int u = d3 ? i / 3 : i, comp = d3 ? i - 3 * u : 0;
       float v = bw[off + i] - (comp == 0 ? mean[0] : comp == 1 ? mean[1] : mean[2]) * ln.mean_shift[iw + u];
       bw[off + i] = v;
       sq += v * v;
@@ -609,7 +610,7 @@ __device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, i
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     const float inv = 1.0f / sqrtf(sq / (float)nel + 1e-5f);
     for (int i = lane; i < nel; i += 64) {
-      int u = i / dim;
+      int u = d3 ? i / 3 : i;
       float v = bw[off + i] * (inv * ln.weight[iw + u]);
       if (ln.is0e[bk]) v += ln.bias[ib + u];
       bw[off + i] = v;

@@ -453,52 +453,64 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
   __shared__ float hid[MLP_ROWS][NS + 1];
   __shared__ float w0[MLP_MAXIN * NS];
   __shared__ float w1[NS * NS];
+  __shared__ float s_gs[EMB];
   const int nrows = a.n_rows_dev ? min(*a.n_rows_dev, a.n_rows_max) : a.n_rows_max;
-  const int r0 = blockIdx.x * MLP_ROWS;
-  if (r0 >= nrows) return;
-  const int nr = min(MLP_ROWS, nrows - r0);
+  if ((int)blockIdx.x * MLP_ROWS >= nrows) return;
   const int in = a.w.in;
+  // weights once per workgroup, then a grid-stride walk over the 64-row tiles (one tile per workgroup cost 24 KB of weight staging per
+  // 64 rows: 275 us per call on average at the bench batch, 2 % of the step)
   for (int i = threadIdx.x; i < in * NS; i += 256) w0[i] = a.w.w0t[i];
   for (int i = threadIdx.x; i < NS * NS; i += 256) w1[i] = a.w.w1t[i];
   const float coeff = a.gs_coeff ? a.gs_coeff[0] : 0.f;
-  for (int i = threadIdx.x; i < MLP_ROWS * in; i += 256) {
-    int r = i / in, c = i - r * in;
-    float v = 0.f;
-    if (r < nr) {
-      int row = r0 + r;
-      int g = a.mode == IN_G ? 0 : a.row_graph_tab[a.tgt ? a.tgt[row] : row];
-      int cc = c;
-      if (a.mode == IN_LIGNODE) {
-        v = cc < a.nnode ? a.lig_node[(size_t)row * a.nnode + cc] : a.temb[g * EMB + cc - a.nnode];
-      } else {
-        if (a.mode == IN_LIGEDGE) {
-          if (cc < a.nfeat) { int k = a.aux[row]; v = k >= 0 ? a.bond_feat[(size_t)k * a.nfeat + cc] : 0.f; cc = -1; }
-          else cc -= a.nfeat;
-        }
-        if (cc >= 0) {
-          if (a.mode != IN_G && cc < EMB) v = a.temb[g * EMB + cc];
-          else {
-            int k = a.mode == IN_G ? cc : cc - EMB;
-            float d = fminf(a.dist[row], a.gs_offset[EMB - 1]) - a.gs_offset[k];
-            v = expf(coeff * (d * d));
-          }
-        }
-      }
-    }
-    xin[r][c] = v;
-  }
+  if (threadIdx.x < EMB) s_gs[threadIdx.x] = a.gs_offset ? a.gs_offset[threadIdx.x] : 0.f;
+  __syncthreads();
   // zero padding of the reduction dim to a multiple of 4 (MFMA k-step)
   const int kin = (in + 3) & ~3;
-  if (kin > in) {
-    for (int i = threadIdx.x; i < MLP_ROWS * (kin - in); i += 256) xin[i / (kin - in)][in + i % (kin - in)] = 0.f;
+  if (kin > in)
     for (int i = threadIdx.x; i < (kin - in) * NS; i += 256) w0[in * NS + i] = 0.f;
-  }
-  __syncthreads();
-  // both layers on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): wave w owns rows 16w..16w+15,
-  // D[channel, row] orientation => lane (g, n) holds 4 consecutive output channels of row 16w + n
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
   const int row = 16 * wave + n;
+  for (int r0 = blockIdx.x * MLP_ROWS; r0 < nrows; r0 += gridDim.x * MLP_ROWS) {
+  const int nr = min(MLP_ROWS, nrows - r0);
+  {   // input assembly: four threads per row (columns q, q + 4, ...); what belongs to the row -- its graph, its clamped distance -- is
+      // fetched once per thread, the Gaussian offsets come from LDS (element-wise assembly with a division and 3-4 dependent global
+      // loads per element was most of this kernel's time)
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const bool live = r < nr;
+    const int arow = r0 + (live ? r : 0);
+    const int gph = a.mode == IN_G ? 0 : a.row_graph_tab[a.tgt ? a.tgt[arow] : arow];
+    const float dcl = a.dist ? fminf(a.dist[arow], s_gs[EMB - 1]) : 0.f;
+    const int bond = a.mode == IN_LIGEDGE ? a.aux[arow] : -1;
+    for (int c = q; c < in; c += 4) {
+      float v = 0.f;
+      if (live) {
+        int cc = c;
+        if (a.mode == IN_LIGNODE) {
+          v = cc < a.nnode ? a.lig_node[(size_t)arow * a.nnode + cc] : a.temb[gph * EMB + cc - a.nnode];
+        } else {
+          if (a.mode == IN_LIGEDGE) {
+            if (cc < a.nfeat) { v = bond >= 0 ? a.bond_feat[(size_t)bond * a.nfeat + cc] : 0.f; cc = -1; }
+            else cc -= a.nfeat;
+          }
+          if (cc >= 0) {
+            if (a.mode != IN_G && cc < EMB) v = a.temb[gph * EMB + cc];
+            else {
+              const int k = a.mode == IN_G ? cc : cc - EMB;
+              const float d = dcl - s_gs[k];
+              v = expf(coeff * (d * d));
+            }
+          }
+        }
+      }
+      xin[r][c] = v;
+    }
+  }
+  if (kin > in)
+    for (int i = threadIdx.x; i < MLP_ROWS * (kin - in); i += 256) xin[i / (kin - in)][in + i % (kin - in)] = 0.f;
+  __syncthreads();     // (also: every wave has finished reading `hid` of the previous tile)
+  // both layers on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): wave w owns rows 16w..16w+15,
+  // D[channel, row] orientation => lane (g, n) holds 4 consecutive output channels of row 16w + n
   f32x4 acc[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
@@ -513,7 +525,7 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) hid[row][16 * t + 4 * g + r] = fmaxf(acc[t][r], 0.f);
-  __syncthreads();
+  __syncthreads();     // (also: every wave has finished reading `xin` of this tile)
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -528,11 +540,13 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(a.out + (size_t)(r0 + row) * NS + 16 * t + 4 * g) = acc[t];
   }
+  }
 }
 
 void launch_mlp(const MlpArgs& a, hipStream_t st) {
   if (a.n_rows_max <= 0) return;
-  hipLaunchKernelGGL(k_mlp, dim3((a.n_rows_max + MLP_ROWS - 1) / MLP_ROWS), dim3(256), 0, st, a);
+  const int tiles = (a.n_rows_max + MLP_ROWS - 1) / MLP_ROWS;
+  hipLaunchKernelGGL(k_mlp, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, st, a);    // 58 KB of LDS: two workgroups per CU, four tile sequences per CU
 }
 
 // AtomEncoder (equibind_encoder.py:68-88): sum of 5 categorical embeddings, then

@@ -1,10 +1,9 @@
-mkdir -p gpurun_out/r3
 cd $GRAFT_REPO_ROOT
-for m in split_f16 split f32; do
-  (DBFR_GEMM=$m DBFR_CONV2=1 python tools/conv_bench.py --layer 3 --fam 2 --edges 650000 --reps 5000 > gpurun_out/r3/power_$m.txt 2>&1 &)
-  sleep 11
-  echo "mode $m"
-  for i in 1 2 3 4 5 6 7 8; do rocm-smi --showpower --showclocks 2>&1 | grep -i "power (W)\|sclk" | sed 's/GPU\[0\]\t\t: //' | tr '\n' ' '; echo; sleep 1; done
-  sleep 25
-  tail -1 gpurun_out/r3/power_$m.txt | cut -c1-90
-done
+mkdir -p gpurun_out/r3
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 900 python bench.py --no-cpu-baseline > gpurun_out/r3/bench_default_3.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r3/bench_default_3.json').read().strip().splitlines()[-1])
+r=d['roofline']; print(d['value'], d.get('value_literal_128x40'), r['fp32_equivalent_tflops'], r['frac'], r['conv_time_share'], d['latency']['cfg1_1x4']['seconds'], d['latency']['cfg2_bs16']['seconds'])
+PY
