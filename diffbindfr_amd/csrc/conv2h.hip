@@ -94,8 +94,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
   const int N = nb0 + nb1 + nb2 + nb3;
   const int n_wg = gridDim.x;
   const int full = (N / n_wg) * n_wg, rem = N - full;
+  // The blocks of the last, partial round are cut 2 / 4 / 8-way along the output channels (disjoint message columns).  Which cut: the one
+  // with the smallest (rounds of parts) x (part length), a part costing 1 / 2^si of a block + ~5 % for its own prologue -- e.g. 140 blocks
+  // on 256 workgroups: uncut 1 x 1.05, 2-way 2 x 0.55, 4-way 3 x 0.30, 8-way 5 x 0.17 = 0.86 (the old rule "cut only if every part finds
+  // a free workgroup" left 116 of 256 CUs idle for such a launch: predict.py-sized batches).  A message does not depend on the cut.
   int si = 0;
-  if (rem > 0 && !a.no_split) { const int q = n_wg / rem; si = q >= 8 ? 3 : q >= 4 ? 2 : q >= 2 ? 1 : 0; }
+  if (rem > 0 && !a.no_split) {
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cost = (((rem << c) + n_wg - 1) / n_wg) * ((128 >> c) + 6);
+      if (cost < best) { best = cost; si = c; }
+    }
+  }
   const int total = full + (rem << si);
 
   for (int it = 0;; ++it) {

@@ -1,9 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3
-timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 900 python bench.py --no-cpu-baseline > gpurun_out/r3/bench_default_3.json 2>/dev/null
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r3/bench_default_3.json').read().strip().splitlines()[-1])
-r=d['roofline']; print(d['value'], d.get('value_literal_128x40'), r['fp32_equivalent_tflops'], r['frac'], r['conv_time_share'], d['latency']['cfg1_1x4']['seconds'], d['latency']['cfg2_bs16']['seconds'])
-PY
+for c in cfg1 bs16 bs40 p80 p160 c5p16; do for ns in 1 0; do echo -n "$c nosplit-old-rule=$ns: "; DBFR_CONV2_NOSPLIT=$ns timeout 200 python tools/latency_run.py --case $c --reps 5 2>&1 | tail -1; done; done
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "split_kernels or bitwise or fused" 2>&1 | tail -2
