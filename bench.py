@@ -15,6 +15,8 @@ BASELINE.json configs[1] (128 complexes x 40 poses = 5120 poses); with any K >= 
 the rate over the first 5120 poses.  --config 3 / 4: every job shares ONE receptor /
 ONE ligand record (forward screen / target fishing).  Per-complex records are resident in HBM before the timed region
 (uploaded once per ligand / pocket); fp32 arithmetic throughout (the reference runs fp32).  Rank 0 prints ONE JSON line.
+After the timed region (N = 1) the script measures the dominant kernel's HBM traffic itself: two child runs of one batch under
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (`--no-pmc` skips them), then the latency cases and the CPU-oracle baseline.
 """
 import argparse
 import copy
@@ -174,6 +176,53 @@ def cpu_baseline(cfg_id, samp, dev, n_poses=1, batched=(2, 2), batched_steps=5):
     return out
 
 
+PMC_KERNEL = {"split_f16": "k_conv2h", "split": "k_conv2r", "split_l1": "k_conv2s"}
+
+
+def measure_traffic(mode, args):
+    """HBM traffic of the dominant kernel measured ON THIS BOX: two child runs of this script (one batch each) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, as MI355X_MICROARCH.md prescribes (the two
+    do not fit one pass) -- summed over the kernel's dispatches, per launch.  FETCH_SIZE is doubled (gfx950 tallies the 128-byte
+    requests of 16-byte-per-lane reads at 64 bytes; same guide).  Returns (dict, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    kern = PMC_KERNEL.get(mode)
+    if any("rocprof" in v.lower() for k, v in os.environ.items() if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")):
+        return None, "no live PMC pass (this process already runs under a profiler)"
+    if kern is None or shutil.which("rocprofv3") is None:
+        return None, "no live PMC pass (rocprofv3 absent or fp32-instruction mode)"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="dbfr_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "1", "--warmup", "0", "--config", str(args.config), "--batch-poses", str(args.batch_poses),
+                   "--no-profile", "--no-cpu-baseline", "--no-latency", "--no-native", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            tot, disp = 0.0, set()
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if kern in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        tot += float(row["Counter_Value"])
+                        disp.add(row["Dispatch_Id"])
+            if not disp:
+                return None, f"no {kern} dispatch in the {ctr} pass"
+            out[ctr] = tot * 1024.0 / len(disp)          # the counters are in KiB
+            out["dispatches"] = len(disp)
+    except Exception as e:      # a profiler problem must not cost the bench line
+        return None, f"live PMC pass failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, None
+
+
 def latency_leg(samp, dev, lib, model):
     """BASELINE configs[0] literally, as predict.py is used: ONE complex of the 3DBS shape x 4 poses x 20 steps
     (records resident, assemble + init + sample + status sync timed), and predict.py's `-bs 16` of the cfg-2 shape."""
@@ -213,6 +262,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-native", action="store_true", help="skip the one-batch run of the fp32-matrix-instruction kernels")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="no child runs under rocprofv3 --pmc (roofline.traffic falls back to the constant of profiles/)")
     ap.add_argument("--cpu-poses", type=int, default=None)
     ap.add_argument("--cpu-batched-steps", type=int, default=5)
     args = ap.parse_args()
@@ -280,17 +330,28 @@ def main():
         # what the named matrix instruction executes: `products` MFMA-flops per algorithmic flop of the 144 x W GEMM (97.6 % of the
         # conv's flops; the 144 x 144 hidden layer stays on the fp32 instruction inside the same kernel and is not counted here)
         ex = alg if mode == "f32" else P["products"] * W2_SHARE * alg
-        traffic, tsrc = None, "no PMC pass for this workload"
-        pmc_rel = PMC_FILE[mode] if args.config == 2 else PMC_FILE_CFG5.get(mode) if args.config == 5 else None
-        pmc = os.path.join(ROOT, pmc_rel) if pmc_rel else None
-        if pmc and os.path.exists(pmc) and args.batch_poses == 640:
-            pj = json.load(open(pmc))     # separate rocprofv3 --pmc passes (tools/prof_r3.sh), NOT measured in this run
-            traffic = pj["traffic_bytes_per_launch"]
-            tsrc = (f"{pmc_rel}: FETCH_SIZE+WRITE_SIZE of separate --pmc passes over `bench.py --config {args.config} --batch-poses 640`, "
-                    f"per launch of this kernel; a constant from that file, valid for that workload only")
+        traffic, tsrc, traw = None, "no PMC pass for this workload", None
+        live, why = (None, "--no-pmc") if (args.no_pmc or world != 1 or mode != main_mode) else measure_traffic(mode, args)
+        if live is not None:
+            traffic = 2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"]
+            traw = {"fetch_size_raw": live["FETCH_SIZE"], "write_size": live["WRITE_SIZE"], "dispatches": live["dispatches"]}
+            tsrc = ("measured in this run: two child runs of this command (one batch) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` "
+                    "(separate passes, counters only), per launch of this kernel; traffic = 2 x FETCH_SIZE (gfx950 correction for 16-byte-per-"
+                    "lane reads, MI355X_MICROARCH.md) + WRITE_SIZE")
+        else:
+            pmc_rel = PMC_FILE[mode] if args.config == 2 else PMC_FILE_CFG5.get(mode) if args.config == 5 else None
+            pmc = os.path.join(ROOT, pmc_rel) if pmc_rel else None
+            if pmc and os.path.exists(pmc) and args.batch_poses == 640:
+                pj = json.load(open(pmc))     # separate rocprofv3 --pmc passes (tools/prof_r3.sh), NOT measured in this run
+                traffic = 2.0 * pj["fetch_bytes_per_launch_raw"] + pj["write_bytes_per_launch_raw"]
+                traw = {"fetch_size_raw": pj["fetch_bytes_per_launch_raw"], "write_size": pj["write_bytes_per_launch_raw"]}
+                tsrc = (f"{why}; constant from {pmc_rel} (separate --pmc passes over `bench.py --config {args.config} --batch-poses 640`, per "
+                        f"launch of this kernel; 2 x FETCH_SIZE + WRITE_SIZE), valid for that workload only")
+            else:
+                tsrc = f"{why}; no PMC file for this workload"
         alg_bytes = fb.value / nl.value
         roof = {"bound": "mfma", "achieved": round(ex, 1), "peak": P["peak"], "unit": "TFLOP/s", "frac": round(ex / P["peak"], 4),
-                "traffic": traffic, "traffic_source": tsrc,
+                "traffic": traffic, "traffic_source": tsrc, "traffic_counters": traw,
                 "algorithmic_bytes_per_launch": alg_bytes, "traffic_ratio": round(traffic / alg_bytes, 3) if traffic else None,
                 "what": "achieved = flops the matrix pipe EXECUTES per second on `instruction` (products_per_fp32_product x the 144 x W share of the "
                         "algorithmic rate); peak = that instruction's dense peak; fp32_equivalent_tflops = algorithmic fp32 flops / kernel time",
@@ -305,7 +366,7 @@ def main():
                 "algorithmic_gbytes_per_s": round(fb.value / (ms.value * 1e-3) / 1e9, 1)}
         return roof
 
-    mode = model.gemm_mode(dev)
+    mode = main_mode = model.gemm_mode(dev)
     roof = None if args.no_profile else read_roofline(elapsed, mode)
     native = None
     if world == 1 and not args.no_profile and not args.no_native and mode != "f32":

@@ -1,3 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for c in cfg1 bs16 bs40 p80 p160 c5p16; do for ns in 1 0; do echo -n "$c nosplit-old-rule=$ns: "; DBFR_CONV2_NOSPLIT=$ns timeout 200 python tools/latency_run.py --case $c --reps 5 2>&1 | tail -1; done; done
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "split_kernels or bitwise or fused" 2>&1 | tail -2
+mkdir -p gpurun_out/r3
+( time timeout 900 python bench.py --no-cpu-baseline --steps 4 > gpurun_out/r3/bench_default_4.json 2> gpurun_out/r3/bench_default_4.err ) 2>&1 | grep real
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r3/bench_default_4.json').read().strip().splitlines()[-1])
+r=d['roofline']; print(d['value'], r['fp32_equivalent_tflops'], r['frac'], r['traffic'], r['traffic_ratio'], r['traffic_counters']); print(r['traffic_source'][:200]); print(d['native_f32']['traffic'], d['native_f32']['traffic_source'][:120])
+PY
+tail -3 gpurun_out/r3/bench_default_4.err

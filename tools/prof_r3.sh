@@ -28,7 +28,7 @@ stats() {  # stats <tag> <bench args...>
   rm -rf $OUT/${tag}_stats
   head -8 $OUT/${tag}_kernel_stats.csv
 }
-Q="--no-cpu-baseline --no-latency --no-native"
+Q="--no-cpu-baseline --no-latency --no-native --no-pmc"
 if [ $WHAT = all ] || [ $WHAT = lines ]; then
   cd $R
   timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
