@@ -10,8 +10,9 @@
 //     per tile;
 //   * h = relu(W1 a + b1): per EDGE, in the kernel (largest of the edge's 144 activations); the bias is multiplied by the
 //     edge's factor where k_conv2r copied it into the accumulator, and the inverse goes into the message store.
-// The two small products of all five k-steps and the five large ones run in SEPARATE accumulators (small ones start from the
-// bias, large ones from 0) that are added once per tile -- where k_conv2r moved its accumulator into the previous-tile
+// The small products of all five k-steps (4 x 32 k + the last 16 k, whose two small products share ONE x32 MFMA: A = [hi_w | lo_w],
+// B = [lo_h | hi_h]) and the five large ones run in SEPARATE accumulators (small ones start from the bias, large ones from 0) that are
+// added once per tile -- where k_conv2r moved its accumulator into the previous-tile
 // registers: the large chain is rounded 5 times instead of 15, which is what puts the error below the fp32 instruction's
 // (tools/exp/split_f16.hip, profiles/r3_split_experiments.txt).
 //
@@ -20,8 +21,8 @@
 // tile is now 9 KiB of pieces and half as many MFMAs long:
 //   * TWO barriers per tile instead of three, the minimum for a one-tile ring (every slot is written once and read once per
 //     tile, and both orders need a barrier between them).  Slots of k-steps 0..2 ("A") are read during k-steps 4, 0, 1 and
-//     written during k-step 2; slots of k-step 3 and of the last 16 k ("B") are read during k-steps 2, 3 and written during
-//     k-step 0; barriers open k-steps 2 and 4;
+//     written during k-step 3 (window: 2, 3); slots of k-step 3 and of the last 16 k ("B") are read during k-steps 2, 3 and
+//     written during k-step 1 (window: 4, 0, 1); barriers open k-steps 2 and 4;
 //   * a wave moves ONE 1-KiB share of A (16 bytes per lane) and ONE 512-byte share of B per tile -- 2 loads + 2 LDS writes per
 //     tile instead of 6 + 6.  A has seven shares: the six 1-KiB pieces and the tile's 16 bias values (64 bytes; the other
 //     lanes of that share are out of the buffer's range, get zeros and write them into padding); waves 6, 7 both move the bias
@@ -32,8 +33,8 @@
 //     v[244:255] behind amdgpu_num_vgpr(244), loads / waits / writes in inline assembly -- the kernel was correct but 1-2 % SLOWER
 //     than this form, and the reservation turned out not to be binding: another instantiation of the same template used v244 / v245
 //     as temporaries.  The W2 pieces are L2 hits 92 % of the time, profiles/r3_pmc_k_conv2h.json.)
-// The x32 -> x16 accumulator hazard of conv2r.hip does not arise: with two accumulator pairs every x16 MFMA's SrcC was written
-// at least four MFMAs earlier.
+// The x32 -> x16 accumulator hazard of conv2r.hip does not arise: with two accumulator pairs the one x16 MFMA per block takes as
+// SrcC an accumulator whose last writer is at least two MFMAs (>= 32 issue cycles) back.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
