@@ -1,9 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3
-( time timeout 900 python bench.py --no-cpu-baseline --steps 4 > gpurun_out/r3/bench_default_4.json 2> gpurun_out/r3/bench_default_4.err ) 2>&1 | grep real
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 1 > gpurun_out/r3/bench_final.json 2> gpurun_out/r3/bench_final.err ) 2>&1 | grep real
 python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r3/bench_default_4.json').read().strip().splitlines()[-1])
-r=d['roofline']; print(d['value'], r['fp32_equivalent_tflops'], r['frac'], r['traffic'], r['traffic_ratio'], r['traffic_counters']); print(r['traffic_source'][:200]); print(d['native_f32']['traffic'], d['native_f32']['traffic_source'][:120])
+d=json.loads(open('gpurun_out/r3/bench_final.json').read().strip().splitlines()[-1])
+r=d['roofline']; print(d['value'], d['value_literal_128x40'], d['ms_per_step'], r['achieved'], r['frac'], r['fp32_equivalent_tflops'], r['traffic'], r['traffic_ratio'], d['cpu_baseline']['value'], d['cpu_baseline']['parity']['lig_rmsd_A'], d['native_f32']['poses_per_sec'])
 PY
-tail -3 gpurun_out/r3/bench_default_4.err
