@@ -576,6 +576,12 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   return rc;
 }
 
+extern "C" int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out) {
+  if (!frag || !bias || !out || !k_out || n_tiles <= 0) return fail(DBFR_ERR_ARG, "dbfr_test_pack_f16_tiles: bad argument");
+  *k_out = pack_f16_tiles(frag, bias, 0, n_tiles, (uint16_t*)out);
+  return DBFR_OK;
+}
+
 extern "C" int dbfr_model_set_gemm(dbfr_model* m, int32_t mode) {
   if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_SPLIT_F16) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
   m->gemm_split = mode;

@@ -427,6 +427,11 @@ int dbfr_wigner3j(int32_t l1, int32_t l2, int32_t l3, double* out);
  * + coeff as float bits in column 9. kind: 0..3 layer convs by depth, 4 final_conv,
  * 5 tor convs.  Returns number of paths (<= max_paths) or a negative status.       */
 int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* weight_numel);
+/* Test hook (host code, no GPU): the tile packer of DBFR_GEMM_SPLIT_F16.  frag = n_tiles x [9 k-steps of 16][64 lanes][4] fp32 MFMA
+ * fragments (K = 144), bias = n_tiles x 16; out = n_tiles x 9280 bytes: [hi, lo][4 k-steps of 32][64 lanes][8 fp16], then
+ * [64 lanes][hi 4 | lo 4 fp16] for the last 16 k, then the 16 bias values (fp32) -- everything multiplied by 2^k, the power of two that
+ * puts the largest |value| of these tiles into [2^14, 2^15).  Returns k in *k_out.                                                     */
+int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out);
 /* Profiling hooks: time (ms) spent in the dominant fused conv kernel and the
  * number of launches + edges since the last reset, measured with hip events on
  * the launch stream when profiling is enabled.  conv_flops = algorithmic FLOP

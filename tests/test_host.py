@@ -300,3 +300,40 @@ def test_library_build_id_matches_the_sources():
     """The in-tree libdbfr.so carries the hash of the sources it was built from (diffbindfr_amd/build.py)."""
     from diffbindfr_amd import build
     assert L.load().dbfr_build_id().decode() == build.source_hash()
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 3e3])
+def test_f16_tile_packer_scales_and_splits_exactly(scale):
+    """DBFR_GEMM_SPLIT_F16's host side (api.cpp pack_f16_tiles through its test hook, no GPU): the tiles of a run are multiplied by ONE
+    power of two that puts their largest magnitude into [2^14, 2^15); hi = fp16(v), lo = fp16(v - hi) then hold v to 2^-22 relative for
+    everything within 2^-17 of the maximum and to 2^-25 absolute below (fp16 subnormals); the last 16 k sit as [hi 4 | lo 4] per lane
+    (the A operand of the one x32 MFMA that carries both small products); the bias rows carry the same factor."""
+    import ctypes as C
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    nt = 5
+    frag = (rng.standard_normal((nt, 9, 64, 4)) * scale).astype(np.float32)
+    frag[1] *= 1e-3                                          # a tile of much smaller rows inside the run
+    frag[2, :, :, 0] = 0.0
+    bias = (rng.standard_normal((nt, 16)) * scale).astype(np.float32)
+    out = np.zeros(nt * 9280, np.uint8)
+    k = C.c_int32()
+    L.check(lib.dbfr_test_pack_f16_tiles(frag.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), nt, out.ctypes.data_as(C.c_void_p), C.byref(k)))
+    s = np.float64(2.0) ** k.value
+    mx = np.abs(frag).max() * s
+    assert 2 ** 14 <= mx < 2 ** 15
+    tiles = out.reshape(nt, 9280)
+    main = tiles[:, :8192].copy().view(np.float16).reshape(nt, 2, 4, 64, 8).astype(np.float64)       # [piece][k-step of 32][lane][8]
+    tail = tiles[:, 8192:9216].copy().view(np.float16).reshape(nt, 64, 2, 4).astype(np.float64)       # [lane][hi | lo][4]
+    b = tiles[:, 9216:9280].copy().view(np.float32).reshape(nt, 16)
+    assert np.array_equal(b, (bias.astype(np.float64) * s).astype(np.float32))
+    want = frag.astype(np.float64) * s                                                                   # [t][s4][lane][q]
+    got = np.empty_like(want)
+    for s4 in range(8):
+        got[:, s4] = main[:, 0, s4 >> 1, :, 4 * (s4 & 1):4 * (s4 & 1) + 4] + main[:, 1, s4 >> 1, :, 4 * (s4 & 1):4 * (s4 & 1) + 4]
+    got[:, 8] = tail[:, :, 0] + tail[:, :, 1]
+    err = np.abs(got - want)
+    assert (err <= np.maximum(np.abs(want) * 2.0 ** -22, 2.0 ** -25)).all(), float((err / np.maximum(np.abs(want), 1e-30)).max())
+    assert np.isfinite(main).all() and np.abs(main[:, 0]).max() < 2 ** 15
+    with pytest.raises(Exception):
+        L.check(lib.dbfr_test_pack_f16_tiles(None, None, 0, None, None))

@@ -1,9 +1,19 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3
-timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 1 > gpurun_out/r3/bench_final.json 2> gpurun_out/r3/bench_final.err ) 2>&1 | grep real
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/r3
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r3/lat -o s -- python $R/tools/latency_run.py --case cfg1 --reps 5 > $R/gpurun_out/r3/lat.log 2>&1
+tail -2 $R/gpurun_out/r3/lat.log | head -1
+head -14 $R/gpurun_out/r3/lat/*kernel_stats.csv | cut -c1-130
 python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r3/bench_final.json').read().strip().splitlines()[-1])
-r=d['roofline']; print(d['value'], d['value_literal_128x40'], d['ms_per_step'], r['achieved'], r['frac'], r['fp32_equivalent_tflops'], r['traffic'], r['traffic_ratio'], d['cpu_baseline']['value'], d['cpu_baseline']['parity']['lig_rmsd_A'], d['native_f32']['poses_per_sec'])
+import csv,glob,os
+R=os.environ['GRAFT_REPO_ROOT']
+rows=list(csv.DictReader(open(glob.glob(R+'/gpurun_out/r3/lat/*kernel_trace.csv')[0])))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+# last run: take last 1/6 of the kernels
+n=len(rows)//6
+last=rows[-n:]
+busy=sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in last)
+span=int(last[-1]['End_Timestamp'])-int(last[0]['Start_Timestamp'])
+print('last run: kernels',n,'busy ms',busy/1e6,'span ms',span/1e6)
 PY
+rm -rf $R/gpurun_out/r3/lat
