@@ -400,8 +400,8 @@ def main():
                                            "center": counters[3], "tor": counters[4], "sc_tor": counters[5]},
                        "weights": "seeded random init of the reference architecture (22.9 M params)",
                        "arithmetic": "fp32 in, fp32 out; radial MLP's 144 x W GEMM: " + PIPE[mode]["arithmetic"],
-                       "parallelism": f"dp{world}: jobs LPT-sharded, poses of a job on one GPU, one all_gather_into_tensor of "
-                                      f"[ligand | atom14] records at the end"},
+                       "parallelism": f"dp{world}: jobs LPT-sharded, poses of a job on one GPU, ragged [ligand | atom14] records gathered at the end "
+                                      f"(all_gather_into_tensor in windows of 256 MiB per rank)"},
             "roofline": roof,
         }
         if native is not None:
