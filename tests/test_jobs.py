@@ -350,3 +350,18 @@ def test_full_size_batch_equals_small_batches_bit_for_bit(cfg_id, n_jobs, poses,
     small = ddist.run_sharded(samp, jobs, poses, seed=3, device=dev, batch_poses=small_batch)
     for (l0, a0), (l1, a1) in zip(big, small):
         assert torch.isfinite(l0).all() and torch.equal(l0, l1) and torch.equal(a0, a1)
+
+
+@pytest.mark.gpu
+def test_host_store_equals_device_store_on_the_gpu():
+    """store='host' (pose records streamed to pinned host memory batch by batch, bounded HBM) gives the very poses of store='device'."""
+    dev = torch.device("cuda:0")
+    _, _, _, samp = _hip(dev)
+    _, jobs = make_jobs(3, 5, 60, 10, seed=6)
+    poses = [3, 2, 7, 1, 2]
+    a = ddist.run_sharded(samp, jobs, poses, seed=4, device=dev, batch_poses=4)
+    b = ddist.run_sharded(samp, jobs, poses, seed=4, device=dev, batch_poses=4, store="host", gather="root")
+    for (l0, a0), (l1, a1) in zip(a, b):
+        assert l1.device.type == "cpu" and l1.is_pinned()
+        assert torch.equal(l0.cpu(), l1) and torch.equal(a0.cpu(), a1)
+    assert all("_dev" not in j.lig.__dict__ for j in jobs)          # halves released after their last batch
