@@ -285,12 +285,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       for (int b = 0; b < 2; ++b) {
         float m2 = fmaxf(mx[b], __shfl_xor(mx[b], 16));
         m2 = fmaxf(m2, __shfl_xor(m2, 32));
-        // H' = f 2^j, f in [0.5, 1)  ->  factor 2^(15 - j) on H' = 2^(15 - j + k1 + 15 - ja) on h; everything clamped so that the
-        // factors and their inverses stay normal fp32 numbers (an edge whose activations are all tiny keeps them as fp16
-        // subnormals or zeros: nothing to lose)
-        const int j = max(-100, min(100, __builtin_amdgcn_frexp_expf(m2)));
-        const float t = __builtin_amdgcn_ldexpf(1.f, 15 - j);
-        const int tot = max(-120, min(120, 15 - j + k1 + 15 - ja[b]));
+        // H' = f 2^j, f in [0.5, 1)  ->  factor 2^(15 - j) on H' = 2^tot on h with tot = 15 - j + k1 + 15 - ja.  tot is what multiplies
+        // the W2 bias (already x 2^k of its run) in the accumulator: it is kept within +-64 so that the product stays a finite fp32
+        // number whatever the activations (an edge whose largest activation is below 2^-49 gets a smaller factor than the window
+        // asks for: its pieces lose relative precision, next to an O(1) bias nothing to lose), and the factor on H' follows from it
+        const int j = __builtin_amdgcn_frexp_expf(m2);
+        const int tot = max(-64, min(64, 15 - j + k1 + 15 - ja[b]));
+        const float t = __builtin_amdgcn_ldexpf(1.f, tot - k1 - 15 + ja[b]);
         se[b] = __builtin_amdgcn_ldexpf(1.f, tot);
         ue[b] = __builtin_amdgcn_ldexpf(1.f, -tot);
 #pragma unroll
