@@ -90,7 +90,7 @@ def test_gpu_examples_follow_the_reference_trajectories(name):
     the reference's over all 20 steps; ONE per fixture departs by 0.01-0.04 A from some step on.  That is the reference algorithm's own
     sensitivity, not an implementation difference: its graphs have hard cutoffs (4 A / 5 A / 0.2 sigma + 5 A) with no envelope on the
     edge features, so a pair within rounding distance of a cutoff enters the graph in one run and not in the other -- the CPU oracle run
-    twice with the initial ligand coordinates moved by N(0, 1e-6 A) shows the same (tools/exp/example_sensitivity.py,
+    twice with the initial ligand coordinates moved by N(0, 1e-6 A) shows the same (tests/tools/example_sensitivity.py,
     profiles/r3_example_sensitivity.txt).  Held here: >= 80 % of the trajectories within 1e-3 A, median below 1e-4 A, every one
     within 0.1 A."""
     from diffbindfr_amd import assemble, dist as ddist

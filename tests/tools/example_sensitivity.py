@@ -7,7 +7,7 @@ twice on the same batch: (A) as frozen -- must reproduce the fixture -- and (B) 
 N(0, 1e-6 A), the size of fp32 rounding at these coordinates.  Per-pose deviation B - A after 20 steps shows whether hard neighbour
 cutoffs (4 A / 5 A / 0.2 sigma + 5 A, no envelope on the edge features) make single trajectories jump under such a change.
 
-    python tools/exp/example_sensitivity.py [forward|reverse] [sigma]     (about 2 x 2 min on 128 host threads)
+    python tests/tools/example_sensitivity.py [forward|reverse] [sigma]     (about 2 x 2 min on 128 host threads)
 """
 import copy
 import os
