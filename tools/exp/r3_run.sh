@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3 | cut -c1-300
-DBFR_GEMM=split_f16 DBFR_CONV2=1 timeout 120 python tools/conv_bench.py --layer 3 --fam 2 --edges 650000 --reps 10 2>&1 | tail -1 | cut -c1-200
+mkdir -p gpurun_out/r3
+timeout 600 python tools/pipeline_bench.py > gpurun_out/r3/pipeline.json 2> gpurun_out/r3/pipeline.err
+tail -c 1500 gpurun_out/r3/pipeline.json; tail -3 gpurun_out/r3/pipeline.err
