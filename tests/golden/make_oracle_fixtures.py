@@ -1,11 +1,12 @@
 """Fixtures the ORACLE generates (no reference needed, so this runs anywhere -- e.g. on the GPU box's 128 host threads):
 
-    python tests/golden/make_oracle_fixtures.py [out_dir]
+    python tests/golden/make_oracle_fixtures.py [out_dir [5] [2]]
 
   cfg5_traj.npz   BASELINE.json configs[4] (large pocket: ~600 pocket atoms / ~80 ligand atoms, flexible side chains), one complex x
                   one pose, all 20 reverse-diffusion steps through oracle/sampler.py (pinned on the reference's own sample(), see
                   make_golden.py): collated batch + noise tape + ligand trajectory + first / last atom14 frame.  Replayed by
-                  tests/test_gpu_parity.py::test_cfg5_shape_trajectory_matches_the_oracle_fixture at 1e-3 A.
+                  tests/test_gpu_parity.py::test_cfg_shape_trajectory_matches_the_oracle_fixture at 1e-3 A.
+  cfg2_traj.npz   the same for configs[1] (PoseBusters shape: ~200 pocket atoms / ~30 ligand atoms) -- the shape the bench line is quoted on.
 """
 import copy
 import os
@@ -25,18 +26,18 @@ def npy(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
 
-def cfg5_trajectory(out_dir):
-    d = synthetic.make_batch(5, n_complex=1, poses=1, seed=505)
+def cfg_trajectory(out_dir, cfg_id, seed, noise_seed):
+    d = synthetic.make_batch(cfg_id, n_complex=1, poses=1, seed=seed)
     G = d.num_graphs
     mcfg = sm.default_cfg()
     params = sm.init_params(mcfg, seed=1)
     scfg = schedule.default_sample_cfg()
     n_tor, n_sc = int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum())
-    noise = sampler.draw_noise(scfg.actual_steps, G, n_tor, n_sc, seed=55)
+    noise = sampler.draw_noise(scfg.actual_steps, G, n_tor, n_sc, seed=noise_seed)
     T = synthetic.residue_tables()
     t0 = time.time()
     lig, a14 = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise, torch.from_numpy(T["atom14_to_group"]).long(), visualize=True)
-    print(f"cfg 5 shape: {int(d.rec_atm_pos.shape[0])} pocket atoms / {int(d.lig_pos.shape[0])} ligand atoms, {scfg.actual_steps} steps through the "
+    print(f"cfg {cfg_id} shape: {int(d.rec_atm_pos.shape[0])} pocket atoms / {int(d.lig_pos.shape[0])} ligand atoms, {scfg.actual_steps} steps through the "
           f"oracle on {torch.get_num_threads()} threads in {time.time() - t0:.0f}s")
     out = {k: npy(v) for k, v in vars(d).items() if torch.is_tensor(v)}
     for g, m in enumerate(d.rot_node_mask):
@@ -46,7 +47,7 @@ def cfg5_trajectory(out_dir):
                traj_lig=npy(lig).astype(np.float32), atom14_step0=npy(a14[0]).astype(np.float32), final_atom14=npy(a14[-1]).astype(np.float32))
     for k in ("default_frame", "rigid_group_positions"):
         out[k] = out[k].astype(np.float32)
-    path = os.path.join(out_dir, "cfg5_traj.npz")
+    path = os.path.join(out_dir, f"cfg{cfg_id}_traj.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB")
 
@@ -54,4 +55,8 @@ def cfg5_trajectory(out_dir):
 if __name__ == "__main__":
     out_dir = sys.argv[1] if len(sys.argv) > 1 else HERE
     os.makedirs(out_dir, exist_ok=True)
-    cfg5_trajectory(out_dir)
+    which = [int(x) for x in sys.argv[2:]] or [5, 2]
+    if 5 in which:
+        cfg_trajectory(out_dir, 5, 505, 55)      # (the arguments cfg5_traj.npz was generated with)
+    if 2 in which:
+        cfg_trajectory(out_dir, 2, 202, 22)

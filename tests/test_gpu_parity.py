@@ -567,17 +567,19 @@ def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, 
     assert err["split_f16"] <= err["f32"] and rms["split_f16"] <= rms["f32"], (err, rms)
 
 
-def test_cfg5_shape_trajectory_matches_the_oracle_fixture(dev):
-    """BASELINE configs[4] at its own shape (~600 pocket atoms / ~80 ligand atoms): tests/golden/cfg5_traj.npz holds one complex x one
-    pose taken through all 20 steps by the ORACLE (tests/golden/make_oracle_fixtures.py, generated offline on host cores).  The HIP
-    sampler must follow the ligand trajectory and end on the same side chains within 1e-3 A, in every GEMM mode."""
+@pytest.mark.parametrize("cfg_id,min_atoms,min_lig", [(5, 500, 60), (2, 150, 20)])
+def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms, min_lig):
+    """BASELINE configs[4] (~600 pocket atoms / ~80 ligand atoms) and configs[1] (~200 / ~30: the shape the bench line is quoted on) at
+    their own shapes: tests/golden/cfg{5,2}_traj.npz hold one complex x one pose taken through all 20 steps by the ORACLE
+    (tests/golden/make_oracle_fixtures.py, generated offline on host cores).  The HIP sampler must follow the ligand trajectory and
+    end on the same side chains within 1e-3 A, in every GEMM mode."""
     import os
     from tests.helpers import GOLDEN
-    path = os.path.join(GOLDEN, "cfg5_traj.npz")
+    path = os.path.join(GOLDEN, f"cfg{cfg_id}_traj.npz")
     if not os.path.exists(path):
-        pytest.skip("cfg5_traj.npz not generated (tests/golden/make_oracle_fixtures.py)")
+        pytest.skip(f"cfg{cfg_id}_traj.npz not generated (tests/golden/make_oracle_fixtures.py)")
     d, z = load_golden_batch(path)
-    assert int(d.rec_atm_pos.shape[0]) >= 500 and int(d.lig_pos.shape[0]) >= 60
+    assert int(d.rec_atm_pos.shape[0]) >= min_atoms and int(d.lig_pos.shape[0]) >= min_lig
     params = sm.init_params(sm.default_cfg(), seed=int(z["params_seed"]))
     model = dba.TensorProductModelHIP({}).to(dev)
     model.load_state_dict(params, strict=True)

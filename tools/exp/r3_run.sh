@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3
-timeout 600 python tools/pipeline_bench.py > gpurun_out/r3/pipeline.json 2> gpurun_out/r3/pipeline.err
-tail -c 1500 gpurun_out/r3/pipeline.json; tail -3 gpurun_out/r3/pipeline.err
+cd $GRAFT_REPO_ROOT
+timeout 900 python tests/golden/make_oracle_fixtures.py gpurun_out/r3 2 2>&1 | grep -v Warning | tail -2
+cp gpurun_out/r3/cfg2_traj.npz tests/golden/
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cfg_shape" 2>&1 | tail -3
