@@ -1,5 +1,9 @@
-mkdir -p gpurun_out/r3
 cd $GRAFT_REPO_ROOT
-timeout 900 python tests/golden/make_oracle_fixtures.py gpurun_out/r3 2 2>&1 | grep -v Warning | tail -2
-cp gpurun_out/r3/cfg2_traj.npz tests/golden/
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "cfg_shape" 2>&1 | tail -3
+mkdir -p gpurun_out/r3
+timeout 900 python bench.py --steps 60 --no-cpu-baseline --no-latency --no-native --no-pmc > gpurun_out/r3/bench_soak60.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r3/bench_soak60.json').read().strip().splitlines()[-1])
+r=d['roofline']; print('soak 60 batches (38 400 poses):', d['value'], d['value_literal_128x40'], r['fp32_equivalent_tflops'], r['frac'])
+PY
+rocm-smi --showtemp 2>&1 | grep -i "junction\|hotspot\|edge" | head -3
