@@ -59,6 +59,10 @@ PIPE = {
     "split_f16": dict(kernel="k_conv2h (persistent; all four convs of an interaction layer, or the two torsion-head convs, per launch): fused radial MLP "
                              "+ tensor product; W2 pieces through an LDS ring, one copy per tile per CU, two barriers per tile",
                       instruction="v_mfma_f32_16x16x32_f16 (+ _16x16x16_f16 for the last 16 k)", products=3, peak=HALF_MATRIX_PEAK_TFLOPS,
+                      hidden_on_pipe=True,
+                      # profiles/r3_mfma_power.txt: what a bare stream of this instruction sustains on this board with random operands
+                      # (the firmware's power management holds it at 2.05 GHz); the nominal peak is reached with all-zero operands only
+                      sustained=1937.0,
                       arithmetic="three fp16 x fp16 partial products per fp32 product (operands scaled by exact powers of two and cut into two fp16 "
                                  "pieces: 23 of 24 significand bits), small and large products in separate fp32 accumulators -- error vs fp64 <= the "
                                  "fp32 MFMA's (max and rms)"),
@@ -328,8 +332,9 @@ def main():
         alg = fl.value / (ms.value * 1e-3) / 1e12            # algorithmic fp32 flops 2*144*(144+W) per edge / kernel time
         P = PIPE[mode]
         # what the named matrix instruction executes: `products` MFMA-flops per algorithmic flop of the 144 x W GEMM (97.6 % of the
-        # conv's flops; the 144 x 144 hidden layer stays on the fp32 instruction inside the same kernel and is not counted here)
-        ex = alg if mode == "f32" else P["products"] * W2_SHARE * alg
+        # conv's flops); in k_conv2r / k_conv2s the 144 x 144 hidden layer stays on the fp32 instruction inside the same kernel and is
+        # not counted, k_conv2h runs it on the same three-product form (W1h tiles)
+        ex = alg if mode == "f32" else P["products"] * (1.0 if P.get("hidden_on_pipe") else W2_SHARE) * alg
         traffic, tsrc, traw = None, "no PMC pass for this workload", None
         live, why = (None, "--no-pmc") if (args.no_pmc or world != 1 or mode != main_mode) else measure_traffic(mode, args)
         if live is not None:
@@ -358,6 +363,11 @@ def main():
                 "kernel": P["kernel"], "instruction": P["instruction"], "products_per_fp32_product": P["products"],
                 "fp32_equivalent_tflops": round(alg, 2), "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS,
                 "fp32_equivalent_over_fp32_matrix_peak": round(alg / FP32_MATRIX_PEAK_TFLOPS, 4),
+                "pipe_sustained_random_operands": P.get("sustained"),
+                "frac_of_sustained": round(ex / P["sustained"], 4) if P.get("sustained") else None,
+                "sustained_note": ("a bare stream of this instruction with random operands, nothing else running, measured on this board model "
+                                   "(tools/exp/mfma_power.hip -> profiles/r3_mfma_power.txt): the power management holds it at 2.05 GHz; the "
+                                   "nominal peak is reached with all-zero operands only") if P.get("sustained") else None,
                 "launches": nl.value, "avg_launch_ms": round(ms.value / nl.value, 4), "flops_per_launch": fl.value / nl.value,
                 "conv_time_share": round(ms.value * 1e-3 / elapsed_s, 4),
                 "algorithmic_bytes_note": "fused form: 4 (48 + 9 + 3 + 48 + 48 + D_in + D_out) B per edge (edge record, two gathered radial-MLP "

@@ -594,10 +594,14 @@ __device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, i
       float v = bw[off + i];
       if (comp == 0) mean[0] += v; else if (comp == 1) mean[1] += v; else mean[2] += v;
     }
+    for (int o = 32; o > 0; o >>= 1) mean[0] += __shfl_xor(mean[0], o);
+    mean[0] /= (float)mul;
+    if (d3) {                              // scalar blocks have one component: two of the three butterflies are skipped (wave-uniform)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      for (int o = 32; o > 0; o >>= 1) mean[c] += __shfl_xor(mean[c], o);
-      mean[c] /= (float)mul;
+      for (int c = 1; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) mean[c] += __shfl_xor(mean[c], o);
+        mean[c] /= (float)mul;
+      }
     }
     float sq = 0.f;
     for (int i = lane; i < nel; i += 64) {
