@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdbfr.so")
 SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "conv2.hip", "conv2s.hip", "conv2r.hip", "conv2h.hip", "graph.hip", "heads.hip", "export.hip", "mdn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("DBFR_BUILD_DEV") == "1":      # developer build: the timing-only kernel variants behind DBFR_CONV*_ABL / _VAR (wrong results)
+    FLAGS.append("-DDBFR_DEV_VARIANTS")
 # conv: no SLP vectorisation -- it pairs the contraction FMAs of different edge blocks into v_pk_fma_f32 with a v_mov
 # shuffle per operand pair, which costs more vector-pipe slots next to the MFMAs than it saves and makes the kernel spill.
 # (-Wno-array-bounds: the NB=1 instantiation indexes per-block arrays of length 1 inside `if (NB > 1)` branches)
@@ -31,9 +33,11 @@ FILE_FLAGS["conv2h.hip"] = FILE_FLAGS["conv2r.hip"]
 DEFAULT_FP = ["-ffp-contract=off"]
 
 
-def source_hash():
+def source_hash(dev=False):
     """sha256 over every file the library is built from (sorted names + contents): compiled into api.cpp as
-    DBFR_BUILD_ID and returned by dbfr_build_id(), so that a test can tell a stale prebuilt .so from the tree it sits in."""
+    DBFR_BUILD_ID and returned by dbfr_build_id(), so that a test can tell a stale prebuilt .so from the tree it sits in.
+    A developer build (DBFR_BUILD_DEV=1) carries another id: tests/test_gpu_parity.py::test_native_library_is_loaded
+    refuses it, and switching between the two rebuilds every object."""
     import hashlib
     h = hashlib.sha256()
     files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip", ".h", ".inc"))])
@@ -41,6 +45,8 @@ def source_hash():
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
+    if dev:
+        h.update(b"DBFR_DEV_VARIANTS")
     return h.hexdigest()[:16]
 
 
@@ -55,7 +61,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "residue_tables.inc"), os.path.join(HERE, "..", "include", "dbfr.h")]
     objs, jobs = [], []
-    bid = source_hash()
+    bid = source_hash(dev="-DDBFR_DEV_VARIANTS" in FLAGS)
     stamp = os.path.join(CSRC, ".build_id")
     if not os.path.exists(stamp) or open(stamp).read() != bid:      # any source changed: api.cpp carries the id
         open(stamp, "w").write(bid)

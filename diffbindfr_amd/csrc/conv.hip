@@ -440,8 +440,10 @@ void launch_conv_layer(const ConvArgs* c4, hipStream_t st) {
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t st) {
-  static int abl = -1;   // developer knob DBFR_CONV_ABL: 1 no contraction, 2 no W2 re-load, 8 prologue only (timing only, wrong results)
+#ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1 python -m diffbindfr_amd.build): timing-only variants, wrong results
+  static int abl = -1;   // DBFR_CONV_ABL: 1 no contraction, 2 no W2 re-load, 8 prologue only
   if (abl < 0) { const char* e = getenv("DBFR_CONV_ABL"); abl = e ? atoi(e) : 0; }
+#endif
   const int te = 16 * CONV_NB;
   const int tiles = (a.max_edges + te - 1) / te;
   if (tiles <= 0) return;
@@ -467,7 +469,10 @@ void launch_conv(const ConvArgs& a, hipStream_t st) {
   }
 #define LAUNCH(KK, AB) hipLaunchKernelGGL((k_conv<KK, CONV_NB, AB>), dim3(tiles), dim3(256), 0, st, b)
   if (a.w.K != 144) { LAUNCH(96, 0); return; }
-  switch (abl) { case 1: LAUNCH(144, 1); break; case 2: LAUNCH(144, 2); break; case 8: LAUNCH(144, 8); break; default: LAUNCH(144, 0); }
+#ifdef DBFR_DEV_VARIANTS
+  switch (abl) { case 1: LAUNCH(144, 1); return; case 2: LAUNCH(144, 2); return; case 8: LAUNCH(144, 8); return; default: break; }
+#endif
+  LAUNCH(144, 0);
 #undef LAUNCH
 }
 

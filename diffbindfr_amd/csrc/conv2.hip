@@ -307,8 +307,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2(Conv2Args a) {
 
 void launch_conv2(const Conv2Args& a, hipStream_t st) {
   static int n_cu = 0;
-  static int run_barrier = getenv("DBFR_CONV2_BARRIER") ? atoi(getenv("DBFR_CONV2_BARRIER")) : 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
+  static int skew = getenv("DBFR_CONV2_SKEW") ? atoi(getenv("DBFR_CONV2_SKEW")) : 0;
   constexpr int NW = 8;
   const size_t lds = (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
   if (!n_cu) {
@@ -316,23 +316,24 @@ void launch_conv2(const Conv2Args& a, hipStream_t st) {
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<NW, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  static int skew = getenv("DBFR_CONV2_SKEW") ? atoi(getenv("DBFR_CONV2_SKEW")) : 0;
   Conv2Args b = a;
   b.skew = skew;
-  b.run_barrier = run_barrier;
+  b.run_barrier = 0;
   b.no_split = no_split;
+  // (the LDS attribute is set on every launch: it is per device, and a process may drive several)
+#define GO(...) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                     hipLaunchKernelGGL((k_conv2<__VA_ARGS__>), dim3(n_cu), dim3(64 * NW), lds, st, b); } while (0)
+#ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1): barrier placements and timing-only ablations (wrong results)
+  static int run_barrier = getenv("DBFR_CONV2_BARRIER") ? atoi(getenv("DBFR_CONV2_BARRIER")) : 0;
   static int abl = getenv("DBFR_CONV2_ABL") ? atoi(getenv("DBFR_CONV2_ABL")) : 0;
-  if (abl == 1) hipLaunchKernelGGL((k_conv2<NW, 0, 1>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 2) hipLaunchKernelGGL((k_conv2<NW, 0, 2>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (abl == 3) hipLaunchKernelGGL((k_conv2<NW, 0, 3>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (run_barrier == 3) hipLaunchKernelGGL((k_conv2<NW, 3>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else if (run_barrier == 2) hipLaunchKernelGGL((k_conv2<NW, 2>), dim3(n_cu), dim3(64 * NW), lds, st, b);
-  else hipLaunchKernelGGL((k_conv2<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
+  b.run_barrier = run_barrier;
+  if (abl == 1) { GO(NW, 0, 1); return; }
+  if (abl == 2) { GO(NW, 0, 2); return; }
+  if (abl == 3) { GO(NW, 0, 3); return; }
+  if (run_barrier == 3) { GO(NW, 3); return; }
+  if (run_barrier == 2) { GO(NW, 2); return; }
+#endif
+  GO(NW, 0);
+#undef GO
 }

@@ -582,7 +582,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
 void launch_conv2h(const Conv2Args& a, hipStream_t st) {
   static int n_cu = 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
-  static int abl = getenv("DBFR_CONV2H_ABL") ? atoi(getenv("DBFR_CONV2H_ABL")) : 0;   // developer ablations (wrong results)
   constexpr int NW = 8;
   const size_t lds = CH_RING_BYTES + (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
   if (!n_cu) {
@@ -595,11 +594,14 @@ void launch_conv2h(const Conv2Args& a, hipStream_t st) {
   b.skew = 0;
   b.run_barrier = 0;
   b.no_split = no_split;
-#define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                         hipLaunchKernelGGL((k_conv2h<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
-  V(1) V(2) V(3) V(4) V(7) V(8) V(16) V(32) V(64) V(256) V(512)
+  // (the LDS attribute is set on every launch: it is per device, and a process may drive several)
+#define V(x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               hipLaunchKernelGGL((k_conv2h<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
+#ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1 python -m diffbindfr_amd.build): the ABL variants of the kernel's header comment
+  static int abl = getenv("DBFR_CONV2H_ABL") ? atoi(getenv("DBFR_CONV2H_ABL")) : 0;
+  if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 3) V(3) if (abl == 4) V(4) if (abl == 7) V(7) if (abl == 8) V(8) if (abl == 16) V(16)
+  if (abl == 32) V(32) if (abl == 64) V(64) if (abl == 256) V(256) if (abl == 512) V(512)
+#endif
+  V(0)
 #undef V
-  // (set on every launch: the attribute is per device, and a process may drive several)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_conv2h<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
 }

@@ -516,7 +516,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
 void launch_conv2r(const Conv2Args& a, hipStream_t st) {
   static int n_cu = 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
-  static int abl = getenv("DBFR_CONV2R_ABL") ? atoi(getenv("DBFR_CONV2R_ABL")) : 0;   // developer ablations (wrong results)
   constexpr int NW = 8;
   const size_t lds = C3_RING_BYTES + (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
   if (!n_cu) {
@@ -524,15 +523,18 @@ void launch_conv2r(const Conv2Args& a, hipStream_t st) {
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   Conv2Args b = a;
   b.skew = 0;
   b.run_barrier = 0;
   b.no_split = no_split;
-#define V(x) if (abl == x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                         hipLaunchKernelGGL((k_conv2r<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
-  V(1) V(2) V(34) V(64) V(128)
+  // (the LDS attribute is set on every launch: it is per device, and a process may drive several)
+#define V(x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+               hipLaunchKernelGGL((k_conv2r<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
+#ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1): timing-only ablations (wrong results)
+  static int abl = getenv("DBFR_CONV2R_ABL") ? atoi(getenv("DBFR_CONV2R_ABL")) : 0;
+  if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 34) V(34) if (abl == 64) V(64) if (abl == 128) V(128)
+#endif
+  V(0)
 #undef V
-  hipLaunchKernelGGL((k_conv2r<NW, 0>), dim3(n_cu), dim3(64 * NW), lds, st, b);
 }

@@ -444,33 +444,21 @@ void launch_conv2s(const Conv2Args& a, hipStream_t st) {
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  static int var = getenv("DBFR_CONV2S_VAR") ? atoi(getenv("DBFR_CONV2S_VAR")) : 0;   // developer: 10 RB + ABL
   Conv2Args b = a;
   b.skew = skew;
   b.run_barrier = 0;
   b.no_split = no_split;
-  const dim3 gr(n_cu), bl(64 * NW);
+  // (the LDS attribute is set on every launch: it is per device, and a process may drive several)
+#define GO(RB, AB) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2s<NW, RB, AB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                     hipLaunchKernelGGL((k_conv2s<NW, RB, AB>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
+#ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1): DBFR_CONV2S_VAR = 10 RB + ABL (barrier placement, timing-only ablations)
+  static int var = getenv("DBFR_CONV2S_VAR") ? atoi(getenv("DBFR_CONV2S_VAR")) : 0;
   switch (var) {
-    case 20: hipLaunchKernelGGL((k_conv2s<NW, 2, 0>), gr, bl, lds, st, b); break;
-    case 22: hipLaunchKernelGGL((k_conv2s<NW, 2, 2>), gr, bl, lds, st, b); break;
-    case 1: hipLaunchKernelGGL((k_conv2s<NW, 0, 1>), gr, bl, lds, st, b); break;
-    case 2: hipLaunchKernelGGL((k_conv2s<NW, 0, 2>), gr, bl, lds, st, b); break;
-    case 3: hipLaunchKernelGGL((k_conv2s<NW, 0, 3>), gr, bl, lds, st, b); break;
-    case 4: hipLaunchKernelGGL((k_conv2s<NW, 0, 4>), gr, bl, lds, st, b); break;
-    case 8: hipLaunchKernelGGL((k_conv2s<NW, 0, 8>), gr, bl, lds, st, b); break;
-    case 16: hipLaunchKernelGGL((k_conv2s<NW, 0, 16>), gr, bl, lds, st, b); break;
-    case 32: hipLaunchKernelGGL((k_conv2s<NW, 0, 32>), gr, bl, lds, st, b); break;
-    default: hipLaunchKernelGGL((k_conv2s<NW, 0, 0>), gr, bl, lds, st, b); break;
+    case 20: GO(2, 0) case 22: GO(2, 2) case 1: GO(0, 1) case 2: GO(0, 2) case 3: GO(0, 3) case 4: GO(0, 4)
+    case 8: GO(0, 8) case 16: GO(0, 16) case 32: GO(0, 32) default: break;
   }
+#endif
+  GO(0, 0)
+#undef GO
 }

@@ -1,7 +1,8 @@
 """Developer micro-benchmark of ONE fused tensor-product conv through the C ABI test hook (dbfr_test_conv): random
 node features / edges of a given count, HIP-event timing, algorithmic TFLOP/s = 2 K (K + W) E / t.
     DBFR_CONV2=1 python tools/conv_bench.py --layer 3 --fam 2 --edges 650000
-The knobs of the kernels are environment variables read by the library (DBFR_CONV2, DBFR_CONV2_BARRIER, ...)."""
+The knobs of the kernels are environment variables read by the library (DBFR_CONV2, DBFR_GEMM, ...); the timing-only
+variants (DBFR_CONV2_BARRIER, DBFR_CONV*_ABL, DBFR_CONV2S_VAR) need a developer build: DBFR_BUILD_DEV=1 python -m diffbindfr_amd.build."""
 import argparse
 import ctypes as C
 import os
