@@ -378,7 +378,14 @@ static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int
   for (size_t i = (size_t)tile0 * KT * 256; i < (size_t)(tile0 + nt) * KT * 256; ++i) mx = std::max(mx, fabsf(frag[i]));
   int e = 0;
   if (mx > 0.f) (void)frexpf(mx, &e);            // mx = f 2^e, f in [0.5, 1)
-  const int k = mx > 0.f ? std::max(-120, std::min(120, 15 - e)) : 0;
+  int k = mx > 0.f ? std::max(-120, std::min(120, 15 - e)) : 0;
+  // the bias rows carry 2^k too and meet the per-edge factor (at most 2^64, conv2h.hip) in the accumulator, and the accumulator meets
+  // the input features in the contraction: keep |bias| 2^k below 2^48 so that all of it stays a finite fp32 number however small the
+  // weights of the run are next to its bias (never binding for weights and biases of comparable size; a run it binds for loses
+  // relative precision in its pieces, nothing else)
+  float bmx = 0.f;
+  for (int i = 16 * tile0; i < 16 * (tile0 + nt); ++i) bmx = std::max(bmx, fabsf(bias16[i]));
+  if (bmx > 0.f) { int eb = 0; (void)frexpf(bmx, &eb); k = std::min(k, 48 - eb); }
   const float sc = ldexpf(1.f, k);
   for (int t = tile0; t < tile0 + nt; ++t) {
     float b[16];

@@ -497,6 +497,28 @@ def _run_conv_hook(fn, h, layer, fam, c, E, dev):
     return msg
 
 
+@pytest.mark.gpu
+def test_split_f16_vanishing_weights_next_to_an_ordinary_bias(setup, dev):
+    """A conv whose lin.3 weights are 1e-30 of their usual size while its bias is not: the run factors of the W2h tiles stop where the
+    bias rows would leave fp32's range under the per-edge factor (api.cpp pack_f16_tiles), so the messages stay finite and equal the
+    fp32 instruction's (which are the bias-only messages to fp32 accuracy)."""
+    mcfg, p, _ = setup
+    p2 = {k: v.clone() for k, v in p.items()}
+    p2["atom_conv_layers.3.fc.lin.3.weight"] *= 1e-30
+    assert float(p2["atom_conv_layers.3.fc.lin.3.bias"].abs().max()) > 0
+    model = dba.TensorProductModelHIP({}).to(dev)
+    model.load_state_dict(p2, strict=True)
+    lib, h = L.load(), model.handle(dev)
+    layer, fam, E = 3, 2, 6000
+    c = _random_conv_inputs(dev, layer, E)
+    with gemm(model, "f32"):
+        ref = _run_conv_hook(lib.dbfr_test_conv, h, layer, fam, c, E, dev)
+    with gemm(model, "split_f16"):
+        a = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E, dev)
+    assert torch.isfinite(a).all() and torch.isfinite(ref).all() and float(ref.abs().max()) > 1e-3
+    assert float((a - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
 CONV_CASES = [(3, 2, 70000), (0, 0, 5000), (4, 1, 1234), (-2, 0, 20000)]
 
 

@@ -337,3 +337,23 @@ def test_f16_tile_packer_scales_and_splits_exactly(scale):
     assert np.isfinite(main).all() and np.abs(main[:, 0]).max() < 2 ** 15
     with pytest.raises(Exception):
         L.check(lib.dbfr_test_pack_f16_tiles(None, None, 0, None, None))
+
+
+def test_f16_tile_packer_keeps_the_bias_finite_next_to_tiny_weights():
+    """A run of vanishing weights next to an O(1) bias: the factor stops where |bias| 2^k reaches 2^48, so that the bias times the
+    kernel's per-edge factor (<= 2^64) times an input feature is still a finite fp32 number; an all-zero run gets the factor 1."""
+    import ctypes as C
+    lib = L.load()
+    rng = np.random.default_rng(4)
+    nt = 2
+    frag = (rng.standard_normal((nt, 9, 64, 4)) * 1e-30).astype(np.float32)
+    bias = rng.standard_normal((nt, 16)).astype(np.float32) * 3.0
+    out = np.zeros(nt * 9280, np.uint8)
+    k = C.c_int32()
+    L.check(lib.dbfr_test_pack_f16_tiles(frag.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), nt, out.ctypes.data_as(C.c_void_p), C.byref(k)))
+    b = out.reshape(nt, 9280)[:, 9216:9280].copy().view(np.float32)
+    assert 2.0 ** 47 <= np.abs(b).max() < 2.0 ** 48 and np.isfinite(b * np.float32(2.0 ** 64)).all()
+    assert np.array_equal(b.reshape(nt, 16), (bias.astype(np.float64) * 2.0 ** k.value).astype(np.float32))
+    frag[:] = 0
+    L.check(lib.dbfr_test_pack_f16_tiles(frag.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), nt, out.ctypes.data_as(C.c_void_p), C.byref(k)))
+    assert k.value == 0
