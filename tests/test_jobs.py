@@ -335,6 +335,48 @@ def test_two_ranks_on_one_gpu_reproduce_one_rank_bit_for_bit(tmp_path, cfg_id):
             assert np.array_equal(one[k], two[k]), (r, k)
 
 
+_RCCL_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from diffbindfr_amd import dist as ddist
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+local = torch.arange(1000, device=dev, dtype=torch.float32) * 0.5
+for mode in ("all", "root"):                       # the driver's windowed gather exactly as run_sharded calls it under RCCL
+    for window in (256, 4096):
+        out = ddist._gather_windows(local, [1000], 1, 0, mode, window, dev)
+        assert len(out) == 1 and torch.equal(out[0], local), (mode, window)
+host = local.cpu().pin_memory()                    # store="host": pinned records staged through a device window
+out = ddist._gather_windows(host, [1000], 1, 0, "all", 300, dev)
+assert torch.equal(out[0], host)
+buf = torch.empty(1000, device=dev)
+dist.all_gather_into_tensor(buf, local)
+assert torch.equal(buf, local)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)     # bench.py's max-over-ranks + barrier
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t) == 1.5
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl-ok")
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_backend_runs_the_drivers_collectives_on_one_rank(tmp_path):
+    """The `nccl` (= RCCL) backend itself, as far as a 1-GPU box allows: a single-rank process group on cuda:0 through the very calls of
+    the multi-GPU path -- `_gather_windows` in both modes (device records and pinned host records through a device window),
+    `all_gather_into_tensor`, the float64 MAX all-reduce of bench.py's timing and the barrier.  (Two ranks cannot share one GPU under
+    RCCL; the 2- and 8-rank runs of this file use gloo.)"""
+    script = tmp_path / "rccl.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg_id,n_jobs,poses,small_batch", [(2, 16, 40, 160), (5, 2, 20, 20)])
 def test_full_size_batch_equals_small_batches_bit_for_bit(cfg_id, n_jobs, poses, small_batch):
