@@ -271,6 +271,13 @@ def main():
     ap.add_argument("--cpu-batched-steps", type=int, default=5)
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too -- RCCL prints its version banner to the C stdout of
+    # rank 0, block-buffered, i.e. it would land BEHIND the line when the process exits -- so file descriptor 1 is pointed at stderr for
+    # the whole run and the line goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank, world, local = ddist.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -411,7 +418,8 @@ def main():
                        "weights": "seeded random init of the reference architecture (22.9 M params)",
                        "arithmetic": "fp32 in, fp32 out; radial MLP's 144 x W GEMM: " + PIPE[mode]["arithmetic"],
                        "parallelism": f"dp{world}: jobs LPT-sharded, poses of a job on one GPU, ragged [ligand | atom14] records gathered at the end "
-                                      f"(all_gather_into_tensor in windows of 256 MiB per rank)"},
+                                      f"(all_gather_into_tensor in windows of 256 MiB per rank)",
+                       "dist_backend": (ddist.dist.get_backend() if ddist.dist.is_initialized() else None)},
             "roofline": roof,
         }
         if native is not None:
@@ -429,9 +437,9 @@ def main():
             # cfg 1 literally = ONE complex x its 4 poses: (a) one pose through all 20 steps (parity), (b) the 4 poses in one call for 5 steps
             line["cpu_baseline"] = cpu_baseline(args.config, samp, dev, n_poses=args.cpu_poses or 1,
                                                 batched={1: (1, 4), 5: None}.get(args.config, (2, 2)), batched_steps=args.cpu_batched_steps)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+        print(json.dumps(line), file=line_out, flush=True)
+    import torch.distributed as dist
+    if dist.is_initialized():      # N > 1 (or the one-rank walk of the collectives, DBFR_DIST_SINGLE=1)
         dist.barrier()
         dist.destroy_process_group()
 

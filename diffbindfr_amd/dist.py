@@ -14,12 +14,22 @@ import torch
 import torch.distributed as dist
 
 
+def _single():
+    """DBFR_DIST_SINGLE=1: developer switch -- form a process group and run every collective even with ONE rank, so that the multi-GPU
+    path (RCCL calls included) can be walked end to end on a 1-GPU box: `DBFR_DIST_SINGLE=1 python bench.py`."""
+    return os.environ.get("DBFR_DIST_SINGLE") == "1"
+
+
+def _active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _single())
+
+
 def init(backend=None):
-    """Initialise from the torchrun environment (RANK/WORLD_SIZE/MASTER_*); no-op for 1 process."""
+    """Initialise from the torchrun environment (RANK/WORLD_SIZE/MASTER_*); no-op for 1 process (unless DBFR_DIST_SINGLE=1)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _single()) and not dist.is_initialized():
         # dmabuf IPC is the only mode the host driver supports (RCCL's hipIpcGetMemHandle fails otherwise); must be in the
         # environment before the HSA runtime starts, i.e. before the first device call of this process
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -27,7 +37,12 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         # DBFR_DIST_BACKEND=gloo: developer override to walk the multi-rank path on a box with fewer GPUs than ranks
         backend = backend or os.environ.get("DBFR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":     # one rank per GPU: bind the communicator to this rank's device up front (no "guessing device ID" at the
+            dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))   # first barrier, errors surface here and not mid-run)
+            torch.cuda.set_device(dev)
+            kw["device_id"] = dev
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         if rank == 0:       # one line, so that an RCCL start-up failure can be told from a sampler failure in the driver's log
             ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
             print(f"[dbfr.dist] backend={backend} (nccl = RCCL on ROCm) world={world} devices_visible={ndev} "
@@ -59,7 +74,7 @@ def shard_lpt(costs, world):
 
 def gather_records(local, world=None):
     """all_gather of equally-shaped per-rank record tensors [n, R] -> [world*n, R] on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return local
     world = world or dist.get_world_size()
     dev = local.device
@@ -72,7 +87,7 @@ def gather_records(local, world=None):
 
 def gather_ragged(local, n_valid):
     """Gather record tensors whose leading dim differs per rank: pad to the max, gather, trim."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return local[:n_valid]
     world = dist.get_world_size()
     n = torch.tensor([n_valid], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else local.device)
@@ -86,7 +101,7 @@ def gather_ragged(local, n_valid):
 
 
 def max_over_ranks(x, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return float(x)
     t = torch.tensor([float(x)], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -94,7 +109,7 @@ def max_over_ranks(x, device):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
@@ -235,7 +250,7 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
                         half.release()
         if on_batch is not None:
             on_batch(bi, sum(n for _, _, n in batch))
-    if world > 1 and mode:
+    if _active() and mode:
         gloo = dist.get_backend() == "gloo"
         stage = torch.device("cpu") if gloo else dev
         bufs = _gather_windows(local, n_flt, world, rank, mode, max(1, int(window_bytes) // 4), stage)

@@ -378,6 +378,22 @@ def test_rccl_backend_runs_the_drivers_collectives_on_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_line_through_rccl_on_one_rank():
+    """`DBFR_DIST_SINGLE=1 python bench.py`: the whole N > 1 code path of bench.py -- process group, barriers, run_sharded's windowed
+    all_gather of the real sampler's records, max over ranks -- with the `nccl` backend and ONE rank (what a 1-GPU box can run of it)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", DBFR_DIST_SINGLE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--batch-poses", "80",
+                        "--no-cpu-baseline", "--no-latency", "--no-native", "--no-pmc"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(lines[0])
+    assert line["config"]["dist_backend"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["poses_total"] == 80 and "backend=nccl" in r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg_id,n_jobs,poses,small_batch", [(2, 16, 40, 160), (5, 2, 20, 20)])
 def test_full_size_batch_equals_small_batches_bit_for_bit(cfg_id, n_jobs, poses, small_batch):
     """BASELINE-sized batches (cfg 2: 16 complexes x 40 poses = the bench batch; cfg 5: 40 poses of 600-atom pockets) take the
