@@ -219,6 +219,22 @@ def test_capacity_overflow_is_reported(setup, dev):
         model._ws = {}
 
 
+def test_non_finite_inputs_are_reported_not_returned(setup, dev):
+    """include/dbfr.h: DBFR_ERR_NUMERIC.  A NaN ligand coordinate makes the global scores non-finite; the device sets its status word
+    (k_trrot) and the host raises -- no silent garbage poses (the reference would return NaNs)."""
+    mcfg, params, model = setup
+    d, _ = load_golden_batch()
+    sc = osched.step_scalars(osched.default_sample_cfg(), 0)
+    dd = osampler.set_time(copy.deepcopy(d), sc, d.num_graphs)
+    dd.lig_pos = dd.lig_pos.clone()
+    dd.lig_pos[0, 0] = float("nan")
+    with pytest.raises(L.DbfrError, match="NUMERIC"):
+        model(namespace_to(dd, dev))
+    # the handle stays usable: the same call with finite inputs right after
+    good = model(namespace_to(osampler.set_time(copy.deepcopy(d), sc, d.num_graphs), dev))
+    assert all(torch.isfinite(x).all() for x in good if x is not None)
+
+
 def test_sampler_resumes_after_capacity_overflow(setup, dev):
     """Budgets far too small for the golden batch: the sampler must grow them step by step (the device freezes the
     poses at the step that overflowed and the host resumes there) and still reproduce the reference's trajectory."""
