@@ -203,7 +203,7 @@ def assemble(records, poses, device):
     i32 = torch.int32
     T = {}
     # ---------------- ligand atoms
-    a_src, a_graph, lig_ptr = _tile(cntl(lambda r: r.n_l), lg, dev)
+    a_src, _, lig_ptr = _tile(cntl(lambda r: r.n_l), lg, dev)
     T["lig_ptr"] = lig_ptr.to(i32)
     T["lig_node"] = catl("lig_node")[a_src].contiguous()
     T["lig_pos"] = catl("lig_pos")[a_src].contiguous()
