@@ -19,7 +19,10 @@ __device__ __forceinline__ f16x8 rnd(unsigned seed, bool zero) {
   return __builtin_bit_cast(f16x8, v);
 }
 
-template <int SHAPE, int LDSRD>
+// ORDER (SHAPE 0 only): 0 = k_conv2h's order within a k-step (hi_w lo_h0, hi_w lo_h1, lo_w hi_h0, lo_w hi_h1, hi_w hi_h0, hi_w hi_h1: three
+// of six consecutive MFMAs share an operand register with their predecessor), 1 = every consecutive pair shares one (hi_w lo_h0, hi_w lo_h1,
+// hi_w hi_h1, lo_w hi_h1, lo_w hi_h0, hi_w hi_h0) -- does operand reuse between consecutive MFMAs lower the power?
+template <int SHAPE, int LDSRD, int ORDER = 0>
 __global__ __launch_bounds__(512, 1) void k(float* out, int iters, int zero) {
   __shared__ __attribute__((aligned(16))) char frag[32 * 1024];
   const int lane = threadIdx.x & 63;
@@ -46,12 +49,27 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters, int zero) {
           __builtin_amdgcn_sched_barrier(0);
         }
         // two edge blocks x (hi*lo, lo*hi -> small accumulator; hi*hi -> large accumulator)
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[j + 1], acc[0], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[(j + 5) & 7], acc[2], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[j], acc[0], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[(j + 4) & 7], acc[2], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[j], acc[1], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[(j + 4) & 7], acc[3], 0, 0, 0);
+        if (ORDER == 0) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[j + 1], acc[0], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[(j + 5) & 7], acc[2], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[j], acc[0], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[(j + 4) & 7], acc[2], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[j], acc[1], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[(j + 4) & 7], acc[3], 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[j + 1], acc[0], 0, 0, 0);            // hi_w lo_h0
+          __builtin_amdgcn_sched_barrier(0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[(j + 5) & 7], acc[2], 0, 0, 0);      // hi_w lo_h1   (A kept)
+          __builtin_amdgcn_sched_barrier(0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[(j + 4) & 7], acc[3], 0, 0, 0);      // hi_w hi_h1   (A kept)
+          __builtin_amdgcn_sched_barrier(0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[(j + 4) & 7], acc[2], 0, 0, 0);      // lo_w hi_h1   (B kept)
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, B[j], acc[0], 0, 0, 0);                // lo_w hi_h0   (A kept)
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, B[j], acc[1], 0, 0, 0);                // hi_w hi_h0   (B kept)
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if ((it & 63) == 63) for (int q = 0; q < 4; ++q) acc[q] *= 1e-3f;
     }
@@ -105,6 +123,16 @@ int main(int argc, char** argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 8.0;
   float* out; hipMalloc(&out, 256 * 512 * 4);
 #define L(S, R, Z) [&](int iters) { hipLaunchKernelGGL((k<S, R>), dim3(256), dim3(512), 0, 0, out, iters, Z); }
+#define LO(R, O) [&](int iters) { hipLaunchKernelGGL((k<0, R, O>), dim3(256), dim3(512), 0, 0, out, iters, 0); }
+  if (argc > 2) {   // operand-reuse order probe
+    for (int rep = 0; rep < 2; ++rep) {
+      run("order 0 (kernel's), registers", LO(0, 0), seconds);
+      run("order 1 (every pair shares an operand), registers", LO(0, 1), seconds);
+      run("order 0 (kernel's), W fragments from LDS one k-step ahead", LO(2, 0), seconds);
+      run("order 1 (every pair shares an operand), LDS one k-step ahead", LO(2, 1), seconds);
+    }
+    return 0;
+  }
   run("16x16x32 f16, operands in registers, random data", L(0, 0, 0), seconds);
   run("32x32x16 f16, operands in registers, random data", L(1, 0, 0), seconds);
   run("16x16x32 f16, W fragments from LDS, random data", L(0, 1, 0), seconds);
