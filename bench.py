@@ -229,9 +229,11 @@ def measure_traffic(mode, args):
 
 def latency_leg(samp, dev, lib, model):
     """BASELINE configs[0] literally, as predict.py is used: ONE complex of the 3DBS shape x 4 poses x 20 steps
-    (records resident, assemble + init + sample + status sync timed), and predict.py's `-bs 16` of the cfg-2 shape."""
+    (records resident, assemble + init + sample + status sync timed), predict.py's `-bs 16` of the cfg-2 shape, and the shape of the
+    ONE sampler timing the reference publishes (notebooks/AF2_model_docking.ipynb, 1 complex x 40 poses x 20 steps
+    in 76.1 s = 0.53 poses/s on an unnamed CUDA GPU with trained weights -- another pocket, another GPU: context, not a baseline)."""
     out = {}
-    for name, cfg_id, n_c, ppc in (("cfg1_1x4", 1, 1, 4), ("cfg2_bs16", 2, 4, 4)):
+    for name, cfg_id, n_c, ppc in (("cfg1_1x4", 1, 1, 4), ("cfg2_bs16", 2, 4, 4), ("cfg1_1x40_notebook_shape", 1, 1, 40)):
         jobs = make_jobs(cfg_id, n_c, seed=77)
         for j in jobs:
             j.lig.dev(dev), j.pocket.dev(dev)
@@ -251,6 +253,8 @@ def latency_leg(samp, dev, lib, model):
         tf = fl.value / reps / dt / 1e12
         out[name] = {"poses": n_c * ppc, "seconds": round(dt, 4), "poses_per_sec": round(n_c * ppc / dt, 2),
                      "conv_tflops_over_wall": round(tf, 2), "frac_of_fp32_matrix_peak": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
+    out["cfg1_1x40_notebook_shape"]["reference_notebook"] = ("76.1 s = 0.53 poses/s for 1 complex x 40 poses x 20 steps on an unnamed CUDA GPU "
+                                                             "(notebooks/AF2_model_docking.ipynb:274-281; BASELINE.md section 1) -- context only")
     return out
 
 
