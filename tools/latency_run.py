@@ -19,7 +19,7 @@ ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg_id, n_c, ppc = {"cfg1": (1, 1, 4), "bs16": (2, 4, 4), "bs40": (2, 1, 40), "p80": (2, 2, 40), "p160": (2, 4, 40), "p320": (2, 8, 40),
-                    "c5p16": (5, 1, 16)}[a.case]
+                    "c5p16": (5, 1, 16), "cfg1x40": (1, 1, 40)}[a.case]
 model = bench.seeded_params().to(dev)
 samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
 jobs = bench.make_jobs(cfg_id, n_c, seed=77)
