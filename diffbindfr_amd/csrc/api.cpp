@@ -33,6 +33,7 @@ struct GraphArgs {
   int step, lds_nl, lds_na, n_chunk;
 };
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
+void launch_edge_log(const GraphArgs& A, int* log_row, hipStream_t st);
 void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
                           int* tor_batch, int* sc_batch, hipStream_t st);
 void launch_time_embed(const float* t, int G, float emb_scale, float* temb, hipStream_t st);
@@ -87,6 +88,31 @@ static thread_local std::string g_err;
 void dbfr_set_error(const std::string& s) { g_err = s; }
 static int fail(int code, const std::string& s) { g_err = s; return code; }
 
+static thread_local bool g_launch_err = false;
+bool dbfr_launch_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return false;
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  g_launch_err = true;
+  return true;
+}
+// entry points call this behind their launches: a launcher that gave up (dbfr_launch_check) makes the call fail with DBFR_ERR_HIP
+static int take_launch_error() {
+  if (!g_launch_err) return DBFR_OK;
+  g_launch_err = false;
+  return DBFR_ERR_HIP;
+}
+int dbfr_current_cu_count() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cache[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev] = n;
+  }
+  return cache[dev];
+}
+
 // DBFR_GEMM = f32 | split: which matrix instruction carries the 144 x W GEMM of the K=144 convs (dbfr_model_set_gemm overrides)
 static int gemm_from_env() {
   const char* e = getenv("DBFR_GEMM");
@@ -108,6 +134,9 @@ struct dbfr_model {
   int conv_fuse;       // big batches: the four convs of a layer as one k_conv grid (conv.hip: k_conv_layer)
   int conv2_layers;    // big batches: interaction layers [0, conv2_layers) still go through k_conv2 (their short W2 favours it)
   int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
+  std::string fallback_convs;   // ';'-separated names of the convs whose weights two fp16 pieces cannot hold (dbfr_model_fallback_convs)
+  uint32_t layer_fallback;      // bit l: interaction layer l goes through k_conv2r in DBFR_GEMM_SPLIT_F16 mode; bit 31: the torsion heads
+  int* edge_log; int edge_log_steps;   // dbfr_model_set_edge_log: caller-owned device buffer [steps][6][G], or null
   Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
   Mlp2 tr_final, rot_final, tor_final, sc_final;
   const float* atom_emb[5]; int atom_dims[5];
@@ -370,7 +399,12 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
 // for the last 16 k (one 16-byte fragment per lane: the A operand of the x32 MFMA that carries both small products of those 16 k,
 // its first half the A operand of the x16 MFMA of the large one), then the tile's 16 bias values (fp32) x 2^k = 9280 B.
 #define CH_TILE_BYTES_HOST 9280
-static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int nt, uint16_t* out) {
+// *depth (may be null) receives the largest d over the rows of these tiles with row maximum 2^(15 - d) after scaling (0 for the row that
+// sets the factor): a row with d <= F16_ROW_DEPTH_OK keeps 22 significant bits in its two pieces, a deeper one loses one bit per step
+// (relative error 2^(d - 40) of the row's own dot product) -- the model routes such a conv to the three-bf16-piece kernel (bf16 has
+// fp32's exponent range), see fallback_convs.
+#define F16_ROW_DEPTH_OK 17
+static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int nt, uint16_t* out, int* depth = nullptr) {
   constexpr int KT = 9;
   const size_t tile_h = CH_TILE_BYTES_HOST / 2, tail_off = 8192 / 2, bias_off = 9216 / 2;
   auto h16 = [](float v) { const _Float16 h = (_Float16)v; uint16_t u; memcpy(&u, &h, 2); return u; };
@@ -387,6 +421,18 @@ static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int
   for (int i = 16 * tile0; i < 16 * (tile0 + nt); ++i) bmx = std::max(bmx, fabsf(bias16[i]));
   if (bmx > 0.f) { int eb = 0; (void)frexpf(bmx, &eb); k = std::min(k, 48 - eb); }
   const float sc = ldexpf(1.f, k);
+  if (depth) {
+    int dmax = 0;
+    for (int t = tile0; t < tile0 + nt; ++t)
+      for (int row = 0; row < 16; ++row) {
+        float rm = 0.f;
+        for (int s4 = 0; s4 < KT; ++s4)
+          for (int gq = 0; gq < 4; ++gq)
+            for (int q = 0; q < 4; ++q) rm = std::max(rm, fabsf(frag[(((size_t)t * KT + s4) * 64 + 16 * gq + row) * 4 + q]));
+        if (rm > 0.f) { int er = 0; (void)frexpf(rm, &er); dmax = std::max(dmax, 15 - (er + k)); }   // (all-zero rows: padded channels)
+      }
+    *depth = dmax;
+  }
   for (int t = tile0; t < tile0 + nt; ++t) {
     float b[16];
     for (int i = 0; i < 16; ++i) b[i] = bias16[16 * t + i] * sc;
@@ -545,9 +591,12 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   {   // ... and into TWO fp16 pieces (conv2h.hip), run by run (a run = the tiles of one tensor-product path of one channel group):
       // pack_f16_tiles below.  k travels in RunDesc.meta bits 24..31; the kernel folds 2^-k into the run's harmonics.
     std::vector<uint16_t> w2h((size_t)n_tiles * (CH_TILE_BYTES_HOST / 2) + 512, 0);
+    int depth_max = 0;
     for (RunDesc& rd : runs) {
       const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
-      const int k = pack_f16_tiles(w2q.data(), b2q.data(), tile0, nt, w2h.data());
+      int depth = 0;
+      const int k = pack_f16_tiles(w2q.data(), b2q.data(), tile0, nt, w2h.data(), &depth);
+      depth_max = std::max(depth_max, depth);
       rd.meta = (rd.meta & 0x00ffffffu) | ((uint32_t)(k & 0xff) << 24);
     }
     o->W2h = upload(m, w2h, &rc);
@@ -562,8 +611,10 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
           for (int q = 0; q < 4; ++q)
             w1q[(((size_t)mt * KT + s4) * 64 + lane) * 4 + q] = W1[(size_t)(16 * mt + (lane & 15)) * K + 16 * s4 + 4 * (lane >> 4) + q];
     std::vector<uint16_t> w1h((size_t)KT * (CH_TILE_BYTES_HOST / 2) + 512, 0);
-    o->k1 = pack_f16_tiles(w1q.data(), B1, 0, KT, w1h.data());
+    int depth1 = 0;
+    o->k1 = pack_f16_tiles(w1q.data(), B1, 0, KT, w1h.data(), &depth1);
     o->W1h = upload(m, w1h, &rc);
+    o->f16_depth = std::max(depth_max, depth1);
   }
   o->runs = upload(m, runs, &rc);
   // contiguous group ranges of near-equal tile count for S = 1, 2, 4, 8
@@ -586,6 +637,24 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
 extern "C" int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out) {
   if (!frag || !bias || !out || !k_out || n_tiles <= 0) return fail(DBFR_ERR_ARG, "dbfr_test_pack_f16_tiles: bad argument");
   *k_out = pack_f16_tiles(frag, bias, 0, n_tiles, (uint16_t*)out);
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_model_fallback_convs(const dbfr_model* m, char* names, size_t names_cap) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  int n = 0;
+  for (char c : m->fallback_convs) n += c == ';';
+  if (names && names_cap) {
+    const size_t len = std::min(names_cap - 1, m->fallback_convs.size());
+    memcpy(names, m->fallback_convs.data(), len);
+    names[len] = 0;
+  }
+  return n;
+}
+
+extern "C" int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap) {
+  if (!m || (log_dev && n_steps_cap <= 0)) return fail(DBFR_ERR_ARG, "dbfr_model_set_edge_log: bad argument");
+  m->edge_log = log_dev; m->edge_log_steps = log_dev ? n_steps_cap : 0;
   return DBFR_OK;
 }
 
@@ -626,6 +695,8 @@ extern "C" int dbfr_conv_paths(int32_t kind, int32_t* t10, int32_t max_paths, in
 }
 
 static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tensors, int32_t n_tensors, dbfr_model** out);
+// DBFR_F16_DEPTH (developer): row depth above which a conv leaves the fp16 kernel; 1000 = never (measures what the fall-back protects from)
+static int f16_depth_ok() { static const int v = getenv("DBFR_F16_DEPTH") ? atoi(getenv("DBFR_F16_DEPTH")) : F16_ROW_DEPTH_OK; return v; }
 
 extern "C" int dbfr_model_create(const dbfr_model_cfg* cfg, const dbfr_tensor* tensors, int32_t n_tensors,
                                  dbfr_model** out) {
@@ -652,6 +723,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   m->cfg = *cfg;
   m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
   m->streams_ready = false;
+  m->edge_log = nullptr; m->edge_log_steps = 0; m->layer_fallback = 0;
   // which fused-conv kernel the K=144 convs use: k_conv2 (persistent, one launch per layer, tail split) wins while a layer
   // is only a few rounds of workgroups (predict.py-sized batches), k_conv (conv.hip) at bench-sized batches.
   // DBFR_CONV2 = 0 / 1 forces one of them, default -1 = by batch size
@@ -665,12 +737,15 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
     {
       rc = pack_conv(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), &m->layer[l][f]);
       if (!rc) rc = pack_conv2(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer[l][f], &m->layer2[l][f]);
+      if (!rc && m->layer2[l][f].f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << l; m->fallback_convs += std::string(fam[f]) + "." + std::to_string(l) + ";"; }
     }
   if (!rc) rc = pack_conv(m, tm, "final_conv", 4, &m->final_conv);
   if (!rc) rc = pack_conv(m, tm, "tor_bond_conv", 5, &m->tor_conv);
   if (!rc) rc = pack_conv2(m, tm, "tor_bond_conv", 5, m->tor_conv, &m->tor_conv2);
+  if (!rc && m->tor_conv2.f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << 31; m->fallback_convs += "tor_bond_conv;"; }
   if (!rc && !cfg->no_sc_torsion) rc = pack_conv(m, tm, "sc_tor_bond_conv", 5, &m->sc_conv);
   if (!rc && !cfg->no_sc_torsion) rc = pack_conv2(m, tm, "sc_tor_bond_conv", 5, m->sc_conv, &m->sc_conv2);
+  if (!rc && !cfg->no_sc_torsion && m->sc_conv2.f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << 31; m->fallback_convs += "sc_tor_bond_conv;"; }
   if (!rc) rc = pack_mlp(m, tm, "lig_node_embedding", cfg->lig_node_features + EMB, NS, NS, true, &m->lig_node_emb);
   if (!rc) rc = pack_mlp(m, tm, "lig_edge_embedding", cfg->lig_edge_features + 2 * EMB, NS, NS, true, &m->lig_edge_emb);
   if (!rc) rc = pack_mlp(m, tm, "atom_edge_embedding", 2 * EMB, NS, NS, true, &m->atom_edge_emb);
@@ -881,7 +956,7 @@ static Conv2Desc conv2_desc(const ConvW2& cw, const int* n_edges, int max_edges,
 }
 
 // one fused k_conv2 launch over up to four K=144 convs (an interaction layer, or the two torsion heads)
-static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int n, hipStream_t st) {
+static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int n, hipStream_t st, bool f16_fallback = false) {
   Conv2Args a;
   memset(&a, 0, sizeof a);
   for (int i = 0; i < n; ++i) a.c[i] = descs[i];
@@ -904,8 +979,8 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     });
   }
   if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, 8 * C2_TRACE_CAP * sizeof(unsigned long long), st); a.trace = trace_dev; }
-  if (m->gemm_split == DBFR_GEMM_SPLIT_F16) launch_conv2h(a, st);
-  else if (m->gemm_split == DBFR_GEMM_SPLIT_BF16) launch_conv2r(a, st);
+  if (m->gemm_split == DBFR_GEMM_SPLIT_F16 && !f16_fallback) launch_conv2h(a, st);
+  else if (m->gemm_split == DBFR_GEMM_SPLIT_BF16 || m->gemm_split == DBFR_GEMM_SPLIT_F16) launch_conv2r(a, st);   // (a launch holding a conv whose weights span more than two fp16 pieces hold: three bf16 pieces)
   else if (m->gemm_split) launch_conv2s(a, st);
   else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);
@@ -929,6 +1004,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   for (int k = 0; k < N_SETS; ++k) ga.set[k] = w.set[k];
   ga.err = w.err; ga.step = step; ga.lds_nl = ga.lds_na = ga.n_chunk = 0;
   launch_edges(ga, false, st);
+  if (m->edge_log && step < m->edge_log_steps) launch_edge_log(ga, m->edge_log + (size_t)step * N_SETS * G, st);
   // ---- embeddings
   {
     MlpArgs a; memset(&a, 0, sizeof a);
@@ -968,7 +1044,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
           conv2_desc(m->layer2[l][2], AA.n_edges, AA.cap, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg[2]),
           conv2_desc(m->layer2[l][3], LA.n_edges, LA.cap, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3])};
       const int Ws[4] = {m->layer[l][0].W, m->layer[l][1].W, m->layer[l][2].W, m->layer[l][3].W};
-      conv2_call(m, ds, Ws, 4, st);
+      conv2_call(m, ds, Ws, 4, st, (m->layer_fallback >> l) & 1u);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
       for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
@@ -1083,7 +1159,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       ds[nd] = conv2_desc(m->sc_conv2, S.n_edges, S.cap, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg[1]);
       Ws[nd++] = m->sc_conv.W;
     }
-    if (nd) conv2_call(m, ds, Ws, nd, st);
+    if (nd) conv2_call(m, ds, Ws, nd, st, (m->layer_fallback >> 31) & 1u);
     if (do_t) {
       launch_reduce_ln(w.msg[0], T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
       launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, st);
@@ -1168,7 +1244,7 @@ extern "C" int dbfr_score(dbfr_model* m, const dbfr_batch* b, const dbfr_cond* c
   rc = run_score(m, b, cond, out, w, st);
   if (rc) return rc;
   HIPCHECK(hipGetLastError());
-  return DBFR_OK;
+  return take_launch_error();
 }
 
 extern "C" int dbfr_sample_range(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps,
@@ -1210,7 +1286,7 @@ extern "C" int dbfr_sample_range(dbfr_model* m, const dbfr_batch* b, const dbfr_
     }
   }
   HIPCHECK(hipGetLastError());
-  return DBFR_OK;
+  return take_launch_error();
 }
 
 extern "C" int dbfr_sample(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps, int32_t n_steps,
@@ -1366,12 +1442,12 @@ static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t fami
     const ConvW2* cw2 = layer >= 0 ? &m->layer2[layer][family] : layer == -2 ? &m->tor_conv2 : &m->sc_conv2;
     const Conv2Desc d = conv2_desc(*cw2, n_edges_dev, n_edges, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg);
     const int W = cw->W;
-    conv2_call(m, &d, &W, 1, (hipStream_t)hip_stream);
+    conv2_call(m, &d, &W, 1, (hipStream_t)hip_stream, cw2->f16_depth > f16_depth_ok());
   } else {
     conv_call(m, *cw, n_edges_dev, n_edges, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg, (hipStream_t)hip_stream);
   }
   HIPCHECK(hipGetLastError());
-  return DBFR_OK;
+  return take_launch_error();
 }
 
 extern "C" int dbfr_test_conv(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,

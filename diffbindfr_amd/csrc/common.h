@@ -84,6 +84,7 @@ struct ConvW2 {
   const void* W2s;    // [n_tiles] x 13824 B: W2q cut into three bf16 pieces for k_conv2s (conv2s.hip; layout: api.cpp pack_conv2)
   const void* W1h;    // [9] x 9280 B: lin.0 (W1p's tiles, bias rows) in the W2h tile format with the one factor 2^k1, for k_conv2h's hidden layer
   int k1;
+  int f16_depth;      // largest row depth of the fp16 packing (api.cpp pack_f16_tiles): above F16_ROW_DEPTH_OK the conv is served by k_conv2r
   const void* W2h;    // [n_tiles] x 9280 B: W2q x 2^k(run) cut into two fp16 pieces + the tile's 16 bias values x 2^k, for k_conv2h (conv2h.hip; k in RunDesc.meta bits 24..31)
   const RunDesc* runs;    // meta bit 20: run reads the second x layout; x offsets already mapped to the LDS row
   int part_run[4][9];     // part_run[si][p] = first run of part p when the conv is cut into 1 << si parts
@@ -174,3 +175,8 @@ struct ConvArgs {
   } while (0)
 
 void dbfr_set_error(const std::string& s);
+// Compute units of the CURRENT device (a process may drive several devices; cached per device id).
+int dbfr_current_cu_count();
+// A kernel launcher could not prepare its launch (e.g. hipFuncSetAttribute refused the LDS size): recorded on this thread and returned
+// as DBFR_ERR_HIP by the entry point that issued the launch (api.cpp: take_launch_error).  Returns true when `e` is an error.
+bool dbfr_launch_check(hipError_t e, const char* what);

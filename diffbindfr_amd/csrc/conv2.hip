@@ -306,23 +306,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2(Conv2Args a) {
 }
 
 void launch_conv2(const Conv2Args& a, hipStream_t st) {
-  static int n_cu = 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
   static int skew = getenv("DBFR_CONV2_SKEW") ? atoi(getenv("DBFR_CONV2_SKEW")) : 0;
   constexpr int NW = 8;
   const size_t lds = (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = dbfr_current_cu_count();
   Conv2Args b = a;
   b.skew = skew;
   b.run_barrier = 0;
   b.no_split = no_split;
   // (the LDS attribute is set on every launch: it is per device, and a process may drive several)
-#define GO(...) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define GO(...) do { if (dbfr_launch_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "k_conv2: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return; \
                      hipLaunchKernelGGL((k_conv2<__VA_ARGS__>), dim3(n_cu), dim3(64 * NW), lds, st, b); } while (0)
 #ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1): barrier placements and timing-only ablations (wrong results)
   static int run_barrier = getenv("DBFR_CONV2_BARRIER") ? atoi(getenv("DBFR_CONV2_BARRIER")) : 0;

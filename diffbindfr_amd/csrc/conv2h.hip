@@ -211,7 +211,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
         }
         amx = fmaxf(amx, __shfl_xor(amx, 16));
         amx = fmaxf(amx, __shfl_xor(amx, 32));
-        ja[b] = max(-14, min(40, __builtin_amdgcn_frexp_expf(amx)));   // (inputs below 2^-14 are not blown up further: the bias is of order 1)
+        // (inputs below 2^-14 are not blown up further: the bias is of order 1.  No clamp on the large side: sa = 2^(15 - ja) is a normal
+        // fp32 number for every finite input, and a clamp there would let a sa overflow fp16 for inputs beyond it)
+        ja[b] = max(-14, __builtin_amdgcn_frexp_expf(amx));
         sa[b] = __builtin_amdgcn_ldexpf(1.f, 15 - ja[b]);
 #pragma unroll
         for (int s4 = 0; s4 < KT; ++s4) {
@@ -286,11 +288,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
         float m2 = fmaxf(mx[b], __shfl_xor(mx[b], 16));
         m2 = fmaxf(m2, __shfl_xor(m2, 32));
         // H' = f 2^j, f in [0.5, 1)  ->  factor 2^(15 - j) on H' = 2^tot on h with tot = 15 - j + k1 + 15 - ja.  tot is what multiplies
-        // the W2 bias (already x 2^k of its run) in the accumulator: it is kept within +-64 so that the product stays a finite fp32
+        // the W2 bias (already x 2^k of its run) in the accumulator: it is kept below 2^64 so that the product stays a finite fp32
         // number whatever the activations (an edge whose largest activation is below 2^-49 gets a smaller factor than the window
-        // asks for: its pieces lose relative precision, next to an O(1) bias nothing to lose), and the factor on H' follows from it
+        // asks for: its pieces lose relative precision, next to an O(1) bias nothing to lose), and the factor on H' follows from it.
+        // On the other side only fp32's own range limits it (se, ue = 2^+-tot stay normal numbers): huge activations keep their window --
+        // a tighter clamp there would push H' t beyond fp16's largest number -- and the bias term, 2^-24 of the products by then,
+        // may flush to zero.
         const int j = __builtin_amdgcn_frexp_expf(m2);
-        const int tot = max(-64, min(64, 15 - j + k1 + 15 - ja[b]));
+        const int tot = max(-120, min(64, 15 - j + k1 + 15 - ja[b]));
         const float t = __builtin_amdgcn_ldexpf(1.f, tot - k1 - 15 + ja[b]);
         se[b] = __builtin_amdgcn_ldexpf(1.f, tot);
         ue[b] = __builtin_amdgcn_ldexpf(1.f, -tot);
@@ -580,22 +585,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
 }
 
 void launch_conv2h(const Conv2Args& a, hipStream_t st) {
-  static int n_cu = 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
   constexpr int NW = 8;
   const size_t lds = CH_RING_BYTES + (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = dbfr_current_cu_count();
   Conv2Args b = a;
   b.skew = 0;
   b.run_barrier = 0;
   b.no_split = no_split;
   // (the LDS attribute is set on every launch: it is per device, and a process may drive several)
-#define V(x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define V(x) { if (dbfr_launch_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2h<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "k_conv2h: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return; \
                hipLaunchKernelGGL((k_conv2h<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
 #ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1 python -m diffbindfr_amd.build): the ABL variants of the kernel's header comment
   static int abl = getenv("DBFR_CONV2H_ABL") ? atoi(getenv("DBFR_CONV2H_ABL")) : 0;

@@ -514,22 +514,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
 }
 
 void launch_conv2r(const Conv2Args& a, hipStream_t st) {
-  static int n_cu = 0;
   static int no_split = getenv("DBFR_CONV2_NOSPLIT") ? atoi(getenv("DBFR_CONV2_NOSPLIT")) : 0;
   constexpr int NW = 8;
   const size_t lds = C3_RING_BYTES + (size_t)NW * C2_WAVE_FLOATS * sizeof(float);
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = dbfr_current_cu_count();
   Conv2Args b = a;
   b.skew = 0;
   b.run_barrier = 0;
   b.no_split = no_split;
   // (the LDS attribute is set on every launch: it is per device, and a process may drive several)
-#define V(x) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define V(x) { if (dbfr_launch_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2r<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "k_conv2r: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return; \
                hipLaunchKernelGGL((k_conv2r<NW, x>), dim3(n_cu), dim3(64 * NW), lds, st, b); return; }
 #ifdef DBFR_DEV_VARIANTS   // developer build (DBFR_BUILD_DEV=1): timing-only ablations (wrong results)
   static int abl = getenv("DBFR_CONV2R_ABL") ? atoi(getenv("DBFR_CONV2R_ABL")) : 0;

@@ -362,12 +362,29 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
     // "done once" flag; the call is cheap next to a launch that stages a > 4 k-atom pocket
     const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (e0 != hipSuccess || e1 != hipSuccess) dbfr_set_error(std::string("k_edges: hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
+    if (dbfr_launch_check(e0 != hipSuccess ? e0 : e1, "k_edges: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return;
   }
   A.n_chunk = (A.b.max_na + 255) / 256;      // must match plan() in api.cpp (g_cnt / g_base hold G * n_chunk entries)
   hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
   hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_edges<true>, dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
+}
+
+// dbfr_model_set_edge_log: per-graph edge counts of this step, log[k * G + g] = sum over the graph's target chunks
+__global__ void k_edge_log(GraphArgs A, int* log) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (g >= A.b.G) return;
+  const EdgeSet& S = A.set[k];
+  int c = 0;
+  if (S.cap > 0)
+    for (int i = 0; i < A.n_chunk; ++i) c += S.g_cnt[g * A.n_chunk + i];
+  log[k * A.b.G + g] = c;
+}
+
+void launch_edge_log(const GraphArgs& A0, int* log_row, hipStream_t st) {
+  GraphArgs A = A0;
+  A.n_chunk = (A.b.max_na + 255) / 256;
+  hipLaunchKernelGGL(k_edge_log, dim3((A.b.G + 255) / 256, N_SETS), dim3(256), 0, st, A, log_row);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -94,7 +94,18 @@ def torus_score_norm(sigma, seed=0):
 
 
 def steps(cfg, torus_seed=0):
-    """list of per-step scalar records + the ctypes dbfr_step array (actual_steps long)."""
+    """list of per-step scalar records + the ctypes dbfr_step array (actual_steps long).
+
+    ``cfg.type == 'ode'`` (scFlex.py:162-165,199-200): the probability-flow step ``0.5 g^2 score dt`` without noise -- on the tape the
+    drift factor becomes ``0.5 g^2`` (an exact halving: the device's ``g2 * score * dt`` then IS the reference's
+    ``0.5 * g ** 2 * score * dt``, rounding for rounding), the noise factor 0, and every step is noise free (nothing is drawn, as in
+    the reference).  Any other ``type`` is the SDE, like the reference's ``else``.  ``cfg.no_random`` (:167-183): SDE drift with z = 0.
+    ``time_schedule`` other than 'linear' raises like scFlex.py:91."""
+    if cfg.time_schedule != "linear":
+        raise NotImplementedError("Current time schedule only supports `linear`.")
+    assert cfg.actual_steps <= cfg.inference_steps, "actual steps should <= inference steps"      # scFlex.py:137
+    ode = cfg.type == "ode"
+    drift = 0.5 if ode else 1.0
     ts = torch.linspace(1, cfg.eps, cfg.inference_steps + 1)
     recs = []
     arr = (L.Step * cfg.actual_steps)()
@@ -108,15 +119,15 @@ def steps(cfg, torus_seed=0):
         rot_g = 2 * rot_s * np.sqrt(np.log(cfg.rot_sigma_max / cfg.rot_sigma_min))
         tor_g = tor_s * np.sqrt(2 * np.log(cfg.tor_sigma_max / cfg.tor_sigma_min))
         sc_g = sc_s * np.sqrt(2 * np.log(cfg.sc_tor_sigma_max / cfg.sc_tor_sigma_min))
-        sq = np.sqrt(dt)
+        sq = np.sqrt(dt) * (0.0 if ode else 1.0)
         r = SimpleNamespace(
             t=float(t), dt=float(dt), tr_sigma=float(tr_s), rot_sigma=float(rot_s), tor_sigma=float(tor_s),
             sc_tor_sigma=float(sc_s), rot_score_norm=float(so3_score_norm(np.array([rot_s]))),
             # scFlex.py:116: the ligand torsion norm is looked up with sc_tor_sigma (quirk kept)
             tor_score_norm2=float(torus_score_norm((torch.ones(1) * sc_s).numpy(), torus_seed)),
-            tr_g2=float(tr_g ** 2), tr_gsdt=float(tr_g * sq), rot_g2=float(rot_g ** 2), rot_gsdt=float(rot_g * sq),
-            tor_g2=float(tor_g ** 2), tor_gsdt=float(tor_g * sq), sc_g2=float(sc_g ** 2), sc_gsdt=float(sc_g * sq),
-            noise_free=bool(cfg.no_random or (cfg.no_final_step_noise and i == cfg.actual_steps - 1)))
+            tr_g2=float(drift * tr_g ** 2), tr_gsdt=float(tr_g * sq), rot_g2=float(drift * rot_g ** 2), rot_gsdt=float(rot_g * sq),
+            tor_g2=float(drift * tor_g ** 2), tor_gsdt=float(tor_g * sq), sc_g2=float(drift * sc_g ** 2), sc_gsdt=float(sc_g * sq),
+            noise_free=bool(ode or cfg.no_random or (cfg.no_final_step_noise and i == cfg.actual_steps - 1)))
         recs.append(r)
         for k, _ in L.Step._fields_:
             setattr(arr[i], k, getattr(r, k))

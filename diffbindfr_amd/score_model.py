@@ -234,6 +234,30 @@ class TensorProductModelHIP(nn.Module):
         self._handles[idx] = (fp, h)
         return h
 
+    def fallback_convs(self, device=None):
+        """Names (state_dict prefixes) of the convs whose weights two fp16 pieces cannot hold -- a run whose rows lie more than 2^17
+        apart -- and which the library therefore serves through the three-bf16-piece kernel whatever ``gemm`` says
+        (``dbfr_model_fallback_convs``).  Empty for seeded weights; a trained checkpoint may name some."""
+        buf = C.create_string_buffer(4096)
+        n = L.load().dbfr_model_fallback_convs(self.handle(device), buf, 4096)
+        if n < 0:
+            L.check(n)
+        return [x for x in buf.value.decode().split(";") if x]
+
+    def edge_log(self, device, n_steps, G):
+        """Switch the per-graph edge-count read-out on for the sampler calls that follow on ``device``
+        (``dbfr_model_set_edge_log``): returns the device int32 tensor [n_steps, 6, G] the library fills -- sets in the order
+        (ligand, pocket, cross lig<-atom, cross atom<-lig, ligand torsion, side-chain torsion).  ``n_steps = 0`` switches it off."""
+        dev = torch.device(device)
+        if n_steps <= 0:
+            L.check(L.load().dbfr_model_set_edge_log(self.handle(dev), None, 0))
+            self._edge_log = None
+            return None
+        log = torch.zeros(n_steps, 6, G, dtype=torch.int32, device=dev)
+        L.check(L.load().dbfr_model_set_edge_log(self.handle(dev), C.c_void_p(log.data_ptr()), n_steps))
+        self._edge_log = log          # (kept alive while the library holds the pointer)
+        return log
+
     def set_gemm(self, mode):
         """Switch the GEMM mode ("f32" | "split" | None = library default at the next re-pack) of this model on every device."""
         assert mode in (None,) + tuple(GEMM_MODES)

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define DBFR_ABI_VERSION 2   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2 (additions only) */
+#define DBFR_ABI_VERSION 3   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
+                                3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs (additions only) */
 
 typedef enum {
   DBFR_OK = 0,
@@ -193,6 +194,16 @@ int dbfr_sample_range(dbfr_model* m, const dbfr_batch* b, const dbfr_step* steps
  * largest edge count each set needed so far, [8] int64 in dbfr_status_sync's counter order
  * {lig, atom, cross lig<-atom, 0, tor, sc_tor, cross atom<-lig, 0}.  Synchronises the stream.                      */
 int dbfr_capacity_report(void* workspace, void* hip_stream, int32_t* first_failed_step, int64_t* needed_edges);
+
+/* Per-graph read-out of the per-step graphs (dbfr_status_sync's counters are per batch).  With log != NULL every step s < n_steps_cap of
+ * the dbfr_sample / dbfr_sample_range calls that follow on this model writes the edge count of graph g in edge set k to
+ * log[(s * 6 + k) * G + g] (device int32, caller-owned, >= n_steps_cap * 6 * G entries, G = the batch's graph count), k = {0 ligand
+ * (bonds + radius_graph, tpscore.py:586), 1 pocket (:613), 2 cross lig<-atom, 3 cross atom<-lig (the same pairs, :655-660), 4 ligand
+ * torsion (:721), 5 side-chain torsion (:747)}; dbfr_score writes row s = 0.  A set that overflowed its capacity still reports the count
+ * it needed.  log == NULL switches the read-out off (the default).  The counts make a hard-cutoff event visible: two runs whose
+ * coordinates differ in the 5th decimal build different graphs exactly where a pair sits within rounding distance of a cutoff
+ * (tests/test_examples.py).                                                                                                        */
+int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap);
 
 /* ---- pose initialisation, on the device.
  * Replaces the per-pose real-time transforms LigInit + SCProtInit +
@@ -412,6 +423,13 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 #define DBFR_GEMM_SPLIT_F16 3
 #define DBFR_GEMM_DEFAULT DBFR_GEMM_SPLIT_F16
 int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
+/* DBFR_GEMM_SPLIT_F16 holds a weight row to 22 significant bits while the row's largest |w| is within 2^17 of the largest |w| of its
+ * tensor-product run (one power-of-two factor per run; lin.0: per matrix).  dbfr_model_create measures every run of every conv; a conv
+ * with a deeper row (a trained checkpoint may hold one; seeded weights do not) is served by the DBFR_GEMM_SPLIT_BF16 kernel -- bf16 has
+ * fp32's exponent range -- together with the other convs of its launch (an interaction layer / the two torsion heads), whatever the
+ * mode says.  Returns the number of such convs; names (may be NULL) receives their state_dict prefixes, ';'-terminated each
+ * ("atom_conv_layers.3;").                                                                                                       */
+int dbfr_model_fallback_convs(const dbfr_model* model, char* names, size_t names_cap);
 int dbfr_model_get_gemm(const dbfr_model* model);
 
 /* ---- introspection / test hooks */

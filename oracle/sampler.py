@@ -20,13 +20,14 @@ import torch
 from . import geometry, schedule, score_model
 
 
-def draw_noise(actual_steps, G, n_tor, n_sc, seed, no_final_step_noise=True):
-    """Tape drawn in the reference's order (tr, rot, tor, sc_tor per step)."""
+def draw_noise(actual_steps, G, n_tor, n_sc, seed, no_final_step_noise=True, none=False):
+    """Tape drawn in the reference's order (tr, rot, tor, sc_tor per step).  ``none``: the all-zero tape of `type='ode'` /
+    `no_random=True` runs (the reference draws nothing then, scFlex.py:162-183)."""
     g = torch.Generator().manual_seed(seed)
     z = SimpleNamespace(tr=torch.zeros(actual_steps, G, 3), rot=torch.zeros(actual_steps, G, 3),
                         tor=torch.zeros(actual_steps, n_tor), sc=torch.zeros(actual_steps, n_sc))
     for s in range(actual_steps):
-        if no_final_step_noise and s == actual_steps - 1:
+        if none or (no_final_step_noise and s == actual_steps - 1):
             continue
         z.tr[s] = torch.normal(0, 1, size=(G, 3), generator=g)
         z.rot[s] = torch.normal(0, 1, size=(G, 3), generator=g)
@@ -51,13 +52,23 @@ def sde_step(data, sc, scores, z, t_idx, atom14_to_group):
     """scFlex.py:154-230: perturbations + the two geometry updates, in place on ``data``."""
     tr_score, rot_score, tor_score, sc_tor_score = scores
     dt = sc.dt
-    tr_perturb = sc.tr_g ** 2 * tr_score * dt + sc.tr_g * np.sqrt(dt) * z.tr[t_idx]
-    rot_perturb = sc.rot_g ** 2 * rot_score * dt + sc.rot_g * np.sqrt(dt) * z.rot[t_idx]
-    tor_perturb = sc.tor_g ** 2 * tor_score * dt + sc.tor_g * np.sqrt(dt) * z.tor[t_idx]
+    ode = getattr(sc, "ode", False)
+    if ode:                                           # scFlex.py:162-165: probability-flow ODE, no noise
+        tr_perturb = 0.5 * sc.tr_g ** 2 * tr_score * dt
+        rot_perturb = 0.5 * sc.rot_g ** 2 * rot_score * dt
+        tor_perturb = 0.5 * sc.tor_g ** 2 * tor_score * dt
+    else:                                             # :166-183 (z = 0 on noise-free steps: the tape holds zeros there)
+        zero = sc.noise_free
+        tr_perturb = sc.tr_g ** 2 * tr_score * dt + sc.tr_g * np.sqrt(dt) * (torch.zeros_like(z.tr[t_idx]) if zero else z.tr[t_idx])
+        rot_perturb = sc.rot_g ** 2 * rot_score * dt + sc.rot_g * np.sqrt(dt) * (torch.zeros_like(z.rot[t_idx]) if zero else z.rot[t_idx])
+        tor_perturb = sc.tor_g ** 2 * tor_score * dt + sc.tor_g * np.sqrt(dt) * (torch.zeros_like(z.tor[t_idx]) if zero else z.tor[t_idx])
     data.lig_pos = geometry.update_batchlig_pos(
         tr_perturb, rot_perturb, tor_perturb, data.lig_pos, data.lig_edge_index,
         data.tor_edge_mask, data.rot_node_mask, batch=data.lig_node_batch)
-    sc_perturb = sc.sc_tor_g ** 2 * sc_tor_score * dt + sc.sc_tor_g * np.sqrt(dt) * z.sc[t_idx]
+    if ode:                                           # :199-200
+        sc_perturb = 0.5 * sc.sc_tor_g ** 2 * sc_tor_score * dt
+    else:
+        sc_perturb = sc.sc_tor_g ** 2 * sc_tor_score * dt + sc.sc_tor_g * np.sqrt(dt) * (torch.zeros_like(z.sc[t_idx]) if sc.noise_free else z.sc[t_idx])
     chi = data.torsion_angle[:, 1:]
     chi[data.sc_torsion_edge_mask] = chi[data.sc_torsion_edge_mask] + sc_perturb
     data.torsion_angle[:, 1:] = chi

@@ -30,6 +30,9 @@ def default_sample_cfg(**over):
 
 
 def t_schedule(cfg):
+    """scFlex.py:83-91."""
+    if cfg.time_schedule != "linear":
+        raise NotImplementedError("Current time schedule only supports `linear`.")
     return torch.linspace(1, cfg.eps, cfg.inference_steps + 1)
 
 
@@ -153,6 +156,7 @@ def step_scalars(cfg, t_idx, torus_seed=0):
     # scFlex.py:116 uses sc_tor_sigma for the *ligand* torsion norm too (quirk kept)
     tor_norm2 = torch.from_numpy(torus_score_norm(torch.ones(1) * sc_s, torus_seed)).float()
     last = cfg.no_final_step_noise and t_idx == cfg.actual_steps - 1
+    ode = cfg.type == "ode"                                            # scFlex.py:162: anything else takes the SDE branch
     return SimpleNamespace(t=t, dt=dt, tr_sigma=tr_s, rot_sigma=rot_s, tor_sigma=tor_s, sc_tor_sigma=sc_s,
                            tr_g=tr_g, rot_g=rot_g, tor_g=tor_g, sc_tor_g=sc_g, rot_score_norm=rot_norm,
-                           tor_score_norm2=tor_norm2, noise_free=bool(cfg.no_random or last))
+                           tor_score_norm2=tor_norm2, ode=ode, noise_free=bool(ode or cfg.no_random or last))

@@ -288,6 +288,57 @@ def golden_model_and_sampler():
     np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
 
 
+def golden_sampler_modes():
+    """The sampler's other branches on the small batch of sampler.npz (inputs are there): `sample_cfg.type = 'ode'` (scFlex.py:162-165,
+    199-200: 0.5 g^2 score dt, nothing drawn) and `no_random = True` (:167-183: SDE drift, z = 0) through the reference's own
+    DiffBindFR.sample(); the oracle must reproduce both; `time_schedule != 'linear'` must raise (:91).  -> tests/golden/sampler_modes.npz"""
+    print("[sampler modes: ode / no_random / time_schedule guard]")
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=1)
+    model = ns.tpscore.TensorProductModel(ref_model_cfg()).eval()
+    model.load_state_dict(params, strict=True)
+    d = synthetic.make_batch(2, n_complex=2, poses=2, seed=3, n_atoms=60, n_lig=10)
+    G = d.num_graphs
+    go = sys.modules["druglib.utils.geometry_utils"]
+    go.so3 = types.SimpleNamespace(score_norm=schedule.so3_score_norm)
+    go.torus = types.SimpleNamespace(score_norm=lambda s: schedule.torus_score_norm(s, 0))
+    n_tor, n_sc = int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum())
+    out = {}
+    for tag, over in (("ode", dict(type="ode")), ("no_random", dict(no_random=True))):
+        scfg = schedule.default_sample_cfg(**over)
+        ref_sampler = ns.scflex.DiffBindFR(diffusion_model=None, test_cfg=ED(sample_cfg=ED(vars(scfg))))
+        ref_sampler.diffusion_model_cfg = ED(no_sc_torsion=False)
+        ref_sampler.diffusion_model = model
+        rd = ED({k: (v.clone() if torch.is_tensor(v) else v) for k, v in vars(d).items() if k != "rot_node_mask"})
+        rd.metastore = {"rot_node_mask": [m.clone() for m in d.rot_node_mask]}
+        torch.manual_seed(5)
+        state = torch.get_rng_state()
+        res = ref_sampler.sample(rd, visualize=True)
+        assert torch.equal(torch.get_rng_state(), state), f"{tag}: the reference drew random numbers"
+        lig_ref = torch.cat([r[0] for r in res], dim=1)
+        a14_ref = torch.cat([r[1] for r in res], dim=1)
+        noise = sampler.draw_noise(scfg.actual_steps, G, n_tor, n_sc, seed=5, none=True)
+        lig_o, a14_o = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise, torch.from_numpy(T["atom14_to_group"]).long(),
+                                      torus_seed=0, visualize=True)
+        close(lig_o, lig_ref, 1e-4, f"sample() {tag}: ligand trajectory (20 steps)")
+        close(a14_o, a14_ref, 1e-4, f"sample() {tag}: atom14 trajectory (20 steps)")
+        out[f"{tag}_traj_lig"], out[f"{tag}_traj_atom14"] = npy(lig_ref), npy(a14_ref)
+    z = np.load(os.path.join(HERE, "sampler.npz"))
+    dsde = float(np.abs(z["traj_lig"] - out["ode_traj_lig"]).max())
+    print(f"  ode vs sde final ligand positions differ by up to {dsde:.2f} A (the modes are not interchangeable)")
+    assert dsde > 0.1
+    scfg = schedule.default_sample_cfg(time_schedule="cosine")
+    ref_sampler = ns.scflex.DiffBindFR(diffusion_model=None, test_cfg=ED(sample_cfg=ED(vars(scfg))))
+    try:
+        ref_sampler.t_schedule()
+        raise AssertionError("the reference accepted time_schedule='cosine'")
+    except NotImplementedError as e:
+        out["time_schedule_error"] = np.asarray(str(e))
+    out["params_seed"] = np.asarray(1)
+    np.savez_compressed(os.path.join(HERE, "sampler_modes.npz"), **out)
+    print("  sampler_modes.npz:", os.path.getsize(os.path.join(HERE, "sampler_modes.npz")) // 1024, "KiB")
+
+
 def golden_pose_init():
     """f1: LigInit / SCFixer / SCProtInit / Atom14ToAllAtomsRepr of the reference's struct_init.py run on seeded
     global generators; the oracle gets the same draws as an explicit tape."""
@@ -704,9 +755,104 @@ def _ligand_half_from_sdf(path, du, seed):
                 rot_node_mask=torch.from_numpy(np.asarray(rot)))
 
 
-def _reference_trajectories(recs, seed, what):
+class _EdgeRecorder:
+    """Wraps the graph builders of the REFERENCE's TensorProductModel instance (tpscore.py:575-759) for one sample() run and logs, per
+    step and per graph, (1) the edge count of each of the five per-step edge sets -- lig = bonds + radius_graph(5 A, cap 32), atom =
+    radius_graph(4 A), cross = lig x {CA, CB} + radius(0.2 sigma + 5 A), tor / sc = bond mid-point -> atoms within 5 / 4 A (cap 32) --
+    and (2) the set's MARGIN: the smallest | |x_i - x_j| - cutoff | over all candidate pairs of the graph, evaluated in float64 on the
+    coordinates the reference holds at that step.  A margin below ~1e-4 A means a pair sits within rounding distance of a hard cutoff:
+    an implementation whose coordinates differ in the 5th decimal may legitimately build a different graph at that step
+    (tests/test_examples.py).  The margins stand in for the per-step coordinates themselves (3 MB per fixture)."""
+    SETS = ("lig", "atom", "cross", "tor", "sc")
+
+    def __init__(self, model, G):
+        self.m, self.G, self.counts, self.margins = model, G, [], []
+        self._orig = {}
+
+    def _per_graph(self, batch, idx):
+        return np.bincount(npy(batch[idx]).astype(np.int64), minlength=self.G)[:self.G]
+
+    def _margin(self, xa, ba, xb, bb, cut, exclude_self=False):
+        out = np.full(self.G, np.inf)
+        xa, xb, ba, bb = npy(xa).astype(np.float64), npy(xb).astype(np.float64), npy(ba), npy(bb)
+        for g in range(self.G):
+            A, B = xa[ba == g], xb[bb == g]
+            if len(A) == 0 or len(B) == 0:
+                continue
+            d = np.sqrt(((A[:, None, :] - B[None, :, :]) ** 2).sum(-1))
+            if exclude_self:
+                d = d[~np.eye(len(A), dtype=bool)]
+            c = cut[g] if np.ndim(cut) else cut
+            if d.size:
+                out[g] = np.abs(d - c).min()
+        return out
+
+    def install(self):
+        m, R = self.m, self
+
+        def lig(data):
+            r = R._orig["build_lig_conv_graph"](data)
+            R.counts.append({}); R.margins.append({})
+            R.counts[-1]["lig"] = R._per_graph(data.lig_node_batch, r[1][0])
+            R.margins[-1]["lig"] = R._margin(data.lig_pos, data.lig_node_batch, data.lig_pos, data.lig_node_batch, float(m.lig_cutoff), True)
+            return r
+
+        def atom(data):
+            r = R._orig["build_atom_conv_graph"](data)
+            R.counts[-1]["atom"] = R._per_graph(data.rec_atm_pos_batch, r[1][0])
+            R.margins[-1]["atom"] = R._margin(data.rec_atm_pos, data.rec_atm_pos_batch, data.rec_atm_pos, data.rec_atm_pos_batch, float(m.atom_cutoff), True)
+            return r
+
+        def cross(data):
+            r = R._orig["build_cross_conv_graph"](data)
+            R.counts[-1]["cross"] = R._per_graph(data.lig_node_batch, r[0][0])
+            a37 = data.pocket_node_feature[:, 0].long()
+            nab = ~((a37 == 1) | (a37 == 3))
+            cut = npy(data.tr_sigma).astype(np.float64) * np.float64(np.float32(0.2)) + 5.0 if m.dynamic_max_cross else float(m.cross_cutoff)
+            R.margins[-1]["cross"] = R._margin(data.lig_pos, data.lig_node_batch, data.rec_atm_pos[nab], data.rec_atm_pos_batch[nab], cut)
+            return r
+
+        def tor(data, x):
+            r = R._orig["build_lig_bond_conv_graph"](data, x)
+            bonds = data.lig_edge_index[:, data.tor_edge_mask.bool()]
+            bb = data.lig_node_batch[bonds[0]]
+            R.counts[-1]["tor"] = R._per_graph(bb, r[0][0])
+            mid = (data.lig_pos[bonds[0]] + data.lig_pos[bonds[1]]) / 2
+            R.margins[-1]["tor"] = R._margin(mid, bb, data.lig_pos, data.lig_node_batch, float(m.lig_cutoff))
+            return r
+
+        def sc(data, x):
+            r = R._orig["build_sc_bond_conv_graph"](data, x)
+            bonds = data.sc_torsion_edge_index
+            bb = data.rec_atm_pos_batch[bonds[0]]
+            R.counts[-1]["sc"] = R._per_graph(bb, r[0][0])
+            mid = (data.rec_atm_pos[bonds[0]] + data.rec_atm_pos[bonds[1]]) / 2
+            R.margins[-1]["sc"] = R._margin(mid, bb, data.rec_atm_pos, data.rec_atm_pos_batch, float(m.atom_cutoff))
+            return r
+
+        for name, fn in (("build_lig_conv_graph", lig), ("build_atom_conv_graph", atom), ("build_cross_conv_graph", cross),
+                         ("build_lig_bond_conv_graph", tor), ("build_sc_bond_conv_graph", sc)):
+            self._orig[name] = getattr(m, name)
+            object.__setattr__(m, name, fn)
+        return self
+
+    def arrays(self):
+        """(edge_counts [steps, G, 5] int32, cutoff_margin [steps, G, 5] float32 (inf: the graph has no candidate pair in that set))"""
+        S = len(self.counts)
+        c = np.zeros((S, self.G, 5), np.int32)
+        mg = np.full((S, self.G, 5), np.inf, np.float32)
+        for s in range(S):
+            for k, nm in enumerate(self.SETS):
+                if nm in self.counts[s]:
+                    c[s, :, k] = self.counts[s][nm]
+                    mg[s, :, k] = self.margins[s][nm]
+        return c, mg
+
+
+def _reference_trajectories(recs, seed, what, run_oracle=True):
     """One pose per record (seeded init tape through the pinned LigInit / SCProtInit restatement), all poses in ONE batch through the
-    reference's own DiffBindFR.sample() for 20 steps; the oracle must reproduce it.  Returns (tapes, noise, traj_lig, final_atom14, ptrs)."""
+    reference's own DiffBindFR.sample() for 20 steps (its graph builders wrapped by _EdgeRecorder); the oracle must reproduce it.
+    Returns (tapes, noise, traj_lig, final_atom14, params, (edge_counts, cutoff_margin))."""
     import time
     from oracle import pose_init as opi
     Tt = {k: (torch.from_numpy(np.asarray(v)) if k == "atom14_to_group" else v) for k, v in T.items()}
@@ -737,17 +883,22 @@ def _reference_trajectories(recs, seed, what):
     rd.metastore = {"rot_node_mask": [m.clone() for m in d.rot_node_mask]}
     torch.manual_seed(seed)
     t0 = time.time()
+    recorder = _EdgeRecorder(model, G).install()
     res = ref_sampler.sample(rd, visualize=True)
     print(f"  reference sample(): {G} poses x {scfg.actual_steps} steps ({what}) in {time.time() - t0:.0f}s")
+    edges = recorder.arrays()
+    assert edges[0].shape[0] == scfg.actual_steps
     lig_ref = torch.cat([r[0] for r in res], dim=1)
     a14_ref = torch.cat([r[1] for r in res], dim=1)
     n_tor_tot, n_sc = int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum())
     noise = sampler.draw_noise(scfg.actual_steps, G, n_tor_tot, n_sc, seed=seed)
+    if not run_oracle:
+        return tapes, noise, lig_ref, a14_ref[-1], params, edges
     lig_o, a14_o = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise, torch.from_numpy(T["atom14_to_group"]).long(),
                                   torus_seed=0, visualize=True)
     close(lig_o, lig_ref, 1e-4, f"{what} sample(): ligand trajectories (20 steps)")
     close(a14_o, a14_ref, 1e-4, f"{what} sample(): atom14 trajectories (20 steps)")
-    return tapes, noise, lig_ref, a14_ref[-1], params
+    return tapes, noise, lig_ref, a14_ref[-1], params, edges
 
 
 def golden_examples():
@@ -789,8 +940,21 @@ def golden_examples():
             print(f"  {name}: reference pocket halves added, {os.path.getsize(os.path.join(HERE, name)) // 1024} KiB")
         return
 
-    def save(name, prots, ligs, pairs, tapes, noise, lig_traj, a14_final, params, prots_pk):
-        out = dict(n_prot=np.asarray(len(prots)), n_lig=np.asarray(len(ligs)), pairs=np.asarray(pairs, np.int64),
+    EDGES_ONLY = bool(os.environ.get("GOLDEN_EXAMPLES_EDGES_ONLY"))   # add edge_counts / cutoff_margin to the existing fixtures: the
+    # reference's sample() is run again (recorder installed) and must reproduce the frozen trajectories; the oracle leg is skipped
+
+    def save(name, prots, ligs, pairs, tapes, noise, lig_traj, a14_final, params, prots_pk, edges):
+        if EDGES_ONLY:
+            z = dict(np.load(os.path.join(HERE, name)))
+            dl = float(np.abs(z["traj_lig"] - npy(lig_traj).astype(np.float32)).max())
+            da = float(np.abs(z["final_atom14"] - npy(a14_final).astype(np.float32)).max())
+            print(f"  {name}: re-run vs frozen trajectories max|d| ligand {dl:.2e} A, atom14 {da:.2e} A")
+            assert dl <= 2e-5 and da <= 2e-5, "the re-run does not reproduce the frozen reference trajectories"
+            z.update(edge_counts=edges[0], cutoff_margin=edges[1])
+            np.savez_compressed(os.path.join(HERE, name), **z)
+            print(f"  {name}: edge_counts {edges[0].shape} / cutoff_margin added, {os.path.getsize(os.path.join(HERE, name)) // 1024} KiB")
+            return
+        out = dict(edge_counts=edges[0], cutoff_margin=edges[1], n_prot=np.asarray(len(prots)), n_lig=np.asarray(len(ligs)), pairs=np.asarray(pairs, np.int64),
                    params_seed=np.asarray(1), params_sha256=np.asarray(params_digest(params)),
                    noise_tr=npy(noise.tr), noise_rot=npy(noise.rot), noise_tor=npy(noise.tor), noise_sc=npy(noise.sc),
                    traj_lig=npy(lig_traj).astype(np.float32), final_atom14=npy(a14_final).astype(np.float32))
@@ -817,8 +981,8 @@ def golden_examples():
     assert len(files) == 15
     ligs = [(f[:-4], _ligand_half_from_sdf(os.path.join(ex, "forward", "mols", f), du, 100 + i)) for i, f in enumerate(files)]
     recs = [dict(pk, **lg) for _, lg in ligs]
-    tapes, noise, lt, a14, params = _reference_trajectories(recs, 4321, "examples/forward (3DBS x 15 ligands)")
-    save("real_forward15_traj.npz", [("3dbs", cry, sup)], ligs, [(0, i) for i in range(15)], tapes, noise, lt, a14, params, [pk])
+    tapes, noise, lt, a14, params, edges = _reference_trajectories(recs, 4321, "examples/forward (3DBS x 15 ligands)", run_oracle=not EDGES_ONLY)
+    save("real_forward15_traj.npz", [("3dbs", cry, sup)], ligs, [(0, i) for i in range(15)], tapes, noise, lt, a14, params, [pk], edges)
 
     # ---- reverse: 2 ligands x 3 receptors (pairs ligand-major, as dataframe.py builds the table)
     prots, pks = [], []
@@ -831,8 +995,8 @@ def golden_examples():
     ligs = [(f"ligand_{i + 1}", _ligand_half_from_sdf(os.path.join(ex, "reverse", f"ligand_{i + 1}.sdf"), du, 200 + i)) for i in range(2)]
     pairs = [(p, l) for l in range(2) for p in range(3)]
     recs = [dict(pks[p], **ligs[l][1]) for p, l in pairs]
-    tapes, noise, lt, a14, params = _reference_trajectories(recs, 8765, "examples/reverse (2 ligands x 3 receptors)")
-    save("real_reverse_traj.npz", prots, ligs, pairs, tapes, noise, lt, a14, params, pks)
+    tapes, noise, lt, a14, params, edges = _reference_trajectories(recs, 8765, "examples/reverse (2 ligands x 3 receptors)", run_oracle=not EDGES_ONLY)
+    save("real_reverse_traj.npz", prots, ligs, pairs, tapes, noise, lt, a14, params, pks, edges)
 
 
 
@@ -1380,6 +1544,9 @@ def golden_boundary():
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    if sys.argv[1:] == ["sampler_modes"]:
+        golden_sampler_modes()
+        sys.exit(0)
     if sys.argv[1:] == ["examples"]:          # the two example fixtures alone (15 + 6 poses through the reference's sample(): minutes)
         golden_examples()
         sys.exit(0)
@@ -1387,6 +1554,7 @@ if __name__ == "__main__":
     golden_embeddings()
     golden_schedule()
     golden_model_and_sampler()
+    golden_sampler_modes()
     golden_pose_init()
     golden_pocket()
     golden_real_complex()

@@ -105,6 +105,33 @@ def test_trajectory_matches_reference_fixture(setup, dev, both_gemms):
     assert (a14.cpu() - torch.from_numpy(z["traj_atom14"])).norm(dim=-1).max() < POSE_ATOL
 
 
+@pytest.mark.parametrize("tag,over", [("ode", dict(type="ode")), ("no_random", dict(no_random=True))])
+def test_sampler_modes_match_the_reference_fixture(setup, dev, tag, over):
+    """`--cfg-options model.test_cfg.sample_cfg.type=ode` (scFlex.py:162-165,199-200) and `no_random=True` (:167-183): the reference's
+    own trajectories on the sampler.npz batch (tests/golden/sampler_modes.npz), replayed on the device through the drop-in's own
+    schedule -- with a tape of ones in the noise buffers that neither mode may read."""
+    import os
+    from tests.helpers import GOLDEN
+    mcfg, params, model = setup
+    d, z = load_golden_batch()
+    zm = np.load(os.path.join(GOLDEN, "sampler_modes.npz"))
+    samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg=dict(sample_cfg=over))
+    pb = PackedBatch(namespace_to(d, dev), dev)
+    noise = {k: torch.ones_like(torch.from_numpy(z[f"noise_{k}"])).to(dev).contiguous() for k in ("tr", "rot", "tor", "sc")}
+    recs, _ = samp.schedule()
+    if tag == "no_random":          # SDE factors: the tape is what the host would have drawn -- zeros on noise-free steps (sampler.draw_noise_tape)
+        from diffbindfr_amd.sampler import draw_noise_tape
+        noise = {k: v.to(dev).contiguous() for k, v in draw_noise_tape(recs, pb.G, pb.dims["NTOR"], pb.dims["NSC"]).items()}
+    lig, a14 = samp.sample_packed(pb, noise, visualize=True)
+    assert (lig.cpu() - torch.from_numpy(zm[f"{tag}_traj_lig"])).norm(dim=-1).max() < POSE_ATOL
+    assert (a14.cpu() - torch.from_numpy(zm[f"{tag}_traj_atom14"])).norm(dim=-1).max() < POSE_ATOL
+    # and through the level-2 entry point (forward -> sample: draws its own tape, which must be empty in these modes)
+    res = samp(namespace_to(d, dev), mode="test")
+    lp = pb.lig_ptr_host.tolist()
+    for g_, (l, a) in enumerate(res):
+        assert (l[-1] - torch.from_numpy(zm[f"{tag}_traj_lig"][-1, lp[g_]:lp[g_ + 1]])).norm(dim=-1).max() < POSE_ATOL
+
+
 def _oracle_vs_hip_scores(setup, dev, d, step=6):
     mcfg, params, model = setup
     sc = osched.step_scalars(osched.default_sample_cfg(), step)
@@ -303,11 +330,13 @@ def test_graph_permutation_invariance(setup, dev):
 @pytest.mark.parametrize("layer,fam,name", [(0, 0, "lig_conv_layers.0"), (1, 2, "atom_conv_layers.1"),
                                             (2, 1, "cross_al_conv_layers.2"), (5, 3, "cross_la_conv_layers.5"),
                                             (-1, 0, "final_conv"), (-2, 0, "tor_bond_conv"), (-3, 0, "sc_tor_bond_conv")])
-@pytest.mark.parametrize("kernel", ["k_conv", "k_conv2", "k_conv2s", "k_conv2r"])
+@pytest.mark.parametrize("kernel", ["k_conv", "k_conv2", "k_conv2s", "k_conv2r", "k_conv2h"])
 def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name, kernel):
+    """Every conv shape of the network alone against the oracle's tensor product (oracle._tp over e3nn_lite), through every fused-conv
+    kernel -- the default one (k_conv2h, DBFR_GEMM_SPLIT_F16) included."""
     if kernel != "k_conv" and layer == -1:
         pytest.skip("final_conv (K=96) runs on k_conv only")
-    with gemm(setup[2], {"k_conv2s": "split_l1", "k_conv2r": "split"}.get(kernel, "f32")):
+    with gemm(setup[2], {"k_conv2s": "split_l1", "k_conv2r": "split", "k_conv2h": "split_f16"}.get(kernel, "f32")):
         _fused_conv_and_reduce(setup, dev, layer, fam, name, kernel)
 
 
@@ -636,11 +665,126 @@ def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms,
     model.release()
 
 
-@pytest.mark.parametrize("scale", [1e-4, 1e3, "ragged"])
+K144_CONVS = [(0, 0, "lig_conv_layers.0"), (1, 2, "atom_conv_layers.1"), (2, 1, "cross_al_conv_layers.2"), (3, 2, "atom_conv_layers.3"),
+              (5, 3, "cross_la_conv_layers.5"), (-2, 0, "tor_bond_conv"), (-3, 0, "sc_tor_bond_conv")]
+
+
+def _reshape_weights(p, dist, seed):
+    """The radial-MLP weights of every K=144 conv redrawn / rescaled the way a trained checkpoint might look (nobody has seen one
+    offline): `student_t2` = heavy tails (Student-t, nu = 2: single weights hundreds of times the typical size), `rows_4dec` /
+    `rows_6dec` = every lin.3 row its own magnitude, log-uniform over four / six decades, `chan_6dec` = every OUTPUT CHANNEL of the
+    tensor product (all rows that sum into it) its own magnitude over six decades -- a small channel then shares its run's one
+    power-of-two factor with a large one, the case two fp16 pieces cannot hold -- `x1e-3` / `x1e3` = lin.3 weight and bias scaled."""
+    g = torch.Generator().manual_seed(seed)
+    q = {k: v.clone() for k, v in p.items()}
+    mcfg = sm.default_cfg()
+    for name, (i, shirr, o, nef) in sm.conv_specs(mcfg).items():
+        if nef != 144:
+            continue
+        w, b = q[f"{name}.fc.lin.3.weight"], q[f"{name}.fc.lin.3.bias"]
+        if dist == "student_t2":
+            t = torch.distributions.StudentT(2.0)
+            for k in (f"{name}.fc.lin.0.weight", f"{name}.fc.lin.3.weight"):
+                torch.manual_seed(seed + len(k))
+                q[k] = (t.sample(q[k].shape) * q[k].std()).float()
+        elif dist in ("rows_4dec", "rows_6dec"):
+            dec = 4.0 if dist == "rows_4dec" else 6.0
+            f = torch.pow(10.0, -dec * torch.rand(w.shape[0], generator=g))
+            q[f"{name}.fc.lin.3.weight"], q[f"{name}.fc.lin.3.bias"] = w * f[:, None], b * f
+        elif dist == "chan_6dec":
+            # e3nn weight layout per path: [mul_in (u), mul_out (w)] -> row = w_off + u * mul_out + w; one factor per (output irrep, w)
+            io, oo = o3.Irreps(i), o3.Irreps(o)
+            f = torch.ones(w.shape[0])
+            fac = {}
+            for kind in range(6):
+                wn, paths = dba.score_model.conv_paths(kind)
+                if wn != w.shape[0]:
+                    continue
+                for (i1, i2, iout, l1, l2, lo, mul1, mulo, w_off, _) in paths:
+                    if iout not in fac:
+                        fac[iout] = torch.pow(10.0, -6.0 * torch.rand(mulo, generator=g))
+                    f[w_off:w_off + mul1 * mulo] = fac[iout].repeat(mul1)
+                break
+            q[f"{name}.fc.lin.3.weight"], q[f"{name}.fc.lin.3.bias"] = w * f[:, None], b * f
+        else:
+            sc = {"x1e-3": 1e-3, "x1e3": 1e3}[dist]
+            q[f"{name}.fc.lin.3.weight"], q[f"{name}.fc.lin.3.bias"] = w * sc, b * sc
+    return q
+
+
+@pytest.mark.parametrize("dist", ["student_t2", "rows_4dec", "rows_6dec", "chan_6dec", "x1e-3", "x1e3"])
+def test_default_gemm_on_weights_nobody_has_seen(dev, dist):
+    """The gate that licenses two fp16 pieces as fp32 arithmetic, over weight distributions a trained checkpoint could hold and over ALL
+    K=144 conv shapes: against a float64 evaluation of the same conv (the oracle run in double), the default mode's messages are at
+    least as close as the fp32 matrix instruction's -- per output column (a small channel is not allowed to hide behind a large one),
+    in the largest and in the rms deviation.  Where a run's rows lie further apart than two fp16 pieces hold (`chan_6dec`, `rows_6dec`)
+    the library must notice at model creation (`fallback_convs`) and serve the conv through the three-bf16-piece kernel, which is held
+    to its own gate (1.25 x the fp32 instruction's error + 5e-8)."""
+    mcfg = sm.default_cfg()
+    p = _reshape_weights(sm.init_params(mcfg, seed=1), dist, seed=77)
+    model = dba.TensorProductModelHIP({}).to(dev)
+    model.load_state_dict(p, strict=True)
+    lib, h = L.load(), model.handle(dev)
+    fallback = model.fallback_convs(dev)
+    print(dist, "fallback convs:", fallback)
+    if dist in ("student_t2", "rows_4dec", "x1e-3", "x1e3"):
+        assert fallback == [], fallback               # these fit two fp16 pieces: no conv leaves the default kernel
+    if dist == "chan_6dec":
+        assert len(fallback) >= 20, fallback          # (every conv with more than a handful of channels per run)
+    p64 = {k: v.double() for k, v in p.items()}
+    E = 600
+    worst = {}
+    for layer, fam, name in K144_CONVS:
+        i, shirr, o, nef = sm.conv_specs(mcfg)[name]
+        Din, Dout = o3.Irreps(i).dim, o3.Irreps(o).dim
+        g = torch.Generator().manual_seed(11 + abs(layer))
+        N = 64
+        x, xt = torch.randn(N, Din, generator=g), torch.randn(N, max(Din, 48), generator=g)
+        tgt = torch.sort(torch.randint(0, N, (E,), generator=g)).values
+        gth = torch.randint(0, N, (E,), generator=g)
+        emb = torch.randn(E, 48, generator=g)
+        if "tor" in name:
+            sh_full = torch.randn(E, o3.Irreps(shirr).dim, generator=g)
+            sh9 = torch.zeros(E, 9)
+            sh9[:, :7] = sh_full[:, :7]
+        else:
+            sh_full = o3.spherical_harmonics(shirr, torch.randn(E, 3, generator=g), True, "component")
+            sh9 = sh_full.clone()
+        a64 = torch.cat([emb, xt[tgt, :48], x[gth, :48]], -1).double()
+        m64 = sm._tp(i, shirr, o)(x[gth].double(), sh_full.double(), sm.simple_linear(p64, f"{name}.fc", a64))
+        assert m64.dtype == torch.float64
+        c = dict(x=x.to(dev), xt=xt.to(dev), tgt=tgt.to(dev, torch.int32), gth=gth.to(dev, torch.int32), emb=emb.to(dev),
+                 sh=sh9.contiguous().to(dev), Din=Din, Dout=Dout)
+        col = m64.abs().amax(dim=0).clamp_min(1e-300)                  # per output column: its own size
+        res = {}
+        for mode, fn in (("f32", lib.dbfr_test_conv), ("split_f16", lib.dbfr_test_conv2)):
+            with gemm(model, mode):
+                m = _run_conv_hook(fn, h, layer, fam, c, E, dev)
+            assert torch.isfinite(m).all(), (name, mode)
+            dm = (m.cpu().double() - m64) / col
+            res[mode] = (float(dm.abs().max()), float(dm.pow(2).mean().sqrt()))
+        worst[name] = res
+        print(f"  {dist:10s} {name:24s} max/rms per-column error vs float64: f32 {res['f32'][0]:.2e} / {res['f32'][1]:.2e}   "
+              f"default {res['split_f16'][0]:.2e} / {res['split_f16'][1]:.2e}" + ("   (served by k_conv2r)" if name in fallback else ""))
+        if name in fallback:
+            assert res["split_f16"][0] <= 1.25 * res["f32"][0] + 5e-8 and res["split_f16"][1] <= 1.25 * res["f32"][1] + 5e-8, (name, res)
+        else:
+            assert res["split_f16"][0] <= res["f32"][0] and res["split_f16"][1] <= res["f32"][1], (name, res)
+    model.release()
+
+
+def test_seeded_weights_need_no_fallback(setup, dev):
+    """The weights every fixture and the bench use (seeded xavier / torch-default init): no conv leaves the fp16 kernel."""
+    assert setup[2].fallback_convs(dev) == []
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1e3, 1e13, "ragged"])
 def test_split_f16_scales_its_operands_per_edge(setup, dev, scale):
     """k_conv2h brings its operands into fp16's exponent range with exact powers of two chosen PER EDGE (radial-MLP inputs and hidden
     activations) -- so radial-MLP inputs 1e-4 or 1e3 times their usual size, or edges whose inputs differ by eight decades inside one
-    wave, must cost no accuracy against the fp32 instruction (unscaled, the pieces would underflow / overflow: tools/exp/split_f16.hip)."""
+    wave, must cost no accuracy against the fp32 instruction (unscaled, the pieces would underflow / overflow: tools/exp/split_f16.hip).
+    1e13 (> 2^41): the per-edge factor must follow inputs of any finite size -- a clamp on the large side would make the scaled inputs
+    overflow fp16 into inf / NaN messages where the other kernels return finite ones."""
     mcfg, p, model = setup
     lib, h = L.load(), model.handle(dev)
     layer, fam, E = 3, 2, 9000

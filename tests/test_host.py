@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(L.SYMBOLS) == declared
-    assert lib.dbfr_abi_version() == 2
+    assert lib.dbfr_abi_version() == 3
 
 
 def test_gemm_mode_entry_points_reject_bad_arguments():
@@ -64,6 +64,36 @@ def test_product_schedule_equals_oracle_schedule():
         r = recs[i]
         assert r.rot_score_norm == float(o.rot_score_norm) and r.tor_score_norm2 == float(o.tor_score_norm2)
         assert r.tr_gsdt == float(o.tr_g * np.sqrt(o.dt)) and r.sc_g2 == float(o.sc_tor_g ** 2)
+
+
+def test_product_schedule_ode_and_guards():
+    """`sample_cfg.type='ode'` (scFlex.py:162-165,199-200): drift 0.5 g^2 (exactly half the SDE's factor), no noise factor, no step draws;
+    `no_random` (:167-183): SDE factors, no step draws; `time_schedule` other than 'linear' raises the reference's error (:91)."""
+    sde, _ = psched.steps(psched.sample_cfg())
+    ode, arr = psched.steps(psched.sample_cfg(dict(type="ode")))
+    nor, _ = psched.steps(psched.sample_cfg(dict(no_random=True)))
+    assert len(ode) == len(sde) == 20
+    for a, b, c in zip(sde, ode, nor):
+        for k in ("tr", "rot", "tor", "sc"):
+            assert getattr(b, f"{k}_g2") == float(np.float32(0.5) * np.float32(getattr(a, f"{k}_g2"))) and getattr(b, f"{k}_gsdt") == 0.0
+            assert getattr(c, f"{k}_g2") == getattr(a, f"{k}_g2") and getattr(c, f"{k}_gsdt") == getattr(a, f"{k}_gsdt")
+        assert (b.t, b.dt, b.rot_score_norm, b.tor_score_norm2) == (a.t, a.dt, a.rot_score_norm, a.tor_score_norm2)
+        assert b.noise_free and c.noise_free
+    assert arr[0].tr_gsdt == 0.0 and arr[5].tr_g2 == np.float32(ode[5].tr_g2)
+    zm = np.load(os.path.join(GOLDEN, "sampler_modes.npz"))
+    with pytest.raises(NotImplementedError) as e:
+        psched.steps(psched.sample_cfg(dict(time_schedule="cosine")))
+    assert str(e.value) == str(zm["time_schedule_error"])
+    # the drop-in reads the mode from test_cfg.sample_cfg like the reference (scFlex.py:131)
+    import diffbindfr_amd as dba
+    samp = dba.DiffBindFRHIP(diffusion_model=None, test_cfg=dict(sample_cfg=dict(type="ode")))
+    recs, _ = samp.schedule()
+    assert all(r.noise_free and r.tr_gsdt == 0.0 for r in recs)
+    from diffbindfr_amd.sampler import draw_noise_tape
+    g = torch.Generator().manual_seed(3)
+    st = g.get_state()
+    z = draw_noise_tape(recs, 2, 3, 4, generator=g)
+    assert torch.equal(g.get_state(), st) and all(float(v.abs().max()) == 0.0 for v in z.values())      # nothing drawn
 
 
 def test_state_dict_contract():

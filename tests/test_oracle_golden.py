@@ -4,6 +4,7 @@ import copy
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import geometry, sampler, schedule, score_model as sm
@@ -91,3 +92,29 @@ def test_score_model_and_sampler_fixture():
     lig, a14 = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise, t(T["atom14_to_group"]).long(), visualize=True)
     assert (lig - t(z["traj_lig"])).norm(dim=-1).max() < 1e-3
     assert (a14 - t(z["traj_atom14"])).norm(dim=-1).max() < 1e-3
+
+
+@pytest.mark.parametrize("tag,over", [("ode", dict(type="ode")), ("no_random", dict(no_random=True))])
+def test_sampler_modes_fixture(tag, over):
+    """tests/golden/sampler_modes.npz: the reference's own sample() with `type='ode'` (scFlex.py:162-165,199-200) and with
+    `no_random=True` (:167-183) on the batch of sampler.npz; the oracle follows both (0.0 at generation time)."""
+    d, z = load_golden_batch()
+    zm = np.load(os.path.join(GOLDEN, "sampler_modes.npz"))
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=int(zm["params_seed"]))
+    scfg = schedule.default_sample_cfg(**over)
+    G = d.num_graphs
+    # a tape of ones: neither mode may read it
+    noise = sampler.draw_noise(scfg.actual_steps, G, int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum()), seed=1)
+    for k in ("tr", "rot", "tor", "sc"):
+        getattr(noise, k).fill_(1.0)
+    lig, a14 = sampler.sample(params, mcfg, scfg, copy.deepcopy(d), noise, t(T["atom14_to_group"]).long(), visualize=True)
+    assert (lig - t(zm[f"{tag}_traj_lig"])).norm(dim=-1).max() < 1e-3
+    assert (a14 - t(zm[f"{tag}_traj_atom14"])).norm(dim=-1).max() < 1e-3
+
+
+def test_time_schedule_guard_matches_the_reference():
+    zm = np.load(os.path.join(GOLDEN, "sampler_modes.npz"))
+    with pytest.raises(NotImplementedError) as e:
+        schedule.t_schedule(schedule.default_sample_cfg(time_schedule="cosine"))
+    assert str(e.value) == str(zm["time_schedule_error"])
