@@ -2,6 +2,11 @@
 """Benchmark of the MI355X-native DiffBindFR sampler (BASELINE.json metric: poses/sec).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|1] [--batch-poses B] [--scaling weak|strong]
+                    [--jobs J] [--store device|host] [--gather all|root]
+
+`--gpus N` with N > 1 and no torchrun environment: the script spawns its own N ranks (one process per GPU, LOCAL_RANK -> cuda:LOCAL_RANK,
+rendezvous on 127.0.0.1), relays rank 0's ONE JSON line and returns the ranks' worst exit code; under `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` it uses the environment it finds (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
 
 One "step" = one pass of the hot path over one device batch: B synthetic (complex x pose) graphs of the named
 BASELINE.json config taken through all 20 reverse-diffusion steps by ONE dbfr_sample call (score network x20 + SDE
@@ -258,6 +263,49 @@ def latency_leg(samp, dev, lib, model):
     return out
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N children of this very command, one per GPU, with the torchrun environment
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  Rank 0's stdout carries the ONE JSON line and is
+    relayed; the other ranks' stdout goes to stderr.  Any rank failing ends the others (by their exact pids) and is the exit code --
+    the model is the reference's own multi-process test entry (druglib/core/runner/engine/test_utils.py:96-145 gathers from ranks a
+    launcher started)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports (RCCL needs it)
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0 = ""
+    try:
+        out0, _ = procs[0].communicate()
+    finally:
+        rcs = []
+        for r, p in enumerate(procs):
+            try:
+                rcs.append(p.wait(timeout=None if procs[0].returncode == 0 else 60))
+            except subprocess.TimeoutExpired:          # rank 0 failed and this rank hangs in a collective: end it (exact pid)
+                p.kill()
+                rcs.append(p.wait())
+    lines = [l for l in out0.splitlines() if l.startswith('{"metric"')]
+    for l in out0.splitlines():
+        if not l.startswith('{"metric"'):
+            print(l, file=sys.stderr)
+    rc = next((c for c in rcs if c != 0), 0)
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: expected ONE result line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,7 +321,12 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="no child runs under rocprofv3 --pmc (roofline.traffic falls back to the constant of profiles/)")
     ap.add_argument("--cpu-poses", type=int, default=None)
     ap.add_argument("--cpu-batched-steps", type=int, default=5)
+    ap.add_argument("--jobs", type=int, default=None, help="size of the job table (weak scaling: per rank); default --steps x (--batch-poses // poses per job)")
+    ap.add_argument("--store", choices=("device", "host"), default="device", help="dist.run_sharded: pose records in HBM, or streamed to pinned host memory batch by batch")
+    ap.add_argument("--gather", choices=("all", "root"), default="all", help="dist.run_sharded: every rank receives every pose, or rank 0 only")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher: be one
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too -- RCCL prints its version banner to the C stdout of
     # rank 0, block-buffered, i.e. it would land BEHIND the line when the process exits -- so file descriptor 1 is pointed at stderr for
@@ -283,7 +336,7 @@ def main():
     os.dup2(2, 1)
 
     rank, world, local = ddist.init()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (a launcher's environment that does not match the command line)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device(f"cuda:{local % torch.cuda.device_count()}")   # one rank per GPU; the modulo only matters for the gloo dry run
     torch.cuda.set_device(dev)
@@ -297,7 +350,7 @@ def main():
     samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
     recs, _ = samp.schedule()
     T = len(recs)
-    n_jobs = args.steps * jobs_per_batch * (world if args.scaling == "weak" else 1)
+    n_jobs = (args.jobs if args.jobs else args.steps * jobs_per_batch) * (world if args.scaling == "weak" else 1)
     jobs = make_jobs(args.config, n_jobs, seed=1)
     shards, reps = ddist.shard_jobs(jobs, ppc, world)
     for j in shards[rank]:                       # per-complex records resident in HBM before the timed region
@@ -311,6 +364,7 @@ def main():
         lib.dbfr_profile_read(h, None, None, None, None, 1)
         lib.dbfr_profile_enable(h, 1)
     done = []
+    torch.cuda.reset_peak_memory_stats(dev)
     ddist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -319,17 +373,25 @@ def main():
     def on_batch(i, n):
         done.append(n)
         stamps.append(time.perf_counter())      # every batch ends with a status sync on its stream: the stamp is a completion time
-    res = ddist.run_sharded(samp, jobs, ppc, seed=100, device=dev, batch_poses=B, on_batch=on_batch)
+    res = ddist.run_sharded(samp, jobs, ppc, seed=100, device=dev, batch_poses=B, on_batch=on_batch, store=args.store, gather=args.gather,
+                            release=False)      # (the records stay resident: they were uploaded before the timed region)
     torch.cuda.synchronize(dev)
+    t_local = time.perf_counter() - t0          # this rank's own clock, sampling + gather
     ddist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = ddist.max_over_ranks(elapsed, dev)
+    t_sampled = (stamps[-1] - t0) if stamps else 0.0
+    # what every rank did, all-gathered: the line shows that the collective saw `world` ranks, and on which devices
+    per_rank = ddist.all_gather_vec([rank, dev.index, float(sum(done)), len(done), t_local, t_sampled,
+                                     torch.cuda.max_memory_allocated(dev) / 2 ** 30], dev)
     counters = (C.c_int64 * 8)()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     L.check(lib.dbfr_status_sync(C.c_void_p(model.workspace_of(dev).data_ptr()), stream, counters))
-    assert all(r is not None and torch.isfinite(r[0]).all() and torch.isfinite(r[1]).all() for r in res), "non-finite pose coordinates"
+    mine = res if (args.gather == "all" or rank == 0) else [res[j] for j in shards[rank]]
+    assert all(r is not None and torch.isfinite(r[0]).all() and torch.isfinite(r[1]).all() for r in mine), "non-finite pose coordinates"
     poses = sum(reps)
-    assert sum(int(r[0].shape[0]) for r in res) == poses
+    if args.gather == "all" or rank == 0:
+        assert sum(int(r[0].shape[0]) for r in res) == poses
 
     def read_roofline(elapsed_s, mode):
         """The dominant kernel's line from the library's own HIP events (recorded on the stream the kernel runs on)."""
@@ -423,7 +485,12 @@ def main():
                        "arithmetic": "fp32 in, fp32 out; radial MLP's 144 x W GEMM: " + PIPE[mode]["arithmetic"],
                        "parallelism": f"dp{world}: jobs LPT-sharded, poses of a job on one GPU, ragged [ligand | atom14] records gathered at the end "
                                       f"(all_gather_into_tensor in windows of 256 MiB per rank)",
-                       "dist_backend": (ddist.dist.get_backend() if ddist.dist.is_initialized() else None)},
+                       "dist_backend": (ddist.dist.get_backend() if ddist.dist.is_initialized() else None),
+                       "store": args.store, "gather": args.gather,
+                       "ranks_seen": len(per_rank),
+                       "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
+                                     "sampling_s": round(v[5], 4), "gather_and_unpack_s": round(v[4] - v[5], 4),
+                                     "torch_peak_hbm_gib": round(v[6], 3)} for v in per_rank]},
             "roofline": roof,
         }
         if native is not None:

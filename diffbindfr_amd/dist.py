@@ -108,6 +108,16 @@ def max_over_ranks(x, device):
     return float(t)
 
 
+def all_gather_vec(vals, device):
+    """A few numbers per rank, from every rank to every rank: list[world] of lists (bench.py's per-rank read-out)."""
+    if not _active():
+        return [[float(v) for v in vals]]
+    t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
 def barrier():
     if _active():
         dist.barrier()
@@ -181,7 +191,7 @@ def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
 
 
 def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_max=10.0, gather=True, on_batch=None,
-                store="device", window_bytes=256 << 20, release=True, tapes=None):
+                store="device", window_bytes=256 << 20, release=False, tapes=None):
     """The multi-GPU product entry: a job list in, poses out in job order.
 
         jobs    list of ``assemble.ComplexRecord`` -- the (protein, ligand) pair table of the reference
@@ -195,7 +205,9 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
         store   "device": the pose records stay in HBM; "host": every batch's records go to pinned host memory as the batch
                 finishes and the gather is staged through a ``window_bytes`` device buffer -- HBM use is then bounded by one
                 batch + the window, whatever the size of the job table.
-        release drop a record half's device copy (``_Half.release``) after the last batch of this rank that uses it.
+        release True: drop a record half's device copy (``_Half.release``) after the last batch of this rank that uses it -- for job
+                tables whose records do not fit HBM together (the forward screen's 10 k ligands do, at 20 KB each).  It MUTATES the
+                caller's records (a second run uploads them again), hence off by default.
         tapes   {job index: (init tape, noise tape)} of recorded random numbers used instead of drawing (``draw_tapes``).
 
     Every rank holds the whole (cheap, host-side) job table, takes its LPT share, runs it in batches of <= ``batch_poses``

@@ -311,10 +311,50 @@ class KarmaDockHIP(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ the Scorer entry
+def scorer_state_dict(ckpt):
+    """The scorer's parameters out of whatever the reference's loaders read (DiffBindFR/scoring/utils/early_stop.py:27-38):
+      * ``{'model': {...}}`` -- ``Early_stopper.load_model(mine=True)``, the route ``Scorer`` takes with ``mdn_paper.pt``
+        (engines.py:262-268): every key loses its first SIX characters (the saved wrapper's prefix) and gets ``module.`` for the
+        DataParallel model the reference loads into -- here the bare name remains;
+      * ``{'model_state_dict': {...}}`` -- ``mine=False`` / ``save_model``;
+      * a flat state_dict.
+    A ``module.`` prefix (DataParallel) is dropped in every case."""
+    if not isinstance(ckpt, dict):
+        raise TypeError(f"scorer checkpoint: expected a dict, got {type(ckpt).__name__}")
+    if "model" in ckpt and isinstance(ckpt["model"], dict):
+        sd = {k[6:]: v for k, v in ckpt["model"].items()}
+    elif "model_state_dict" in ckpt and isinstance(ckpt["model_state_dict"], dict):
+        sd = ckpt["model_state_dict"]
+    else:
+        sd = ckpt
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def load_scorer_weights(model, ckpt, min_fraction=0.9):
+    """``strict=False`` like the reference (its checkpoint carries pose-prediction modules the scoring forward never calls) -- but a load
+    that matches (almost) none of the model's parameters is an error here, not a silent run on the initial parameters: raises unless
+    at least ``min_fraction`` of ``model``'s parameters and buffers were found with their shapes.  Returns the matched key count."""
+    sd = scorer_state_dict(ckpt)
+    mine = model.state_dict()
+    hit = [k for k in mine if k in sd and tuple(sd[k].shape) == tuple(mine[k].shape)]
+    if len(hit) < min_fraction * len(mine):
+        bad = [k for k in mine if k in sd and tuple(sd[k].shape) != tuple(mine[k].shape)]
+        raise L.DbfrError(f"scorer checkpoint: {len(hit)} of {len(mine)} parameters found (first missing: "
+                          f"{[k for k in mine if k not in sd][:3]}, shape mismatches: {bad[:3]}, checkpoint keys look like {list(sd)[:3]}); "
+                          f"refusing to score with the initial parameters")
+    model.load_state_dict(sd, strict=False)
+    return len(hit)
+
+
 def collate_flat(items):
     """Concatenate flat per-pair dicts (``batch_from_hetero`` layout, one graph each or already batched) into one batch --
     what the reference's PyG DataLoader does with the HeteroData samples (engines.py:270-277): node tensors stacked, edge
-    indices shifted by the node offsets, ``*_batch`` renumbered."""
+    indices shifted by the node offsets, ``*_batch`` renumbered.  Every item must carry the same keys (``lig_batch`` /
+    ``pro_batch`` may be absent: one graph)."""
+    keys = set(items[0])
+    for i, it in enumerate(items):
+        if set(it) != keys:
+            raise KeyError(f"collate_flat: item {i} has keys {sorted(set(it) ^ keys)} that the others lack (or lacks theirs)")
     out = {k: [] for k in items[0]}
     lo = po = g = 0
     for it in items:
@@ -347,25 +387,37 @@ def Scorer(test_dataset, model_weight=None, output_path="mdn_score.csv", batch_s
 
     ``test_dataset``: indexable, ``len()``; item i is the featurised sample of pair i -- the reference's HeteroData (anything
     ``batch_from_hetero`` reads) or the flat dict -- and ``pair_frame`` a pandas frame with one row per item (optional).
-    ``model_weight``: a state_dict, a path ``torch.load`` reads, or None (keep ``model``'s weights); keys carrying
-    DataParallel's ``module.`` prefix are accepted, unknown keys ignored (``strict=False`` like engines.py:263-268).
-    Batches of ``batch_size`` samples are collated here (``collate_flat``) and go through ONE ``dbfr_mdn_forward`` each.
+    ``model_weight``: a checkpoint dict, a path ``torch.load`` reads, or None (keep ``model``'s weights) -- in any of the layouts the
+    reference's ``Early_stopper.load_model`` reads (``scorer_state_dict``: ``mdn_paper.pt`` is ``{'model': {'<6-char prefix><name>': ...}}``);
+    unknown keys are ignored (``strict=False`` like engines.py:263-268), but a checkpoint that matches less than 90 % of the model's
+    parameters raises (``load_scorer_weights``) instead of scoring with the initial parameters.
+    Batches of ``batch_size`` samples are collated here (``collate_flat``) and go through ONE ``dbfr_mdn_forward`` each.  A sample that
+    is ``None`` (failed featurisation) is left out of its batch like the reference's PassNoneDataLoader does
+    (scoring/dataset/dataloader.py:16-17) and its row gets NaN -- the reference's frame assignment would raise on the length mismatch.
     Returns the list of scores (the reference returns None after writing the file)."""
     dev = torch.device(f"cuda:{device_id}" if not isinstance(device_id, torch.device) else device_id)
     model = model or KarmaDockHIP()
-    if model_weight is not None:
-        sd = model_weight if isinstance(model_weight, dict) else torch.load(str(model_weight), map_location="cpu")
-        sd = sd.get("model_state_dict", sd) if isinstance(sd, dict) else sd
-        model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}, strict=False)
     if logger is not None:
         logger.info("Load scoring model...")
+    if model_weight is not None:
+        ckpt = model_weight if isinstance(model_weight, dict) else torch.load(str(model_weight), map_location="cpu")
+        n_hit = load_scorer_weights(model, ckpt)
+        if logger is not None:
+            logger.info(f"scoring model: {n_hit} tensors loaded")
     scores = []
     n = len(test_dataset)
     for i0 in range(0, n, batch_size):
         items = [test_dataset[i] for i in range(i0, min(n, i0 + batch_size))]
-        flat = [it if isinstance(it, dict) and "ligand" not in it else batch_from_hetero(it) for it in items]
-        d = {k: v.to(dev) for k, v in collate_flat(flat).items()}
-        scores.extend(model.score(d).cpu().numpy().tolist())
+        keep = [k for k, it in enumerate(items) if it is not None]
+        part = [float("nan")] * len(items)
+        if keep:
+            flat = [items[k] if isinstance(items[k], dict) and "ligand" not in items[k] else batch_from_hetero(items[k]) for k in keep]
+            d = {k: v.to(dev) for k, v in collate_flat(flat).items()}
+            got = model.score(d).cpu().numpy().tolist()
+            assert len(got) == len(keep), "one sample = one graph"
+            for k, v in zip(keep, got):
+                part[k] = v
+        scores.extend(part)
     frame = getattr(test_dataset, "pair_frame", None)
     if frame is not None:
         frame["mdn_score"] = scores

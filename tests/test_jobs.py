@@ -209,6 +209,9 @@ def test_record_halves_are_released_after_their_last_batch():
             seen.append(len(jobs[0].pocket.__dict__.get("_dev", {})))
             return super().run_complexes(records, poses, device, tr_sigma_max, seeds, pose_ranges)
     ddist.run_sharded(Spy(), jobs, poses, seed=1, device="cpu", batch_poses=bp)
+    assert all(len(j.lig.__dict__.get("_dev", {})) == 1 for j in jobs)     # default: the caller's records are left as they were uploaded
+    seen.clear()
+    ddist.run_sharded(Spy(), jobs, poses, seed=1, device="cpu", batch_poses=bp, release=True)
     assert all(s == 1 for s in seen)                       # the shared pocket stays resident while batches still need it ...
     assert "_dev" not in jobs[0].pocket.__dict__           # ... and is dropped after the last one
     assert all("_dev" not in j.lig.__dict__ for j in jobs)
@@ -394,6 +397,54 @@ def test_bench_line_through_rccl_on_one_rank():
 
 
 @pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's own command form): the script starts its two ranks itself
+    (LOCAL_RANK -> device, rendezvous on 127.0.0.1), rank 0's ONE line comes back through the parent, and the line shows that the
+    collectives saw two ranks.  gloo, because two RCCL ranks cannot share the one GPU of this box."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DBFR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch-poses", "320",
+                        "--no-profile"], env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and out[0].startswith('{"metric"'), r.stdout[-2000:]          # ONE line on stdout, nothing else
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    c = line["config"]
+    assert c["dist_backend"] == "gloo" and c["ranks_seen"] == 2 and c["poses_total"] == 640
+    assert sorted(p["rank"] for p in c["per_rank"]) == [0, 1] and sum(p["poses"] for p in c["per_rank"]) == 640
+    assert all(p["elapsed_s"] > 0 for p in c["per_rank"])
+    # a launcher environment that contradicts the command line is refused, not silently run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-profile"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_launcher_relays_one_line_and_the_worst_exit_code(tmp_path, monkeypatch):
+    """bench.spawn_ranks without a GPU: the children are this interpreter running a stand-in script; rank 0's result line is relayed
+    alone, other output goes to stderr, a failing rank makes the launch fail."""
+    import bench
+    stand_in = tmp_path / "child.py"
+    stand_in.write_text("import os, sys\n"
+                        "r = int(os.environ['RANK']); assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r)\n"
+                        "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                        "print('noise from rank', r)\n"
+                        "if r == 0: print('{\"metric\": \"poses_per_sec\", \"n_gpus\": 3}')\n"
+                        "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == r)\n")
+    monkeypatch.setattr(bench, "__file__", str(stand_in))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.spawn_ranks(3, [])
+    assert rc == 0 and buf.getvalue().strip() == '{"metric": "poses_per_sec", "n_gpus": 3}'
+    monkeypatch.setenv("FAIL_RANK", "2")
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert bench.spawn_ranks(3, []) == 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg_id,n_jobs,poses,small_batch", [(2, 16, 40, 160), (5, 2, 20, 20)])
 def test_full_size_batch_equals_small_batches_bit_for_bit(cfg_id, n_jobs, poses, small_batch):
     """BASELINE-sized batches (cfg 2: 16 complexes x 40 poses = the bench batch; cfg 5: 40 poses of 600-atom pockets) take the
@@ -418,7 +469,7 @@ def test_host_store_equals_device_store_on_the_gpu():
     _, jobs = make_jobs(3, 5, 60, 10, seed=6)
     poses = [3, 2, 7, 1, 2]
     a = ddist.run_sharded(samp, jobs, poses, seed=4, device=dev, batch_poses=4)
-    b = ddist.run_sharded(samp, jobs, poses, seed=4, device=dev, batch_poses=4, store="host", gather="root")
+    b = ddist.run_sharded(samp, jobs, poses, seed=4, device=dev, batch_poses=4, store="host", gather="root", release=True)
     for (l0, a0), (l1, a1) in zip(a, b):
         assert l1.device.type == "cpu" and l1.is_pinned()
         assert torch.equal(l0.cpu(), l1) and torch.equal(a0.cpu(), a1)

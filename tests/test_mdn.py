@@ -251,6 +251,35 @@ def test_scoring_model_goes_through_the_energy_registry():
         dba.DiffBindFRHIP(diffusion_model=None, scoring_model={"type": "NoSuchScorer"})
 
 
+def test_scorer_checkpoint_layouts_of_the_reference_loader():
+    """DiffBindFR/scoring/utils/early_stop.py:27-38: `Scorer` loads `mdn_paper.pt` with `mine=True` = `torch.load(f)['model']`, every key
+    re-keyed as 'module.' + k[6:]; `mine=False` reads ['model_state_dict'].  All three layouts (+ DataParallel's prefix) must reach the
+    model's own names -- and a checkpoint that reaches none of them must raise instead of scoring with the initial parameters."""
+    from diffbindfr_amd import lib as L, mdn
+    P = oms.init_params(seed=11)
+    model = mdn.KarmaDockHIP()
+    assert set(model.state_dict()) <= set(P) | set(model.state_dict())
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    extra = {"egnn_layers.0.weight": torch.zeros(3)}            # the checkpoint carries modules the scoring forward never calls
+    for ckpt in ({"model": {"model." + k: v for k, v in {**P, **extra}.items()}},          # six-character wrapper prefix
+                 {"model": {"abcde." + k: v for k, v in P.items()}},                      # (any six characters: the reference cuts by count)
+                 {"model_state_dict": {"module." + k: v for k, v in P.items()}},
+                 {"module." + k: v for k, v in P.items()}, dict(P)):
+        m = mdn.KarmaDockHIP()
+        n = mdn.load_scorer_weights(m, ckpt)
+        assert n == len(m.state_dict())
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, P[k].to(v.dtype)), k
+    assert any(not torch.equal(before[k], P[k].to(before[k].dtype)) for k in before)      # (the load changed something)
+    for bad in ({"model": dict(P)},                              # 'model' layout without the prefix: six characters of every NAME are cut
+                {"state_dict": dict(P)}, {"model." + k: v for k, v in P.items()}):
+        with pytest.raises(L.DbfrError, match="refusing to score"):
+            mdn.load_scorer_weights(mdn.KarmaDockHIP(), bad)
+    with pytest.raises(KeyError, match="collate_flat"):
+        mdn.collate_flat([{"lig_pos": torch.zeros(2, 3), "pro_node_s": torch.zeros(3, 9)},
+                          {"lig_pos": torch.zeros(2, 3), "pro_node_s": torch.zeros(3, 9), "lig_batch": torch.zeros(2)}])
+
+
 @pytest.mark.gpu
 def test_gpu_scorer_entry_writes_the_pair_frame(tmp_path):
     """``mdn.Scorer`` (engines.py:230-302): samples one by one -> batches of `batch_size` -> mdn_score column + csv; the scores
@@ -277,3 +306,12 @@ def test_gpu_scorer_entry_writes_the_pair_frame(tmp_path):
         assert list(back.columns) == ["pair", "mdn_score"] and np.allclose(back["mdn_score"], s)
         out.append(s)
     assert np.allclose(out[0], out[1], rtol=1e-5)
+    # the checkpoint layout `Scorer` meets in the reference (mdn_paper.pt through Early_stopper.load_model(mine=True)), and a sample whose
+    # featurisation failed (None): left out of its batch like PassNoneDataLoader does, NaN in its row
+    ds = DS(items[:2] + [None] + items[2:])
+    ds.pair_frame = pd.DataFrame({"pair": list(range(len(ds)))})
+    s = mdn.Scorer(ds, model_weight={"model": {"model." + k: v for k, v in P.items()}}, output_path=tmp_path / "mdn_none.csv", batch_size=4, device_id=0)
+    assert len(s) == 6 and np.isnan(s[2]) and rel_err(torch.tensor(s[:2] + s[3:]), ref) < 1e-4
+    from diffbindfr_amd import lib as L
+    with pytest.raises(L.DbfrError, match="refusing to score"):
+        mdn.Scorer(DS(items), model_weight={"model": dict(P)}, output_path=None, device_id=0)
