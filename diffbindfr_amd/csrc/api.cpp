@@ -863,7 +863,7 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   for (int k = 0; k < N_SETS; ++k) {
     if (caps[k] > 0x7fffff00L) return fail(DBFR_ERR_ARG, "batch too large for int32 edge indices; split it");
     static const char* names[N_SETS] = {"ll", "aa", "al", "la", "tor", "sc"};
-    edge_set_take(b, w->set[k], (int)caps[k], ntg[k] + 1, G * ((B->max_na + 255) / 256), w->n_edges6 ? w->n_edges6 + k : nullptr, names[k]);
+    edge_set_take(b, w->set[k], (int)caps[k], ntg[k] + 1, G * dbfr_edge_chunks(B->max_na, B->max_nl), w->n_edges6 ? w->n_edges6 + k : nullptr, names[k]);
     maxcap = std::max(maxcap, caps[k]);
   }
   w->c_tgt = b.take<int>(NL); w->c_gth = b.take<int>(NL); w->c_dist = b.take<float>(NL); w->c_sh = b.take<float>((size_t)NL * SH_LD, "center.sh");

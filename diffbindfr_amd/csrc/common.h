@@ -13,6 +13,8 @@
 #define SH_LD 9         // per-edge spherical-harmonic record (l=0..2), tor convs use 7 of 9
 #define EMB 32          // sigma / distance embedding width
 #define MAXD 168        // widest irreps feature: 48x0e+12x1o+12x1e+48x0o
+#define EDGE_CHUNK 64   // targets per workgroup of the edge builder (graph.hip: k_edges), 4 lanes each
+int dbfr_edge_chunks(int max_na, int max_nl);   // workgroups per (graph, edge set): sizes EdgeSet::g_cnt / g_base
 
 // kernel-side tensor-product path types: closed forms of the real Wigner-3j tensors
 enum PathType { PT_SS = 0, PT_SV = 1, PT_VS = 2, PT_VVS = 3, PT_VVV = 4, PT_VTV = 5 };
@@ -144,7 +146,7 @@ struct EdgeSet {           // one per-step edge list, grouped (CSR) by scatter-t
   float* emb;          // [cap][NS] edge embedding after its SimpleLinear
   int* row_start;      // [n_targets]
   int* row_cnt;        // [n_targets]
-  int* g_cnt;          // [G * n_chunk] per-(graph, target chunk) totals (count pass)
+  int* g_cnt;          // [G * n_chunk] per-(graph, target chunk) totals (count pass); n_chunk = dbfr_edge_chunks()
   int* g_base;         // [G * n_chunk] base offset of each chunk's first edge (scan)
 };
 

@@ -579,6 +579,12 @@ __device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, i
   if (lane < d4) {
     const f32x4* r = reinterpret_cast<const f32x4*>(msg + (size_t)rs * D) + lane;
     int e = 0;
+    // eight rows requested before the first add (the adds keep the CSR order: same bits as any other unrolling)
+    for (; e + 8 <= rc; e += 8) {
+      const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
+      const f32x4 v4 = r[(size_t)(e + 4) * d4], v5 = r[(size_t)(e + 5) * d4], v6 = r[(size_t)(e + 6) * d4], v7 = r[(size_t)(e + 7) * d4];
+      acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+    }
     for (; e + 4 <= rc; e += 4) {
       const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
       acc += v0; acc += v1; acc += v2; acc += v3;

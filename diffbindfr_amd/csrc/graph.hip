@@ -36,7 +36,7 @@ struct GraphArgs {
                           // [2+k] set k overflowed in THIS step, [8+k] largest edge count seen for set k
   int step;               // sampler step index (0 for dbfr_score)
   int lds_nl, lds_na;     // LDS staging capacities (>= max_nl / max_na of the batch)
-  int n_chunk;            // 256-target chunks per graph the pocket-atom-targeted sets are split into (own workgroup each)
+  int n_chunk;            // EDGE_CHUNK-target chunks per graph every set is split into (own workgroup each)
 };
 
 __device__ __forceinline__ float d2_rn(float ax, float ay, float az, float bx, float by, float bz) {
@@ -122,11 +122,13 @@ __device__ void cap_thresholds(GraphLds& s, const float* px, const float* py, co
   __syncthreads();
 }
 
-// Count (emit == false) or emit the edges of target `t` (local index) of the given set.
-// Returns the number of edges of the target.  `base` = absolute slot of its first edge.
+// Count (EMIT == false) or emit the edges of target `t` (local index) of the given set whose gather candidates lie in the lane's
+// share [lo, hi) of the candidate range (EDGE_LANES lanes per target, contiguous shares in index order; the lane with `first` also
+// takes the ligand's bond edges, which come first in the reference's edge list).  Returns the number of edges of the share.
+// `base` = absolute slot of the share's first edge.
 template <bool EMIT>
 __device__ int target_edges(const GraphLds& s, const GraphArgs& A, int kind, int g, int t, int l0, int nl, int a0,
-                            int na, int base) {
+                            int na, int lo, int hi, bool first, int base) {
   const EdgeSet& S = A.set[kind];
   int cnt = 0;
   auto emit = [&](int tgt, int gth, int aux, float vx, float vy, float vz) {
@@ -146,11 +148,12 @@ __device__ int target_edges(const GraphLds& s, const GraphArgs& A, int kind, int
   const float* RP = A.b.rec_pos;
   if (kind == SET_LL) {
     const int gt = l0 + t;
-    for (int k = A.b.bond_ptr[gt]; k < A.b.bond_ptr[gt + 1]; ++k) {  // bond edges (u=t -> v): tgt=u, gth=v
-      int v = A.b.bond_dst[k];
-      emit(gt, v, k, LP[3 * v] - LP[3 * gt], LP[3 * v + 1] - LP[3 * gt + 1], LP[3 * v + 2] - LP[3 * gt + 2]);
-    }
-    for (int i = 0; i < nl; ++i) {
+    if (first)
+      for (int k = A.b.bond_ptr[gt]; k < A.b.bond_ptr[gt + 1]; ++k) {  // bond edges (u=t -> v): tgt=u, gth=v
+        int v = A.b.bond_dst[k];
+        emit(gt, v, k, LP[3 * v] - LP[3 * gt], LP[3 * v + 1] - LP[3 * gt + 1], LP[3 * v + 2] - LP[3 * gt + 2]);
+      }
+    for (int i = lo; i < hi; ++i) {
       if (i == t || t > s.thr[i]) continue;
       if (d2_rn(s.lx[i], s.ly[i], s.lz[i], s.lx[t], s.ly[t], s.lz[t]) < A.lig_cut2) {
         int gi = l0 + i;  // radius edge (neighbour=t, centre=i): scatter to t, gather from i
@@ -159,7 +162,7 @@ __device__ int target_edges(const GraphLds& s, const GraphArgs& A, int kind, int
     }
   } else if (kind == SET_AA) {
     const int gt = a0 + t;
-    for (int i = 0; i < na; ++i) {
+    for (int i = lo; i < hi; ++i) {
       if (i == t || t > s.thr[i]) continue;
       if (d2_rn(s.ax[i], s.ay[i], s.az[i], s.ax[t], s.ay[t], s.az[t]) < A.atom_cut2) {
         int gi = a0 + i;
@@ -168,7 +171,7 @@ __device__ int target_edges(const GraphLds& s, const GraphArgs& A, int kind, int
     }
   } else if (kind == SET_AL) {  // target ligand atom, gathers pocket atoms; vec = rec - lig
     const int gt = l0 + t;
-    for (int i = 0; i < na; ++i) {
+    for (int i = lo; i < hi; ++i) {
       int gi = a0 + i;
       bool in = A.is_cab[gi] || d2_rn(s.lx[t], s.ly[t], s.lz[t], s.ax[i], s.ay[i], s.az[i]) < A.cross_cut2;
       if (in) emit(gt, gi, -1, RP[3 * gi] - LP[3 * gt], RP[3 * gi + 1] - LP[3 * gt + 1], RP[3 * gi + 2] - LP[3 * gt + 2]);
@@ -176,7 +179,7 @@ __device__ int target_edges(const GraphLds& s, const GraphArgs& A, int kind, int
   } else if (kind == SET_LA) {  // target pocket atom, gathers ligand atoms; harmonics of the SAME vec = rec - lig
     const int gt = a0 + t;
     const bool cab = A.is_cab[gt];
-    for (int i = 0; i < nl; ++i) {
+    for (int i = lo; i < hi; ++i) {
       int gi = l0 + i;
       bool in = cab || d2_rn(s.lx[i], s.ly[i], s.lz[i], s.ax[t], s.ay[t], s.az[t]) < A.cross_cut2;
       if (in) emit(gt, gi, -1, RP[3 * gt] - LP[3 * gi], RP[3 * gt + 1] - LP[3 * gi + 1], RP[3 * gt + 2] - LP[3 * gi + 2]);
@@ -185,16 +188,17 @@ __device__ int target_edges(const GraphLds& s, const GraphArgs& A, int kind, int
   return cnt;
 }
 
-// pseudotorque graphs: target = torsion bond (mid-point), gathers atoms within r, first `cap` by index
+// pseudotorque graphs: target = torsion bond (mid-point), gathers atoms within r, first `cap` by index.  The lane handles the
+// candidates [lo, hi) and keeps at most `keep` of them (what the cap leaves for its share once the lanes before it took theirs).
 template <bool EMIT>
-__device__ int torsion_edges(const GraphArgs& A, int kind, int tgt, const float* P, int p0, int np, const float* px,
-                             const float* py, const float* pz, int u, int v, float r2, int cap, int base) {
+__device__ int torsion_edges(const GraphArgs& A, int kind, int tgt, const float* P, int p0, const float* px,
+                             const float* py, const float* pz, int u, int v, float r2, int lo, int hi, int keep, int base) {
   const EdgeSet& S = A.set[kind];
   float mx = (P[3 * u] + P[3 * v]) / 2, my = (P[3 * u + 1] + P[3 * v + 1]) / 2, mz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
   float b9[9];
   if (EMIT) vec_sh(P[3 * v] - P[3 * u], P[3 * v + 1] - P[3 * u + 1], P[3 * v + 2] - P[3 * u + 2], b9);
   int cnt = 0;
-  for (int i = 0; i < np && cnt < cap; ++i) {
+  for (int i = lo; i < hi && cnt < keep; ++i) {
     if (d2_rn(mx, my, mz, px[i], py[i], pz[i]) < r2) {
       if (EMIT) {
         int e = base + cnt;
@@ -242,8 +246,19 @@ __device__ __forceinline__ void target_range(const GraphArgs& A, int kind, int g
   nt = ptr[g + 1] - t0;
 }
 
-template <bool EMIT>
+// Work split (round 4).  A workgroup serves EDGE_CHUNK = 64 consecutive targets of one (graph, set) with EDGE_LANES = 4 lanes per
+// target: lane q of a target walks the q-th quarter of the candidate range, so the per-thread serial walk of a 866-atom pocket is
+// 217 candidates instead of 866 and a graph is 4 x as many workgroups (BASELINE config 1 -- ONE pocket x 4 poses -- was 16 + 16
+// workgroups per step on a 256-CU chip, 9 % of its latency).  Thread order = (target, quarter) = emission order, so the block scan
+// over the per-LANE counts yields every lane's first slot directly and the edge list is the one the one-lane walk produced: by
+// target, bonds first, then by gather index.  The "first cap by index" rule of the pseudotorque sets is applied on the quarter
+// prefix: a lane keeps what the cap leaves once the lanes before it took theirs.
+// EDGE_LANES = 1 (a workgroup = 256 targets, the round-1 form) is kept for batches that fill the chip anyway: there the quartered walk
+// buys nothing and four times as many workgroups each stage the graph and run the block scan (measured at 640 poses: 310.7 -> 296.7
+// poses/s with four lanes everywhere); launch_edges picks by the number of workgroups.  Both forms emit the same list.
+template <bool EMIT, int EDGE_LANES>
 __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
+  constexpr int TPB = 256 / EDGE_LANES;              // targets per pass
   extern __shared__ float dyn_lds[];
   GraphLds s;
   lds_views(s, dyn_lds, A.lds_nl, A.lds_na);
@@ -251,45 +266,52 @@ __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
   const int g = blockIdx.x / C, chunk = blockIdx.x - g * C, kind = blockIdx.y;
   const EdgeSet& S = A.set[kind];
   if (S.cap == 0) return;
-  // Sets whose targets are pocket atoms (up to thousands per graph) are cut into chunks of 256 targets, one workgroup
-  // each (a single 866-atom pocket would otherwise be one workgroup per set: 1.5 ms per step at BASELINE config 1);
-  // the other sets (<= 256 ligand atoms / a few dozen torsions per graph) are done by chunk 0 alone.
-  const bool split = kind == SET_AA || kind == SET_LA;
-  if (!split && chunk > 0) { if (!EMIT) S.g_cnt[blockIdx.x] = 0; return; }
   // this set did not fit its capacity in this step: leave it EMPTY (row_cnt 0) so that nothing downstream reads past
   // the buffers; the host re-plans with the counted sizes and resumes from this step (dbfr_capacity_report)
   const bool overflow = EMIT && A.err[2 + kind] != 0;
   int t0, nt;  // first global target id of the graph, number of targets
   target_range(A, kind, g, t0, nt);
-  const int c_begin = split ? chunk * 256 : 0, c_end = split ? min(nt, c_begin + 256) : nt;
-  if (c_begin >= nt) { if (!EMIT) S.g_cnt[blockIdx.x] = 0; return; }
+  // chunk c serves targets [c TPB, (c + 1) TPB); the last chunk takes whatever lies beyond (launch_edges sizes C by the
+  // batch's largest pocket / ligand, which bounds every set's targets per graph: chi angles < side-chain atoms, torsions < atoms)
+  const int c_begin = chunk * TPB, c_end = chunk == C - 1 ? nt : min(nt, c_begin + TPB);
+  if (c_begin >= nt) { if (!EMIT && threadIdx.x == 0) S.g_cnt[blockIdx.x] = 0; return; }
   int l0, nl, a0, na;
   load_graph(s, A, g, kind, l0, nl, a0, na);
   if (kind == SET_LL) cap_thresholds(s, s.lx, s.ly, s.lz, nl, A.lig_cut2, A.lig_cap);
   if (kind == SET_AA) cap_thresholds(s, s.ax, s.ay, s.az, na, A.atom_cut2, A.atom_cap);
+  const int q = threadIdx.x & (EDGE_LANES - 1), tl = threadIdx.x / EDGE_LANES;
+  const int lane = threadIdx.x & 63, quad0 = lane & ~(EDGE_LANES - 1);
+  // gather candidates of the set: ligand atoms (LL, LA, TOR) or pocket atoms (AA, AL, SC)
+  const int ncand = (kind == SET_LL || kind == SET_LA || kind == SET_TOR) ? nl : na;
+  const int lo = (int)(((long)ncand * q) / EDGE_LANES), hi = (int)(((long)ncand * (q + 1)) / EDGE_LANES);
   int running = EMIT ? S.g_base[blockIdx.x] : 0;
   int total = 0;
-  for (int c0 = c_begin; c0 < c_end; c0 += 256) {  // chunks of 256 targets, block scan inside each
-    const int t = c0 + threadIdx.x;
-    int cnt = 0;
-    if (t < c_end) {
-      if (EMIT) {
-        cnt = overflow ? 0 : S.row_cnt[t0 + t];
-        if (overflow) S.row_cnt[t0 + t] = 0;
-      } else if (kind <= SET_LA) {
-        cnt = target_edges<false>(s, A, kind, g, t, l0, nl, a0, na, 0);
-      } else if (kind == SET_TOR) {
-        int k = A.b.tor_bond[t0 + t];
-        cnt = torsion_edges<false>(A, kind, t0 + t, A.b.lig_pos, l0, nl, s.lx, s.ly, s.lz, A.b.bond_src[k],
-                                   A.b.bond_dst[k], A.lig_cut2, A.lig_cap, 0);
-      } else {
+  for (int c0 = c_begin; c0 < c_end; c0 += TPB) {  // (one pass, but for the last chunk of an oversized set)
+    const int t = c0 + tl;
+    const bool live = t < c_end && !overflow;
+    int cnt = 0, keep = 0x7fffffff, tu = 0, tv = 0;
+    if (live) {
+      const bool known = EMIT && EDGE_LANES == 1;   // one lane per target: the count pass left the target's count in row_cnt
+      if (kind == SET_TOR) {
+        const int k = A.b.tor_bond[t0 + t];
+        tu = A.b.bond_src[k]; tv = A.b.bond_dst[k];
+      } else if (kind == SET_SC) {
         // side-chain bonds: mid-point of (j,k) vs the graph's pocket atoms; s.ax holds UNSCALED coords for SC
-        cnt = torsion_edges<false>(A, kind, t0 + t, A.b.rec_pos, a0, na, s.ax, s.ay, s.az, A.b.sc_bond[2 * (t0 + t)],
-                                   A.b.sc_bond[2 * (t0 + t) + 1], A.atom_cut2, A.lig_cap, 0);
+        tu = A.b.sc_bond[2 * (t0 + t)]; tv = A.b.sc_bond[2 * (t0 + t) + 1];
       }
-      if (!EMIT) S.row_cnt[t0 + t] = cnt;
+      if (known) cnt = S.row_cnt[t0 + t];
+      else if (kind <= SET_LA) cnt = target_edges<false>(s, A, kind, g, t, l0, nl, a0, na, lo, hi, q == 0, 0);
+      else if (kind == SET_TOR) cnt = torsion_edges<false>(A, kind, t0 + t, A.b.lig_pos, l0, s.lx, s.ly, s.lz, tu, tv, A.lig_cut2, lo, hi, A.lig_cap, 0);
+      else cnt = torsion_edges<false>(A, kind, t0 + t, A.b.rec_pos, a0, s.ax, s.ay, s.az, tu, tv, A.atom_cut2, lo, hi, A.lig_cap, 0);
     }
-    // inclusive scan over the 256 threads
+    if (kind > SET_LA && EDGE_LANES > 1) {   // first `cap` by index: what the lanes before this one leave (all four lanes of a quad take this path together)
+      int before = 0;
+#pragma unroll
+      for (int j = 0; j < EDGE_LANES - 1; ++j) { const int cj = __shfl(cnt, quad0 + j); if (j < q) before += cj; }
+      keep = max(0, A.lig_cap - before);
+      cnt = min(cnt, keep);
+    }
+    // inclusive scan over the 256 threads = over (target, quarter) in emission order
     s.scan[threadIdx.x] = cnt;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -298,25 +320,30 @@ __global__ __launch_bounds__(256) void k_edges(GraphArgs A) {
       s.scan[threadIdx.x] += v;
       __syncthreads();
     }
-    const int incl = s.scan[threadIdx.x], chunk_total = s.scan[255];
+    const int incl = s.scan[threadIdx.x], pass_total = s.scan[255];
     __syncthreads();
-    if (EMIT && t < c_end) {
+    if (t < c_end) {
+      int tot = cnt;      // the target's edge count = sum over its lanes
+      if (EDGE_LANES > 1) { tot += __shfl_xor(tot, 1); tot += __shfl_xor(tot, 2); }
+      static_assert(EDGE_LANES == 1 || EDGE_LANES == 4, "lane sums are written for 1 or 4 lanes per target");
+      if (kind > SET_LA && EDGE_LANES == 1) keep = cnt;
       const int base = overflow ? 0 : running + incl - cnt;
-      S.row_start[t0 + t] = base;
-      if (overflow) {
-      } else if (kind <= SET_LA) {
-        target_edges<true>(s, A, kind, g, t, l0, nl, a0, na, base);
-      } else if (kind == SET_TOR) {
-        int k = A.b.tor_bond[t0 + t];
-        torsion_edges<true>(A, kind, t0 + t, A.b.lig_pos, l0, nl, s.lx, s.ly, s.lz, A.b.bond_src[k], A.b.bond_dst[k],
-                            A.lig_cut2, A.lig_cap, base);
+      if (!EMIT) {
+        if (q == 0) S.row_cnt[t0 + t] = tot;
       } else {
-        torsion_edges<true>(A, kind, t0 + t, A.b.rec_pos, a0, na, s.ax, s.ay, s.az, A.b.sc_bond[2 * (t0 + t)],
-                            A.b.sc_bond[2 * (t0 + t) + 1], A.atom_cut2, A.lig_cap, base);
+        if (q == 0) { S.row_start[t0 + t] = base; if (overflow) S.row_cnt[t0 + t] = 0; }
+        if (overflow || cnt == 0) {
+        } else if (kind <= SET_LA) {
+          target_edges<true>(s, A, kind, g, t, l0, nl, a0, na, lo, hi, q == 0, base);
+        } else if (kind == SET_TOR) {
+          torsion_edges<true>(A, kind, t0 + t, A.b.lig_pos, l0, s.lx, s.ly, s.lz, tu, tv, A.lig_cut2, lo, hi, keep, base);
+        } else {
+          torsion_edges<true>(A, kind, t0 + t, A.b.rec_pos, a0, s.ax, s.ay, s.az, tu, tv, A.atom_cut2, lo, hi, keep, base);
+        }
       }
     }
-    running += chunk_total;
-    total += chunk_total;
+    running += pass_total;
+    total += pass_total;
   }
   if (!EMIT && threadIdx.x == 0) S.g_cnt[blockIdx.x] = total;
 }
@@ -352,6 +379,21 @@ __global__ __launch_bounds__(256) void k_edges_scan(GraphArgs A) {
   }
 }
 
+// workgroups per (graph, set) of the finer form: what plan() sizes g_cnt / g_base for (the coarser form uses a prefix of them)
+int dbfr_edge_chunks(int max_na, int max_nl) { const int m = max_na > max_nl ? max_na : max_nl; return (m + EDGE_CHUNK - 1) / EDGE_CHUNK; }
+static int edge_lanes(const dbfr_batch& b);
+static int edge_chunks_of(const dbfr_batch& b) {      // workgroups per (graph, set) of the form launch_edges picks for this batch
+  const int m = b.max_na > b.max_nl ? b.max_na : b.max_nl, tpb = 256 / edge_lanes(b);
+  return (m + tpb - 1) / tpb;
+}
+static int edge_lanes(const dbfr_batch& b) {
+  static const int forced = getenv("DBFR_EDGE_LANES") ? atoi(getenv("DBFR_EDGE_LANES")) : 0;      // developer: 1 | 4
+  if (forced == 1 || forced == 4) return forced;
+  const int m = b.max_na > b.max_nl ? b.max_na : b.max_nl;
+  const long wg1 = (long)b.G * ((m + 255) / 256);          // workgroups per set with one lane per target
+  return wg1 >= 2L * dbfr_current_cu_count() ? 1 : 4;      // four lanes while the coarse form would leave the chip mostly empty
+}
+
 void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
   (void)with_heads_only;
   GraphArgs A = A0;
@@ -360,14 +402,20 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
   const size_t lds = lds_bytes(A.lds_nl, A.lds_na);
   if (lds > 64 * 1024) {   // above the default 64 KB a kernel has to be told -- per DEVICE, and a process may drive several: no
     // "done once" flag; the call is cheap next to a launch that stages a > 4 k-atom pocket
-    const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edges<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (dbfr_launch_check(e0 != hipSuccess ? e0 : e1, "k_edges: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return;
+    for (const void* f : {reinterpret_cast<const void*>(&k_edges<false, 1>), reinterpret_cast<const void*>(&k_edges<true, 1>),
+                          reinterpret_cast<const void*>(&k_edges<false, 4>), reinterpret_cast<const void*>(&k_edges<true, 4>)})
+      if (dbfr_launch_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64), "k_edges: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return;
   }
-  A.n_chunk = (A.b.max_na + 255) / 256;      // must match plan() in api.cpp (g_cnt / g_base hold G * n_chunk entries)
-  hipLaunchKernelGGL(k_edges<false>, dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
-  hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(k_edges<true>, dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
+  A.n_chunk = edge_chunks_of(A.b);      // <= what plan() in api.cpp sized g_cnt / g_base for (dbfr_edge_chunks)
+  if (edge_lanes(A.b) == 1) {
+    hipLaunchKernelGGL((k_edges<false, 1>), dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
+    hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
+    hipLaunchKernelGGL((k_edges<true, 1>), dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
+  } else {
+    hipLaunchKernelGGL((k_edges<false, 4>), dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
+    hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
+    hipLaunchKernelGGL((k_edges<true, 4>), dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
+  }
 }
 
 // dbfr_model_set_edge_log: per-graph edge counts of this step, log[k * G + g] = sum over the graph's target chunks
@@ -383,7 +431,7 @@ __global__ void k_edge_log(GraphArgs A, int* log) {
 
 void launch_edge_log(const GraphArgs& A0, int* log_row, hipStream_t st) {
   GraphArgs A = A0;
-  A.n_chunk = (A.b.max_na + 255) / 256;
+  A.n_chunk = edge_chunks_of(A.b);
   hipLaunchKernelGGL(k_edge_log, dim3((A.b.G + 255) / 256, N_SETS), dim3(256), 0, st, A, log_row);
 }
 

@@ -6,9 +6,25 @@ miniature: every job shares ONE pocket); tests/golden/real_reverse_traj.npz: exa
 (tests/golden/make_golden.py: golden_examples; the oracle reproduced it at <= 1e-4 A there).  The fixtures hold the RAW
 inputs of the product path -- protein atom37 arrays around the site, the pocket-defining crystal ligand, ligand graphs --
 the pocket halves the reference's own pipeline built from them, plus the recorded tapes.  GPU: shared PocketRecord / LigandRecord ->
-ComplexRecord -> assemble / dbfr_init_poses from the recorded init tapes -> 20 steps with the recorded noise: every trajectory
-within 1e-3 A of the reference's, also through dist.run_sharded; and the same from the product's own pocket path
-(pockets_from_proteins: selection + templates on the device), whose halves must equal the reference pipeline's.
+ComplexRecord -> assemble / dbfr_init_poses from the recorded init tapes -> 20 steps with the recorded noise, also through
+dist.run_sharded; and the same from the product's own pocket path (pockets_from_proteins: selection + templates on the device), whose
+halves must equal the reference pipeline's.
+
+What "follows the reference" means here.  The reference's graphs have HARD cutoffs (5 A, 4 A, 0.2 sigma + 5 A; caps of 32 neighbours) and no
+envelope on the edge features, so a pair within rounding distance of a cutoff is an edge in one run and not in another -- the reference
+against itself on another thread count included -- and the trajectory jumps by 0.01-0.04 A.  The fixtures therefore also hold, per step and
+per graph, the reference run's EDGE COUNTS of its five edge sets and each set's MARGIN = the smallest | |x_i - x_j| - cutoff | over the
+graph's candidate pairs, evaluated on the reference's own coordinates (make_golden.py: _EdgeRecorder).  The library reports its own
+per-graph counts (dbfr_model_set_edge_log), and the test asserts, trajectory by trajectory:
+  * counts equal to the reference's at all 20 steps  =>  within 1e-3 A of the reference over all 20 frames -- no allowance;
+  * otherwise, at the FIRST step s0 whose counts differ: (A) the ligand trajectories still agree within 1e-4 A on every frame that
+    entered that step; (B) the library's graphs of step s0 are RIGHT FOR ITS OWN COORDINATES -- the oracle's edge builders
+    (oracle/cluster.py: the restated torch_cluster semantics) run on the coordinates the library held entering s0 give exactly the
+    counts it logged, set by set -- so the difference to the reference is a difference of coordinates in the 5th decimal, not of graph
+    building; (C) the reference's own coordinates put a pair of a differing set within 1e-4 A of its cutoff.  (C) alone is weak: a
+    pocket's ~10^4 in-range pairs put SOME pair that close to 4 A at most steps, which is exactly why single trajectories depart --
+    a flip needs the two runs' coordinates to differ by more than the margin, and they differ by ~1e-5 A.  From s0 on the trajectory
+    is only held to 0.1 A.
 """
 import os
 
@@ -82,29 +98,108 @@ def _deviation(z, pb, lig, a14):
     return [float(dl[:, lp[g]:lp[g + 1]].max()) for g in range(G)], [float(da[rp[g]:rp[g + 1]].max()) for g in range(G)]
 
 
+SETS = ("lig", "atom", "cross", "tor", "sc")        # the reference's five per-step edge sets (fixture order)
+HIP_SETS = (0, 1, 2, 4, 5)                          # the library's six: {lig, atom, cross lig<-atom, cross atom<-lig, tor, sc}
+
+
+def _per_step_deviation(z, pb, lig):
+    """[G, 20]: largest ligand-atom deviation from the reference of graph g in frame s (= after step s)."""
+    dl = (lig.cpu() - torch.from_numpy(z["traj_lig"])).norm(dim=-1)
+    lp = pb.lig_ptr_host.tolist()
+    return np.stack([dl[:, lp[g]:lp[g + 1]].max(dim=1).values.numpy() for g in range(len(lp) - 1)])
+
+
+def _oracle_counts(pb, g, lig_xyz, rec_xyz, tr_sigma):
+    """The five edge counts of graph g for the given coordinates by the oracle's restated torch_cluster calls, as the reference's
+    builders make them (tpscore.py:586, 613, 655-660, 721, 747)."""
+    from oracle.cluster import radius, radius_graph
+    t = {k: v.cpu() for k, v in pb.t.items() if k in ("lig_ptr", "atm_ptr", "bond_src", "bond_dst", "bond_ptr", "tor_ptr", "tor_bond",
+                                                     "sc_ptr", "sc_bond", "pocket_feat")}
+    l0, l1, a0, a1 = int(t["lig_ptr"][g]), int(t["lig_ptr"][g + 1]), int(t["atm_ptr"][g]), int(t["atm_ptr"][g + 1])
+    n_bond = int(t["bond_ptr"][l1] - t["bond_ptr"][l0])
+    lig = int(radius_graph(lig_xyz, 5.0).shape[1]) + n_bond
+    atom = int(radius_graph(rec_xyz, 4.0, max_num_neighbors=1000).shape[1])
+    a37 = t["pocket_feat"][a0:a1, 0].long()
+    cab = (a37 == 1) | (a37 == 3)
+    c = torch.tensor(tr_sigma, dtype=torch.float32) * 0.2 + 5
+    cross = (l1 - l0) * int(cab.sum()) + int(radius(rec_xyz[~cab] / c, lig_xyz / c, 1, max_num_neighbors=10000).shape[1])
+    tb = t["tor_bond"][int(t["tor_ptr"][g]):int(t["tor_ptr"][g + 1])].long()
+    tor = 0
+    if len(tb):
+        mid = (lig_xyz[t["bond_src"][tb].long() - l0] + lig_xyz[t["bond_dst"][tb].long() - l0]) / 2
+        tor = int(radius(lig_xyz, mid, 5.0).shape[1])
+    sb = t["sc_bond"].view(-1, 2)[int(t["sc_ptr"][g]):int(t["sc_ptr"][g + 1])].long() - a0
+    sc = 0
+    if len(sb):
+        mid = (rec_xyz[sb[:, 0]] + rec_xyz[sb[:, 1]]) / 2
+        sc = int(radius(rec_xyz, mid, 4.0).shape[1])
+    return [lig, atom, cross, tor, sc]
+
+
+def _check_against_reference(z, pb, lig, a14, log, tr_sigmas, before_tol=1e-4, margin_tol=1e-4):
+    """The assertions of the module docstring.  Returns the printed table's rows."""
+    assert "edge_counts" in z.files, "fixture without edge_counts: regenerate (GOLDEN_EXAMPLES_EDGES_ONLY=1 make_golden.py examples)"
+    hip = log.cpu().numpy()                                   # [20, 6, G]
+    assert np.array_equal(hip[:, 2], hip[:, 3]), "the two cross sets hold the same pairs"
+    mine = hip[:, HIP_SETS].transpose(0, 2, 1)               # [20, G, 5]
+    ref, margin = z["edge_counts"], z["cutoff_margin"]
+    assert mine.shape == ref.shape, (mine.shape, ref.shape)
+    dev = _per_step_deviation(z, pb, lig)
+    _, da = _deviation(z, pb, lig, a14)
+    rows = []
+    for g in range(ref.shape[1]):
+        diff = np.argwhere(mine[:, g] != ref[:, g])
+        worst = float(dev[g].max())
+        if len(diff) == 0:
+            rows.append((g, "equal", None, None, worst, da[g]))
+            continue
+        s0 = int(diff[:, 0].min())
+        sets = [int(k) for s, k in diff if s == s0]
+        before = float(dev[g, :s0].max()) if s0 else 0.0
+        mg = float(min(margin[s0, g, k] for k in sets))
+        rows.append((g, f"step {s0}: " + ", ".join(f"{SETS[k]} {mine[s0, g, k]} vs {ref[s0, g, k]}" for k in sets), before, mg, worst, da[g]))
+        if s0 > 0:      # (B): the library's graphs of step s0 against the oracle's builders on the library's OWN coordinates entering s0
+            lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
+            m14 = pb.atom14_mask[rp[g]:rp[g + 1]].cpu().bool()
+            own = _oracle_counts(pb, g, lig[s0 - 1, lp[g]:lp[g + 1]].cpu(), a14[s0 - 1, rp[g]:rp[g + 1]].cpu()[m14], tr_sigmas[s0])
+            assert own == mine[s0, g].tolist(), f"job {g} step {s0}: the library built {mine[s0, g].tolist()} edges, the oracle on the same coordinates {own}"
+    for r in rows:
+        print(f"  job {r[0]:2d}  counts {r[1]:44s} before {'-' if r[2] is None else format(r[2], '.1e')}  margin {'-' if r[3] is None else format(r[3], '.1e')}"
+              f"  max dev ligand {r[4]:.2e} atom14 {r[5]:.2e}")
+    for g, what, before, mg, worst, da_g in rows:
+        if what == "equal":
+            assert worst < 1e-3 and da_g < 1e-3, f"job {g}: same graphs as the reference at every step, yet {worst:.2e} / {da_g:.2e} A away"
+        else:
+            assert before < before_tol, f"job {g}: {before:.2e} A away from the reference BEFORE the first differing graph ({what})"
+            assert mg < margin_tol, f"job {g}: graphs differ ({what}) although the reference has no pair within {margin_tol} A of that cutoff (margin {mg:.2e})"
+            assert worst < 0.1 and da_g < 0.1, (g, worst, da_g)
+    return rows
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", FIXTURES)
 def test_gpu_examples_follow_the_reference_trajectories(name):
     """Identical inputs (the pocket halves the reference's pipeline built, shared between the jobs; the recorded tapes), as one batch and
-    through dist.run_sharded in small batches.  Measured: 14 of 15 (forward) and 5 of 6 (reverse) trajectories stay within 6e-5 A of
-    the reference's over all 20 steps; ONE per fixture departs by 0.01-0.04 A from some step on.  That is the reference algorithm's own
-    sensitivity, not an implementation difference: its graphs have hard cutoffs (4 A / 5 A / 0.2 sigma + 5 A) with no envelope on the
-    edge features, so a pair within rounding distance of a cutoff enters the graph in one run and not in the other -- the CPU oracle run
-    twice with the initial ligand coordinates moved by N(0, 1e-6 A) shows the same (tests/tools/example_sensitivity.py,
-    profiles/r3_example_sensitivity.txt).  Held here: >= 80 % of the trajectories within 1e-3 A, median below 1e-4 A, every one
-    within 0.1 A."""
+    through dist.run_sharded in small batches; every trajectory held to the reference's as the module docstring states (graph by
+    graph, step by step), in the default GEMM mode and on the fp32 matrix instruction."""
     from diffbindfr_amd import assemble, dist as ddist
     dev = torch.device("cuda:0")
     z = _load(name)
     pockets = [assemble.PocketRecord({k: torch.from_numpy(z[f"prot{i}_half_{k}"]) for k in HALF_KEYS}) for i in range(int(z["n_prot"]))]
     jobs, samp, tapes = _setup(z, dev, pockets)
-    pb, lig, a14 = samp.run_complexes(jobs, 1, dev, seeds=[0] * len(jobs), tapes=[tapes[g] for g in range(len(jobs))], visualize=True)
-    assert lig.shape[0] == 20
-    dl, da = _deviation(z, pb, lig, a14)
-    print("per job max deviation (A): ligand", [round(x, 6) for x in dl], "atom14", [round(x, 6) for x in da])
-    assert sum(x < 1e-3 for x in dl) >= 0.8 * len(dl) and sum(x < 1e-3 for x in da) >= 0.8 * len(da), (dl, da)
-    assert float(np.median(dl)) < 1e-4 and float(np.median(da)) < 1e-4, (dl, da)
-    assert max(dl) < 0.1 and max(da) < 0.1, (dl, da)
+    model = samp.diffusion_model
+    n_event = {}
+    default = model.gemm_mode(dev)
+    for mode in ("f32", default):
+        model.set_gemm(mode)
+        log = model.edge_log(dev, 20, len(jobs))
+        pb, lig, a14 = samp.run_complexes(jobs, 1, dev, seeds=[0] * len(jobs), tapes=[tapes[g] for g in range(len(jobs))], visualize=True)
+        assert lig.shape[0] == 20
+        print(f"{name} [gemm {mode}]")
+        rows = _check_against_reference(z, pb, lig, a14, log, [r.tr_sigma for r in samp.schedule()[0]])
+        n_event[mode] = sum(r[1] != "equal" for r in rows)
+        model.edge_log(dev, 0, 0)
+    assert max(n_event.values()) <= max(2, len(jobs) // 4), n_event        # cutoff events are the exception, not the rule
     # small batches through the job driver: the poses of a job do not depend on its batch mates -> the very same final poses, in job order
     res = ddist.run_sharded(samp, jobs, 1, seed=0, device=dev, batch_poses=4, tapes=tapes)
     lp, rp_ = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
@@ -118,8 +213,8 @@ def test_gpu_examples_from_raw_proteins(name):
     """The product's own pocket path on the examples' real receptors: atom37 arrays around the site + the crystal ligand ->
     pockets_from_proteins (12 A selection + template extraction on the device, ALL receptors in one pass).  (1) Its pocket halves equal
     the reference pipeline's (same residues, masks, edges, features; fp32 templates within 1e-4 A / 3e-4 rad of the float64 ones).
-    (2) Sampling from them follows the reference trajectories under the same bound as above (the inputs now differ from the reference's
-    in the 5th decimal; see there for why single trajectories depart)."""
+    (2) Sampling from them follows the reference trajectories graph by graph as above; the inputs now differ from the reference's in the
+    5th decimal from the first step on (fp32 templates), so "agrees before the event" and "near the cutoff" are taken at 5e-4 A."""
     from diffbindfr_amd import assemble, pocket
     dev = torch.device("cuda:0")
     z = _load(name)
@@ -144,8 +239,8 @@ def test_gpu_examples_from_raw_proteins(name):
         assert int(mask.sum()) == 105                                       # the 12 A pocket of 3DBS
     pockets = [assemble.PocketRecord({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in h.items()}) for h in halves]
     jobs, samp, tapes = _setup(z, dev, pockets)
+    log = samp.diffusion_model.edge_log(dev, 20, len(jobs))
     pb, lig, a14 = samp.run_complexes(jobs, 1, dev, seeds=[0] * len(jobs), tapes=[tapes[g] for g in range(len(jobs))], visualize=True)
-    dl, da = _deviation(z, pb, lig, a14)
-    print("per job max deviation (A): ligand", [round(x, 6) for x in dl], "atom14", [round(x, 6) for x in da])
-    assert sum(x < 1e-3 for x in dl) >= 0.8 * len(dl) and float(np.median(dl)) < 1e-4, dl
-    assert max(dl) < 0.1 and max(da) < 0.1, (dl, da)
+    print(f"{name} [from raw proteins]")
+    _check_against_reference(z, pb, lig, a14, log, [r.tr_sigma for r in samp.schedule()[0]], before_tol=5e-4, margin_tol=5e-4)
+    samp.diffusion_model.edge_log(dev, 0, 0)
