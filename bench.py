@@ -353,8 +353,11 @@ def main():
     n_jobs = (args.jobs if args.jobs else args.steps * jobs_per_batch) * (world if args.scaling == "weak" else 1)
     jobs = make_jobs(args.config, n_jobs, seed=1)
     shards, reps = ddist.shard_jobs(jobs, ppc, world)
+    t_up = time.perf_counter()
     for j in shards[rank]:                       # per-complex records resident in HBM before the timed region
         jobs[j].lig.dev(dev), jobs[j].pocket.dev(dev)
+    torch.cuda.synchronize(dev)
+    t_up = time.perf_counter() - t_up
     warm = make_jobs(args.config, jobs_per_batch, seed=2)
     for i in range(args.warmup):
         samp.run_complexes(warm, ppc, dev, seed=i)
@@ -364,6 +367,17 @@ def main():
         lib.dbfr_profile_read(h, None, None, None, None, 1)
         lib.dbfr_profile_enable(h, 1)
     done = []
+    # host time spent in batch assembly (record halves -> packed batch, launches included) inside the timed region, for the read-out
+    asm_s = [0.0]
+    _assemble = assemble.assemble
+
+    def timed_assemble(*a, **k):
+        t = time.perf_counter()
+        try:
+            return _assemble(*a, **k)
+        finally:
+            asm_s[0] += time.perf_counter() - t
+    assemble.assemble = timed_assemble
     torch.cuda.reset_peak_memory_stats(dev)
     ddist.barrier()
     torch.cuda.synchronize(dev)
@@ -376,6 +390,7 @@ def main():
     res = ddist.run_sharded(samp, jobs, ppc, seed=100, device=dev, batch_poses=B, on_batch=on_batch, store=args.store, gather=args.gather,
                             release=False)      # (the records stay resident: they were uploaded before the timed region)
     torch.cuda.synchronize(dev)
+    assemble.assemble = _assemble
     t_local = time.perf_counter() - t0          # this rank's own clock, sampling + gather
     ddist.barrier()
     elapsed = time.perf_counter() - t0
@@ -383,7 +398,8 @@ def main():
     t_sampled = (stamps[-1] - t0) if stamps else 0.0
     # what every rank did, all-gathered: the line shows that the collective saw `world` ranks, and on which devices
     per_rank = ddist.all_gather_vec([rank, dev.index, float(sum(done)), len(done), t_local, t_sampled,
-                                     torch.cuda.max_memory_allocated(dev) / 2 ** 30], dev)
+                                     torch.cuda.max_memory_allocated(dev) / 2 ** 30, t_up, asm_s[0]], dev)
+    n_steps = max(int(v[3]) for v in per_rank) if args.jobs else args.steps      # --jobs: a step is still one batch; the slowest rank's count
     counters = (C.c_int64 * 8)()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     L.check(lib.dbfr_status_sync(C.c_void_p(model.workspace_of(dev).data_ptr()), stream, counters))
@@ -470,8 +486,8 @@ def main():
     if rank == 0:
         line = {
             "metric": "poses_per_sec", "value": round(poses / elapsed, 3), "unit": "poses/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            "n_gpus": world, "steps": n_steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / n_steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "pose_steps_per_sec": round(poses * T / elapsed, 2),
             "config": {"workload": f"BASELINE.json configs[{args.config - 1}] {cfg['name']}: {len(jobs)} jobs x {ppc} poses "
@@ -490,7 +506,10 @@ def main():
                        "ranks_seen": len(per_rank),
                        "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
                                      "sampling_s": round(v[5], 4), "gather_and_unpack_s": round(v[4] - v[5], 4),
-                                     "torch_peak_hbm_gib": round(v[6], 3)} for v in per_rank]},
+                                     "torch_peak_hbm_gib": round(v[6], 3), "records_upload_s_before_timing": round(v[7], 4),
+                                     "assemble_host_s": round(v[8], 4)} for v in per_rank],
+                       "hbm_note": "torch_peak_hbm_gib = torch.cuda.max_memory_allocated over the timed region: record halves, packed batch, tapes, "
+                                   "trajectories, the library's workspace (a torch tensor); + 0.28 GiB of packed weights the library allocates itself"},
             "roofline": roof,
         }
         if native is not None:

@@ -21,10 +21,12 @@ per-graph counts (dbfr_model_set_edge_log), and the test asserts, trajectory by 
     entered that step; (B) the library's graphs of step s0 are RIGHT FOR ITS OWN COORDINATES -- the oracle's edge builders
     (oracle/cluster.py: the restated torch_cluster semantics) run on the coordinates the library held entering s0 give exactly the
     counts it logged, set by set -- so the difference to the reference is a difference of coordinates in the 5th decimal, not of graph
-    building; (C) the reference's own coordinates put a pair of a differing set within 1e-4 A of its cutoff.  (C) alone is weak: a
-    pocket's ~10^4 in-range pairs put SOME pair that close to 4 A at most steps, which is exactly why single trajectories depart --
-    a flip needs the two runs' coordinates to differ by more than the margin, and they differ by ~1e-5 A.  From s0 on the trajectory
-    is only held to 0.1 A.
+    building; (C) the reference's own coordinates put a pair of a differing set within twice the deviation measured before s0 of its
+    cutoff (a pair changes sides only if the two runs' coordinates differ by at least its margin; measured: margins of 4e-7 .. 4e-6 A
+    under deviations of 2-3e-5 A).  From s0 on the trajectory is only held to 0.1 A.
+Measured (MI355X, round 4): on the fp32 matrix instruction all 15 + 6 trajectories have the reference's graphs at every step and stay
+within 6e-5 A; in the default GEMM mode two of the 15 forward trajectories meet a cutoff event (step 9: ligand set 630 vs 628 edges,
+margin 3.7e-6 A; step 13: pocket set 10446 vs 10448, margin 4.4e-7 A) and end 0.008 / 0.001 A away; examples/reverse has none.
 """
 import os
 
@@ -136,7 +138,7 @@ def _oracle_counts(pb, g, lig_xyz, rec_xyz, tr_sigma):
     return [lig, atom, cross, tor, sc]
 
 
-def _check_against_reference(z, pb, lig, a14, log, tr_sigmas, before_tol=1e-4, margin_tol=1e-4):
+def _check_against_reference(z, pb, lig, a14, log, tr_sigmas, before_tol=1e-4, margin_tol=5e-6):
     """The assertions of the module docstring.  Returns the printed table's rows."""
     assert "edge_counts" in z.files, "fixture without edge_counts: regenerate (GOLDEN_EXAMPLES_EDGES_ONLY=1 make_golden.py examples)"
     hip = log.cpu().numpy()                                   # [20, 6, G]
@@ -171,7 +173,10 @@ def _check_against_reference(z, pb, lig, a14, log, tr_sigmas, before_tol=1e-4, m
             assert worst < 1e-3 and da_g < 1e-3, f"job {g}: same graphs as the reference at every step, yet {worst:.2e} / {da_g:.2e} A away"
         else:
             assert before < before_tol, f"job {g}: {before:.2e} A away from the reference BEFORE the first differing graph ({what})"
-            assert mg < margin_tol, f"job {g}: graphs differ ({what}) although the reference has no pair within {margin_tol} A of that cutoff (margin {mg:.2e})"
+            # a pair can change sides only if the two runs' coordinates differ by at least its margin: held to twice the deviation measured
+            # on the ligand before the event (pocket atoms move like it), with `margin_tol` as the floor (inputs that differ from the start)
+            lim = max(2.0 * before, margin_tol)
+            assert mg < lim, f"job {g}: graphs differ ({what}) although the reference has no pair within {lim:.1e} A of that cutoff (margin {mg:.2e})"
             assert worst < 0.1 and da_g < 0.1, (g, worst, da_g)
     return rows
 
@@ -242,5 +247,5 @@ def test_gpu_examples_from_raw_proteins(name):
     log = samp.diffusion_model.edge_log(dev, 20, len(jobs))
     pb, lig, a14 = samp.run_complexes(jobs, 1, dev, seeds=[0] * len(jobs), tapes=[tapes[g] for g in range(len(jobs))], visualize=True)
     print(f"{name} [from raw proteins]")
-    _check_against_reference(z, pb, lig, a14, log, [r.tr_sigma for r in samp.schedule()[0]], before_tol=5e-4, margin_tol=5e-4)
+    _check_against_reference(z, pb, lig, a14, log, [r.tr_sigma for r in samp.schedule()[0]], before_tol=5e-4, margin_tol=1e-4)
     samp.diffusion_model.edge_log(dev, 0, 0)
