@@ -44,8 +44,8 @@ from diffbindfr_amd.packing import PackedBatch  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact fp32
 PMC_FILE = {"f32": "profiles/r2_pmc_k_conv.json", "split": "profiles/r2_pmc_k_conv2r.json", "split_l1": "profiles/r2_pmc_k_conv2s.json",
-            "split_f16": "profiles/r3_pmc_k_conv2h.json"}
-PMC_FILE_CFG5 = {"split_f16": "profiles/r3_cfg5_pmc_k_conv2h.json"}
+            "split_f16": "profiles/r4_pmc_k_conv2h.json"}
+PMC_FILE_CFG5 = {"split_f16": "profiles/r4_cfg5_pmc_k_conv2h.json"}
 HALF_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 W2_SHARE = 34992.0 / (34992.0 + 6 * 144.0)   # share of the conv flops 2*144*(144+W) that is the 144 x W GEMM (W = 2880, 3888, 4896, 7776 x3)
 # what the matrix pipe executes per algorithmic fp32 product of the 144 x W GEMM, and on which instruction (include/dbfr.h: DBFR_GEMM_*)

@@ -28,8 +28,9 @@ def _worker(rank, world, port, q):
     allr = ddist.gather_ragged(local, len(mine))
     fixed = ddist.gather_records(torch.full((2, 3), float(rank)))
     mx = ddist.max_over_ranks(1.0 + rank, "cpu")
+    vec = ddist.all_gather_vec([rank, 10 + rank, 0.5 * rank], "cpu")          # bench.py's per-rank read-out
     ddist.barrier()
-    q.put((rank, allr.tolist(), fixed.tolist(), mx))
+    q.put((rank, allr.tolist(), fixed.tolist(), mx, vec))
     dist.destroy_process_group()
 
 
@@ -44,7 +45,8 @@ def test_gather_over_gloo_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, a0, f0, m0), (r1, a1, f1, m1) = res
+    (r0, a0, f0, m0, v0), (r1, a1, f1, m1, v1) = res
     assert a0 == a1 and f0 == f1 and m0 == m1 == 2.0
+    assert v0 == v1 == [[0.0, 10.0, 0.0], [1.0, 11.0, 0.5]]            # every rank sees every rank's numbers, in rank order
     assert sorted(int(x[0]) for x in a0) == [0, 1, 2, 3, 4]            # every complex gathered exactly once
     assert f0 == [[0.0] * 3] * 2 + [[1.0] * 3] * 2
