@@ -640,6 +640,16 @@ extern "C" int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, in
   return DBFR_OK;
 }
 
+extern "C" int dbfr_test_pack_f16_depth(const float* frag, const float* bias, int32_t n_tiles, int32_t* depth_out, int32_t* depth_ok_out) {
+  if (!frag || !bias || !depth_out || n_tiles <= 0) return fail(DBFR_ERR_ARG, "dbfr_test_pack_f16_depth: bad argument");
+  std::vector<uint16_t> out((size_t)n_tiles * (CH_TILE_BYTES_HOST / 2) + 512, 0);
+  int depth = 0;
+  (void)pack_f16_tiles(frag, bias, 0, n_tiles, out.data(), &depth);
+  *depth_out = depth;
+  if (depth_ok_out) *depth_ok_out = F16_ROW_DEPTH_OK;
+  return DBFR_OK;
+}
+
 extern "C" int dbfr_model_fallback_convs(const dbfr_model* m, char* names, size_t names_cap) {
   if (!m) return fail(DBFR_ERR_ARG, "null model");
   int n = 0;

@@ -450,6 +450,10 @@ int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* 
  * [64 lanes][hi 4 | lo 4 fp16] for the last 16 k, then the 16 bias values (fp32) -- everything multiplied by 2^k, the power of two that
  * puts the largest |value| of these tiles into [2^14, 2^15).  Returns k in *k_out.                                                     */
 int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out);
+/* The range guard of the same packer (host code, no GPU): the largest ROW DEPTH d of these tiles taken as one run -- the row's largest
+ * |value| is 2^(15 - d) after the run's factor -- and the limit up to which two fp16 pieces hold a row to 22 significant bits (17): a conv
+ * with a deeper row in one of its runs is what dbfr_model_fallback_convs reports.                                                     */
+int dbfr_test_pack_f16_depth(const float* frag, const float* bias, int32_t n_tiles, int32_t* depth_out, int32_t* depth_ok_out);
 /* Profiling hooks: time (ms) spent in the dominant fused conv kernel and the
  * number of launches + edges since the last reset, measured with hip events on
  * the launch stream when profiling is enabled.  conv_flops = algorithmic FLOP

@@ -332,6 +332,35 @@ def test_library_build_id_matches_the_sources():
     assert L.load().dbfr_build_id().decode() == build.source_hash()
 
 
+def test_f16_range_guard_measures_the_row_depth():
+    """The range guard behind `dbfr_model_fallback_convs` (api.cpp pack_f16_tiles, host code): a run's rows share ONE power-of-two factor;
+    a row whose largest |w| lies 2^d below the run's keeps 22 significant bits in its two fp16 pieces while d <= 17.  The packer reports
+    the largest d of a run; rows at 2^-10 of the maximum pass, a row at 2^-19 (the 'six decades inside a run' case) does not, an all-zero
+    row (a padded channel) does not count, and a bias that dwarfs its weights (the factor stops at |bias| 2^k < 2^48) counts as depth."""
+    import ctypes as C
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    nt = 3
+
+    def depth(frag, bias):
+        d, ok = C.c_int32(), C.c_int32()
+        frag, bias = np.ascontiguousarray(frag, np.float32), np.ascontiguousarray(bias, np.float32)
+        L.check(lib.dbfr_test_pack_f16_depth(frag.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), nt, C.byref(d), C.byref(ok)))
+        assert ok.value == 17
+        return d.value
+
+    base = rng.uniform(0.5, 1.0, (nt, 9, 64, 4)).astype(np.float32) * rng.choice([-1.0, 1.0], (nt, 9, 64, 4)).astype(np.float32)
+    bias = rng.standard_normal((nt, 16)).astype(np.float32)
+    assert depth(base, bias) <= 1                                   # rows of one size
+    f = base.copy(); f[1, :, 5::16, :] *= 2.0 ** -10                # row 5 of tile 1 (lanes 5, 21, 37, 53 hold it): 2^-10 of the others
+    assert 10 <= depth(f, bias) <= 11
+    f = base.copy(); f[2, :, 9::16, :] *= 2.0 ** -19
+    assert 19 <= depth(f, bias) <= 20 and depth(f, bias) > 17       # -> the conv would leave the fp16 kernel
+    f = base.copy(); f[0, :, 3::16, :] = 0.0
+    assert depth(f, bias) <= 1                                      # a padded (all-zero) row is not a deep row
+    assert depth(base * 1e-30, bias) > 17                           # weights 1e-30 of their bias: the factor is held back by the bias rows
+
+
 @pytest.mark.parametrize("scale", [1.0, 1e-4, 3e3])
 def test_f16_tile_packer_scales_and_splits_exactly(scale):
     """DBFR_GEMM_SPLIT_F16's host side (api.cpp pack_f16_tiles through its test hook, no GPU): the tiles of a run are multiplied by ONE
