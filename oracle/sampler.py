@@ -57,8 +57,8 @@ def sde_step(data, sc, scores, z, t_idx, atom14_to_group):
         tr_perturb = 0.5 * sc.tr_g ** 2 * tr_score * dt
         rot_perturb = 0.5 * sc.rot_g ** 2 * rot_score * dt
         tor_perturb = 0.5 * sc.tor_g ** 2 * tor_score * dt
-    else:                                             # :166-183 (z = 0 on noise-free steps: the tape holds zeros there)
-        zero = sc.noise_free
+    else:                                             # :166-183.  `no_random`: z = 0 whatever the tape holds; the noise-free LAST step
+        zero = getattr(sc, "no_random", False)        # (no_final_step_noise) is the tape's business: draw_noise leaves zeros there
         tr_perturb = sc.tr_g ** 2 * tr_score * dt + sc.tr_g * np.sqrt(dt) * (torch.zeros_like(z.tr[t_idx]) if zero else z.tr[t_idx])
         rot_perturb = sc.rot_g ** 2 * rot_score * dt + sc.rot_g * np.sqrt(dt) * (torch.zeros_like(z.rot[t_idx]) if zero else z.rot[t_idx])
         tor_perturb = sc.tor_g ** 2 * tor_score * dt + sc.tor_g * np.sqrt(dt) * (torch.zeros_like(z.tor[t_idx]) if zero else z.tor[t_idx])
@@ -68,7 +68,7 @@ def sde_step(data, sc, scores, z, t_idx, atom14_to_group):
     if ode:                                           # :199-200
         sc_perturb = 0.5 * sc.sc_tor_g ** 2 * sc_tor_score * dt
     else:
-        sc_perturb = sc.sc_tor_g ** 2 * sc_tor_score * dt + sc.sc_tor_g * np.sqrt(dt) * (torch.zeros_like(z.sc[t_idx]) if sc.noise_free else z.sc[t_idx])
+        sc_perturb = sc.sc_tor_g ** 2 * sc_tor_score * dt + sc.sc_tor_g * np.sqrt(dt) * (torch.zeros_like(z.sc[t_idx]) if getattr(sc, "no_random", False) else z.sc[t_idx])
     chi = data.torsion_angle[:, 1:]
     chi[data.sc_torsion_edge_mask] = chi[data.sc_torsion_edge_mask] + sc_perturb
     data.torsion_angle[:, 1:] = chi

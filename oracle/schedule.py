@@ -159,4 +159,5 @@ def step_scalars(cfg, t_idx, torus_seed=0):
     ode = cfg.type == "ode"                                            # scFlex.py:162: anything else takes the SDE branch
     return SimpleNamespace(t=t, dt=dt, tr_sigma=tr_s, rot_sigma=rot_s, tor_sigma=tor_s, sc_tor_sigma=sc_s,
                            tr_g=tr_g, rot_g=rot_g, tor_g=tor_g, sc_tor_g=sc_g, rot_score_norm=rot_norm,
-                           tor_score_norm2=tor_norm2, ode=ode, noise_free=bool(ode or cfg.no_random or last))
+                           tor_score_norm2=tor_norm2, ode=ode, no_random=bool(cfg.no_random),
+                           noise_free=bool(ode or cfg.no_random or last))
