@@ -367,6 +367,7 @@ def main():
         lib.dbfr_profile_read(h, None, None, None, None, 1)
         lib.dbfr_profile_enable(h, 1)
     done = []
+    regrown0 = model.regrown
     # host time spent in batch assembly (record halves -> packed batch, launches included) inside the timed region, for the read-out
     asm_s = [0.0]
     _assemble = assemble.assemble
@@ -503,6 +504,7 @@ def main():
                                       f"(all_gather_into_tensor in windows of 256 MiB per rank)",
                        "dist_backend": (ddist.dist.get_backend() if ddist.dist.is_initialized() else None),
                        "store": args.store, "gather": args.gather,
+                       "edge_budget_regrown_in_timed_region": model.regrown - regrown0,     # DBFR_ERR_CAPACITY -> limits raised -> step resumed
                        "ranks_seen": len(per_rank),
                        "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
                                      "sampling_s": round(v[5], 4), "gather_and_unpack_s": round(v[4] - v[5], 4),
