@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--cpu-batched-steps", type=int, default=5)
     ap.add_argument("--jobs", type=int, default=None, help="size of the job table (weak scaling: per rank); default --steps x (--batch-poses // poses per job)")
     ap.add_argument("--store", choices=("device", "host"), default="device", help="dist.run_sharded: pose records in HBM, or streamed to pinned host memory batch by batch")
+    ap.add_argument("--no-speed-shard", action="store_true", help="N > 1: shard the job table evenly instead of by the ranks' measured speed")
     ap.add_argument("--gather", choices=("all", "root"), default="all", help="dist.run_sharded: every rank receives every pose, or rank 0 only")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher: be one
@@ -352,16 +353,26 @@ def main():
     T = len(recs)
     n_jobs = (args.jobs if args.jobs else args.steps * jobs_per_batch) * (world if args.scaling == "weak" else 1)
     jobs = make_jobs(args.config, n_jobs, seed=1)
-    shards, reps = ddist.shard_jobs(jobs, ppc, world)
+    warm = make_jobs(args.config, jobs_per_batch, seed=2)
+    for i in range(args.warmup):
+        samp.run_complexes(warm, ppc, dev, seed=i)
+    torch.cuda.synchronize(dev)
+    # N > 1: boards hold clocks up to 5 % apart at the power cap, and a statically sharded job takes as long as its slowest rank.  Every
+    # rank times ONE more untimed batch of the same jobs (workspace and code already warm), the times are all-gathered and the job table
+    # is LPT-sharded by measured speed (dist.rank_speeds): faster boards take proportionally more jobs.  The poses do not depend on it.
+    speeds = None
+    if world > 1 and args.warmup > 0 and not args.no_speed_shard:      # (with --warmup 0 the batch would time one-off set-up costs)
+        ddist.barrier()
+        tc = time.perf_counter()
+        samp.run_complexes(warm, ppc, dev, seed=12345)
+        torch.cuda.synchronize(dev)
+        speeds = ddist.rank_speeds(time.perf_counter() - tc, dev)
+    shards, reps = ddist.shard_jobs(jobs, ppc, world, speeds)
     t_up = time.perf_counter()
     for j in shards[rank]:                       # per-complex records resident in HBM before the timed region
         jobs[j].lig.dev(dev), jobs[j].pocket.dev(dev)
     torch.cuda.synchronize(dev)
     t_up = time.perf_counter() - t_up
-    warm = make_jobs(args.config, jobs_per_batch, seed=2)
-    for i in range(args.warmup):
-        samp.run_complexes(warm, ppc, dev, seed=i)
-    torch.cuda.synchronize(dev)
     h = model.handle(dev)
     if not args.no_profile:
         lib.dbfr_profile_read(h, None, None, None, None, 1)
@@ -389,7 +400,7 @@ def main():
         done.append(n)
         stamps.append(time.perf_counter())      # every batch ends with a status sync on its stream: the stamp is a completion time
     res = ddist.run_sharded(samp, jobs, ppc, seed=100, device=dev, batch_poses=B, on_batch=on_batch, store=args.store, gather=args.gather,
-                            release=False)      # (the records stay resident: they were uploaded before the timed region)
+                            release=False, rank_speed=speeds)      # (the records stay resident: they were uploaded before the timed region)
     torch.cuda.synchronize(dev)
     assemble.assemble = _assemble
     t_local = time.perf_counter() - t0          # this rank's own clock, sampling + gather
@@ -506,6 +517,7 @@ def main():
                        "store": args.store, "gather": args.gather,
                        "edge_budget_regrown_in_timed_region": model.regrown - regrown0,     # DBFR_ERR_CAPACITY -> limits raised -> step resumed
                        "ranks_seen": len(per_rank),
+                       "rank_speed": ([round(v, 4) for v in speeds] if speeds else None),     # relative, from one untimed calibration batch; the LPT shard's weights
                        "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
                                      "sampling_s": round(v[5], 4), "gather_and_unpack_s": round(v[4] - v[5], 4),
                                      "torch_peak_hbm_gib": round(v[6], 3), "records_upload_s_before_timing": round(v[7], 4),

@@ -57,14 +57,18 @@ def complex_cost(n_atoms, n_lig, n_cab=None):
     return 10.4 * n_atoms + 15 * n_lig + 2 * n_lig * (n_cab + 11)
 
 
-def shard_lpt(costs, world):
+def shard_lpt(costs, world, speeds=None):
     """Longest-processing-time-first assignment of complexes (all poses of a complex stay on
-    one GPU so its static tensors are uploaded once).  Returns list[world] of index lists."""
+    one GPU so its static tensors are uploaded once).  Returns list[world] of index lists.
+    ``speeds``: relative throughput of every rank (``rank_speeds``; None = all equal): a job goes to the rank that would FINISH it
+    first, so a board that holds a higher clock at the power cap takes proportionally more of the table and all ranks end together."""
+    speeds = [1.0] * world if speeds is None else [float(v) for v in speeds]
+    assert len(speeds) == world and min(speeds) > 0
     order = sorted(range(len(costs)), key=lambda i: -costs[i])
     load = [0.0] * world
     out = [[] for _ in range(world)]
     for i in order:
-        r = min(range(world), key=lambda k: (load[k], k))
+        r = min(range(world), key=lambda k: ((load[k] + costs[i]) / speeds[k], k))
         out[r].append(i)
         load[r] += costs[i]
     for o in out:
@@ -149,10 +153,20 @@ def plan_batches(job_poses, batch_poses):
     return out
 
 
-def shard_jobs(jobs, poses, world):
+def shard_jobs(jobs, poses, world, speeds=None):
     """LPT over the jobs' pose-step cost (``ComplexRecord.cost`` x poses); all poses of a job stay on one rank."""
     reps = [poses] * len(jobs) if isinstance(poses, int) else list(poses)
-    return shard_lpt([j.cost * p for j, p in zip(jobs, reps)], world), reps
+    return shard_lpt([j.cost * p for j, p in zip(jobs, reps)], world, speeds), reps
+
+
+def rank_speeds(seconds, device, spread=0.10):
+    """Relative speed of every rank from the time each took for the SAME calibration batch (all-gathered, so every rank derives the same
+    list): 1 / t, normalised to mean 1, held within +-``spread`` of it (a mis-timed calibration must not unbalance the table by more
+    than the boards can differ: MI355X boards measured here hold clocks 5 % apart at the power cap).  One rank: [1.0]."""
+    ts = [v[0] for v in all_gather_vec([float(seconds)], device)]
+    inv = [1.0 / max(t, 1e-9) for t in ts]
+    mean = sum(inv) / len(inv)
+    return [min(1.0 + spread, max(1.0 - spread, v / mean)) for v in inv]
 
 
 def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
@@ -191,7 +205,7 @@ def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
 
 
 def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_max=10.0, gather=True, on_batch=None,
-                store="device", window_bytes=256 << 20, release=False, tapes=None):
+                store="device", window_bytes=256 << 20, release=False, tapes=None, rank_speed=None):
     """The multi-GPU product entry: a job list in, poses out in job order.
 
         jobs    list of ``assemble.ComplexRecord`` -- the (protein, ligand) pair table of the reference
@@ -209,6 +223,8 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
                 tables whose records do not fit HBM together (the forward screen's 10 k ligands do, at 20 KB each).  It MUTATES the
                 caller's records (a second run uploads them again), hence off by default.
         tapes   {job index: (init tape, noise tape)} of recorded random numbers used instead of drawing (``draw_tapes``).
+        rank_speed  list[world] of relative rank speeds (``rank_speeds``: measured on a calibration batch), THE SAME LIST ON EVERY
+                RANK: the LPT shard weighs the ranks by it.  The poses do not depend on it (per-job random streams).
 
     Every rank holds the whole (cheap, host-side) job table, takes its LPT share, runs it in batches of <= ``batch_poses``
     poses through ``run_complexes``.  Every JOB draws from its own generator ``job_seed(seed, job)``; a job cut into several
@@ -222,7 +238,7 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
     dev = torch.device(device)
     assert store in ("device", "host") and gather in (True, False, "all", "root")
     mode = "all" if gather is True else gather
-    shards, reps = shard_jobs(jobs, poses, world)
+    shards, reps = shard_jobs(jobs, poses, world, rank_speed)
     width = [3 * j.n_l + 42 * j.n_r for j in jobs]
     # flat record buffer of a rank: its jobs in shard order, poses consecutive
     off = [{} for _ in range(world)]

@@ -29,8 +29,9 @@ def _worker(rank, world, port, q):
     fixed = ddist.gather_records(torch.full((2, 3), float(rank)))
     mx = ddist.max_over_ranks(1.0 + rank, "cpu")
     vec = ddist.all_gather_vec([rank, 10 + rank, 0.5 * rank], "cpu")          # bench.py's per-rank read-out
+    sp = ddist.rank_speeds(2.0 if rank == 0 else 2.5, "cpu")                  # rank 0 took 2.0 s for the calibration batch, rank 1 2.5 s
     ddist.barrier()
-    q.put((rank, allr.tolist(), fixed.tolist(), mx, vec))
+    q.put((rank, allr.tolist(), fixed.tolist(), mx, vec, sp))
     dist.destroy_process_group()
 
 
@@ -45,7 +46,8 @@ def test_gather_over_gloo_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, a0, f0, m0, v0), (r1, a1, f1, m1, v1) = res
+    (r0, a0, f0, m0, v0, s0), (r1, a1, f1, m1, v1, s1) = res
+    assert s0 == s1 and abs(s0[0] - 1.1) < 1e-9 and abs(s0[1] - 0.9) < 1e-9   # same list on both ranks; 1/2.0 : 1/2.5 = 1.111 : 0.889, held within +-10 %
     assert a0 == a1 and f0 == f1 and m0 == m1 == 2.0
     assert v0 == v1 == [[0.0, 10.0, 0.0], [1.0, 11.0, 0.5]]            # every rank sees every rank's numbers, in rank order
     assert sorted(int(x[0]) for x in a0) == [0, 1, 2, 3, 4]            # every complex gathered exactly once

@@ -251,6 +251,24 @@ def test_shard_lpt_is_balanced_and_complete():
     assert max(loads) / min(loads) < 1.02
 
 
+def test_shard_lpt_weighs_the_ranks_by_speed():
+    """`shard_lpt(costs, world, speeds)`: boards hold clocks a few per cent apart at the power cap; a job goes to the rank that would finish
+    it first, so the finish times (load / speed) even out instead of the loads."""
+    rng = np.random.default_rng(2)
+    costs = rng.uniform(0.9, 1.1, 640).tolist()
+    speeds = [1.05, 1.0, 0.95, 1.0]
+    parts = ddist.shard_lpt(costs, 4, speeds)
+    assert sorted(i for p in parts for i in p) == list(range(640))
+    t = [sum(costs[i] for i in p) / v for p, v in zip(parts, speeds)]
+    assert max(t) / min(t) < 1.01                               # all ranks end together ...
+    even = ddist.shard_lpt(costs, 4)
+    t_even = [sum(costs[i] for i in p) / v for p, v in zip(even, speeds)]
+    assert max(t_even) / min(t_even) > 1.08 and max(t) < 0.96 * max(t_even)      # ... where the even shard waits 5 % for the slow board
+    assert ddist.shard_lpt(costs, 4, [1.0] * 4) == even
+    assert ddist.rank_speeds(3.0, "cpu") == [1.0]               # one rank: nothing to weigh
+
+
+
 def test_header_is_plain_c(tmp_path):
     """include/dbfr.h must compile as C (no C++/torch/hip types in the ABI)."""
     import subprocess

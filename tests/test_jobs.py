@@ -404,7 +404,7 @@ def test_bench_spawns_its_own_ranks():
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(DBFR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch-poses", "320",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch-poses", "320",
                         "--no-profile"], env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
     out = [l for l in r.stdout.splitlines() if l.strip()]
@@ -415,6 +415,8 @@ def test_bench_spawns_its_own_ranks():
     assert c["dist_backend"] == "gloo" and c["ranks_seen"] == 2 and c["poses_total"] == 640
     assert sorted(p["rank"] for p in c["per_rank"]) == [0, 1] and sum(p["poses"] for p in c["per_rank"]) == 640
     assert all(p["elapsed_s"] > 0 for p in c["per_rank"])
+    # the job table was sharded by the ranks' measured speed (one untimed calibration batch, all-gathered): weights around 1, within +-10 %
+    assert len(c["rank_speed"]) == 2 and all(0.9 <= v <= 1.1 for v in c["rank_speed"]) and abs(sum(c["rank_speed"]) - 2.0) < 0.05
     # a launcher environment that contradicts the command line is refused, not silently run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-profile"],
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
