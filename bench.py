@@ -232,6 +232,78 @@ def measure_traffic(mode, args):
     return out, None
 
 
+class BoardSampler:
+    """Board power and shader clock of one GPU while the timed region runs: `rocm-smi -d <idx> --showpower --showclocks --json` about once a
+    second from a host thread (a register read through the SMI library: nothing is launched on the GPU).  The conv kernel runs at the board's
+    power cap, so the clock the firmware grants differs from board to board -- the line carries what THIS board did (`config.board`).
+    Best effort: no rocm-smi, or an output it cannot read, gives None and costs nothing."""
+
+    def __init__(self, idx):
+        import shutil
+        import threading
+        self.idx, self.rows, self.cap = idx, [], None
+        self.exe = shutil.which("rocm-smi")
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.exe else None
+
+    def _query(self, *flags):
+        import subprocess
+        r = subprocess.run([self.exe, "-d", str(self.idx), *flags, "--json"], capture_output=True, text=True, timeout=10)
+        return next(iter(json.loads(r.stdout).values()))
+
+    def _run(self):
+        import re
+        while not self._stop.wait(1.0):
+            try:
+                c = self._query("--showpower", "--showclocks")
+                pw = sclk = None
+                for k, v in c.items():
+                    kl = k.lower()
+                    if pw is None and "power" in kl and "(w)" in kl:
+                        try:
+                            pw = float(v)
+                        except ValueError:
+                            pass
+                    m = re.search(r"(\d+)\s*mhz", str(v), re.I) if kl.startswith("sclk") else None
+                    if sclk is None and m:
+                        sclk = float(m.group(1))
+                if pw is not None or sclk is not None:
+                    self.rows.append((pw, sclk))
+            except Exception:
+                pass
+
+    def start(self):
+        if self._th:
+            try:
+                m = self._query("--showmaxpower")
+                for k, v in m.items():
+                    if "power" in k.lower():
+                        try:
+                            self.cap = float(v)
+                            break
+                        except ValueError:
+                            pass
+            except Exception:
+                pass
+            self._th.start()
+        return self
+
+    def stop(self):
+        if not self._th:
+            return None
+        self._stop.set()
+        self._th.join(timeout=15)
+        rows = self.rows[2:] if len(self.rows) > 4 else self.rows       # (the first two seconds ramp up)
+        if not rows:
+            return None
+        pw = [r[0] for r in rows if r[0] is not None]
+        ck = [r[1] for r in rows if r[1] is not None]
+        return {"power_cap_w": self.cap, "samples": len(rows),
+                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": max(pw) if pw else None,
+                "sclk_mhz_mean": round(sum(ck) / len(ck), 1) if ck else None, "sclk_mhz_min": min(ck) if ck else None,
+                "source": "rocm-smi -d %d --showpower --showclocks --json, once a second during the timed region (rank 0's board)" % self.idx}
+
+
 def latency_leg(samp, dev, lib, model):
     """BASELINE configs[0] literally, as predict.py is used: ONE complex of the 3DBS shape x 4 poses x 20 steps
     (records resident, assemble + init + sample + status sync timed), predict.py's `-bs 16` of the cfg-2 shape, and the shape of the
@@ -323,6 +395,7 @@ def main():
     ap.add_argument("--cpu-batched-steps", type=int, default=5)
     ap.add_argument("--jobs", type=int, default=None, help="size of the job table (weak scaling: per rank); default --steps x (--batch-poses // poses per job)")
     ap.add_argument("--store", choices=("device", "host"), default="device", help="dist.run_sharded: pose records in HBM, or streamed to pinned host memory batch by batch")
+    ap.add_argument("--no-board", action="store_true", help="do not sample board power / clock with rocm-smi during the timed region")
     ap.add_argument("--no-speed-shard", action="store_true", help="N > 1: shard the job table evenly instead of by the ranks' measured speed")
     ap.add_argument("--gather", choices=("all", "root"), default="all", help="dist.run_sharded: every rank receives every pose, or rank 0 only")
     args = ap.parse_args()
@@ -391,6 +464,7 @@ def main():
             asm_s[0] += time.perf_counter() - t
     assemble.assemble = timed_assemble
     torch.cuda.reset_peak_memory_stats(dev)
+    board = BoardSampler(dev.index).start() if rank == 0 and not args.no_board else None
     ddist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -407,6 +481,7 @@ def main():
     ddist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = ddist.max_over_ranks(elapsed, dev)
+    board = board.stop() if board is not None else None
     t_sampled = (stamps[-1] - t0) if stamps else 0.0
     # what every rank did, all-gathered: the line shows that the collective saw `world` ranks, and on which devices
     per_rank = ddist.all_gather_vec([rank, dev.index, float(sum(done)), len(done), t_local, t_sampled,
@@ -516,6 +591,7 @@ def main():
                        "dist_backend": (ddist.dist.get_backend() if ddist.dist.is_initialized() else None),
                        "store": args.store, "gather": args.gather,
                        "edge_budget_regrown_in_timed_region": model.regrown - regrown0,     # DBFR_ERR_CAPACITY -> limits raised -> step resumed
+                       "board": board,      # power cap, power and shader clock of rank 0's board during the timed region (rocm-smi), or None
                        "ranks_seen": len(per_rank),
                        "rank_speed": ([round(v, 4) for v in speeds] if speeds else None),     # relative, from one untimed calibration batch; the LPT shard's weights
                        "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
