@@ -105,6 +105,31 @@ def test_trajectory_matches_reference_fixture(setup, dev, both_gemms):
     assert (a14.cpu() - torch.from_numpy(z["traj_atom14"])).norm(dim=-1).max() < POSE_ATOL
 
 
+def test_level1_model_inside_the_reference_style_sampler_loop(setup, dev):
+    """The level-1 drop-in (`--cfg-options model.diffusion_model.type=TensorProductModelHIP`): only the score
+    network is replaced, the sampler loop stays the reference's.  Here the loop is the oracle's restatement of scFlex.py:124-250 (deepcopy,
+    set_time, perturbations, update_batchlig_pos, side-chain rebuild -- all on the CPU, pinned on the reference at max|d| = 0) calling
+    `TensorProductModelHIP.forward(data)` for every one of the 20 steps with the batched dict the reference hands its model; the
+    trajectory must be the reference's."""
+    mcfg, params, model = setup
+    d, z = load_golden_batch()
+    from diffbindfr_amd import synthetic as syn
+    a14g = torch.from_numpy(syn.residue_tables()["atom14_to_group"]).long()
+    scfg = osched.default_sample_cfg()
+    noise = osampler.draw_noise(scfg.actual_steps, d.num_graphs, int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum()), seed=int(z["noise_seed"]))
+    data = copy.deepcopy(d)
+    lig_out, a14_out = [], []
+    for t_idx in range(scfg.actual_steps):
+        sc = osched.step_scalars(scfg, t_idx)
+        _data = osampler.set_time(copy.deepcopy(data), sc, d.num_graphs)
+        scores = [x.cpu() if x is not None else None for x in model(namespace_to(_data, dev))]       # the level-1 boundary
+        atom14, _ = osampler.sde_step(data, sc, scores, noise, t_idx, a14g)
+        lig_out.append(data.lig_pos.clone())
+        a14_out.append(atom14.clone())
+    assert (torch.stack(lig_out) - torch.from_numpy(z["traj_lig"])).norm(dim=-1).max() < POSE_ATOL
+    assert (torch.stack(a14_out) - torch.from_numpy(z["traj_atom14"])).norm(dim=-1).max() < POSE_ATOL
+
+
 @pytest.mark.parametrize("tag,over", [("ode", dict(type="ode")), ("no_random", dict(no_random=True))])
 def test_sampler_modes_match_the_reference_fixture(setup, dev, tag, over):
     """`--cfg-options model.test_cfg.sample_cfg.type=ode` (scFlex.py:162-165,199-200) and `no_random=True` (:167-183): the reference's
