@@ -53,27 +53,31 @@ struct TrRotArgs {
   Mlp2 tr, rot; int G; int scale_by_sigma; float* tr_out; float* rot_out; int* err;
 };
 
-__device__ float head_mlp(const Mlp2& w, float nrm, const float* temb) {
-  float out = w.b1 ? w.b1[0] : 0.f;
-  for (int h = 0; h < w.hid; ++h) {
-    float a = w.b0 ? w.b0[h] : 0.f;
-    a += w.w0t[h] * nrm;                               // w0t [in][hid], in index 0 = norm
-    for (int i = 0; i < EMB; ++i) a += w.w0t[(1 + i) * w.hid + h] * temb[i];
-    out += w.w1t[h] * fmaxf(a, 0.f);                   // w1t [hid][1]
-  }
-  return out;
+// One hidden unit of the head MLP (tpscore.py:529-546: Linear(1 + 32 -> ns) - ReLU - Linear(ns -> 1)), times its output weight.
+__device__ __forceinline__ float head_hidden(const Mlp2& w, int h, float nrm, const float* temb) {
+  float a = w.b0 ? w.b0[h] : 0.f;
+  a += w.w0t[h] * nrm;                               // w0t [in][hid], in index 0 = norm
+  for (int i = 0; i < EMB; ++i) a += w.w0t[(1 + i) * w.hid + h] * temb[i];
+  return w.w1t[h] * fmaxf(a, 0.f);                   // w1t [hid][1]
 }
 
-__global__ void k_trrot(TrRotArgs a) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= a.G) return;
+// A wavefront per graph: lane h evaluates hidden unit h of both heads (the weight rows are read coalesced), lane 0 adds the ns terms in
+// index order (fixed order: reproducible).  The one-thread-per-graph form of rounds 1-3 took 64 us per step: 1.5 % of a predict.py-sized step.
+__global__ __launch_bounds__(64) void k_trrot(TrRotArgs a) {
+  __shared__ float part[2][64];
+  const int g = blockIdx.x, h = threadIdx.x;
   const float* v = a.gp + (size_t)g * 12;
   float tr[3] = {v[0] + v[6], v[1] + v[7], v[2] + v[8]};
   float rt[3] = {v[3] + v[9], v[4] + v[10], v[5] + v[11]};
   float ntr = sqrtf(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]);
   float nrt = sqrtf(rt[0] * rt[0] + rt[1] * rt[1] + rt[2] * rt[2]);
-  float mtr = head_mlp(a.tr, ntr, a.temb + g * EMB);
-  float mrt = head_mlp(a.rot, nrt, a.temb + g * EMB);
+  part[0][h] = h < a.tr.hid ? head_hidden(a.tr, h, ntr, a.temb + g * EMB) : 0.f;
+  part[1][h] = h < a.rot.hid ? head_hidden(a.rot, h, nrt, a.temb + g * EMB) : 0.f;
+  __syncthreads();
+  if (h != 0) return;
+  float mtr = a.tr.b1 ? a.tr.b1[0] : 0.f, mrt = a.rot.b1 ? a.rot.b1[0] : 0.f;
+  for (int q = 0; q < a.tr.hid; ++q) mtr += part[0][q];
+  for (int q = 0; q < a.rot.hid; ++q) mrt += part[1][q];
   for (int k = 0; k < 3; ++k) {
     float t = tr[k] / ntr * mtr, r = rt[k] / nrt * mrt;
     if (a.scale_by_sigma) { t = t / a.tr_sigma[g]; r = r * a.rot_norm[g]; }
@@ -84,7 +88,7 @@ __global__ void k_trrot(TrRotArgs a) {
 }
 
 void launch_trrot(const TrRotArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_trrot, dim3((a.G + 63) / 64), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_trrot, dim3(a.G), dim3(64), 0, st, a);      // (hid = ns = 48 <= 64: one lane per hidden unit)
 }
 
 // bond_attr[k][:NS] = x[b0][:NS] + x[b1][:NS]
