@@ -395,6 +395,7 @@ def main():
     ap.add_argument("--cpu-batched-steps", type=int, default=5)
     ap.add_argument("--jobs", type=int, default=None, help="size of the job table (weak scaling: per rank); default --steps x (--batch-poses // poses per job)")
     ap.add_argument("--store", choices=("device", "host"), default="device", help="dist.run_sharded: pose records in HBM, or streamed to pinned host memory batch by batch")
+    ap.add_argument("--no-probe", action="store_true", help="do not measure what the bare matrix pipe sustains on this board (4 s; roofline.frac_of_sustained then uses round 3's constant)")
     ap.add_argument("--no-board", action="store_true", help="do not sample board power / clock with rocm-smi during the timed region")
     ap.add_argument("--no-speed-shard", action="store_true", help="N > 1: shard the job table evenly instead of by the ranks' measured speed")
     ap.add_argument("--gather", choices=("all", "root"), default="all", help="dist.run_sharded: every rank receives every pose, or rank 0 only")
@@ -554,6 +555,15 @@ def main():
 
     mode = main_mode = model.gemm_mode(dev)
     roof = None if args.no_profile else read_roofline(elapsed, mode)
+    if roof is not None and world == 1 and mode == "split_f16" and not args.no_probe:
+        # the denominator of frac_of_sustained measured on THIS board: a bare stream of the instruction with random operands for 4 s
+        sus = C.c_double()
+        if lib.dbfr_probe_mfma_f16(4.0, C.byref(sus), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0:
+            roof["pipe_sustained_random_operands"] = round(sus.value, 1)
+            roof["frac_of_sustained"] = round(roof["achieved"] / sus.value, 4)
+            roof["sustained_note"] = ("measured in this run on this board (dbfr_probe_mfma_f16: a bare stream of the instruction with random operands on every CU "
+                                      "for 4 s, rate over the last 2 s); round 3's board: 1937 (profiles/r3_mfma_power.txt); the nominal peak is reached with "
+                                      "all-zero operands only")
     native = None
     if world == 1 and not args.no_profile and not args.no_native and mode != "f32":
         # the same batch through the fp32-matrix-instruction kernels (k_conv / k_conv2), for the record: one batch, untimed warm-up first

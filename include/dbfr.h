@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define DBFR_ABI_VERSION 3   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
-                                3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs (additions only) */
+                                3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only) */
 
 typedef enum {
   DBFR_OK = 0,
@@ -467,6 +467,12 @@ int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, do
 /* HBM bytes the FUSED conv has to move for the launches the last dbfr_profile_read reported (read before its reset):
  * 4 (48 + 9 + 3 + 48 + 48 + D_in + D_out) per edge = edge record, two gathered radial-MLP rows, gathered input row, message. */
 int dbfr_profile_fused_bytes(const dbfr_model* m, double* fused_form_bytes);
+
+/* What the fp16 matrix pipe of the CURRENT device sustains: a bare stream of v_mfma_f32_16x16x32_f16 (the instruction of DBFR_GEMM_SPLIT_F16)
+ * with random operands on every compute unit, two waves per SIMD, for `seconds` (0 < seconds <= 60; the rate is taken over the second half,
+ * when the firmware has settled the clock at the board's power cap).  *tflops = executed TFLOP/s.  bench.py's roofline.frac_of_sustained
+ * divides by it; the instruction's nominal peak (2 500) is reached with all-zero operands only.  Blocks the calling thread.            */
+int dbfr_probe_mfma_f16(double seconds, double* tflops, void* hip_stream);
 
 /* Test hook: names (';'-separated) / byte offsets / sizes of the library's internal
  * buffers inside the workspace for this batch shape.  Returns the entry count.       */
