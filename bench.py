@@ -233,58 +233,44 @@ def measure_traffic(mode, args):
 
 
 class BoardSampler:
-    """Board power and shader clock of one GPU while the timed region runs: `rocm-smi -d <idx> --showpower --showclocks --json` about once a
-    second from a host thread (a register read through the SMI library: nothing is launched on the GPU).  The conv kernel runs at the board's
-    power cap, so the clock the firmware grants differs from board to board -- the line carries what THIS board did (`config.board`).
-    Best effort: no rocm-smi, or an output it cannot read, gives None and costs nothing."""
+    """Board power and shader clock of one GPU while the timed region runs, read twice a second from the amdgpu hwmon files
+    (/sys/class/drm/card*/device/hwmon/hwmon*/power1_input [uW], freq1_input [Hz], power1_cap) by a host thread -- two small file reads,
+    no subprocess, nothing launched on the GPU.  The conv kernel runs at the board's power cap, so the clock the firmware grants differs
+    from board to board: the line carries what THIS board did (`config.board`).  The card is found by the HIP device's PCI address.  Best effort: without the files it returns None and costs nothing."""
 
     def __init__(self, idx):
-        import shutil
+        import glob
         import threading
-        self.idx, self.rows, self.cap = idx, [], None
-        self.exe = shutil.which("rocm-smi")
+        # the card whose PCI address is the HIP device's (a node's other boards may show up in sysfs too)
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(idx)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+                if os.path.basename(os.path.realpath(f.split("/hwmon/")[0])).startswith(want):
+                    self.dir = os.path.dirname(f)
+                    break
+        except Exception:
+            pass
+        self.rows = []
         self._stop = threading.Event()
-        self._th = threading.Thread(target=self._run, daemon=True) if self.exe else None
+        self._th = threading.Thread(target=self._run, daemon=True) if self.dir else None
 
-    def _query(self, *flags):
-        import subprocess
-        r = subprocess.run([self.exe, "-d", str(self.idx), *flags, "--json"], capture_output=True, text=True, timeout=10)
-        return next(iter(json.loads(r.stdout).values()))
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
 
     def _run(self):
-        import re
-        while not self._stop.wait(1.0):
-            try:
-                c = self._query("--showpower", "--showclocks")
-                pw = sclk = None
-                for k, v in c.items():
-                    kl = k.lower()
-                    if pw is None and "power" in kl and "(w)" in kl:
-                        try:
-                            pw = float(v)
-                        except ValueError:
-                            pass
-                    m = re.search(r"(\d+)\s*mhz", str(v), re.I) if kl.startswith("sclk") else None
-                    if sclk is None and m:
-                        sclk = float(m.group(1))
-                if pw is not None or sclk is not None:
-                    self.rows.append((pw, sclk))
-            except Exception:
-                pass
+        while not self._stop.wait(0.5):
+            pw, ck = self._read("power1_input"), self._read("freq1_input")
+            if pw is not None or ck is not None:
+                self.rows.append((pw / 1e6 if pw is not None else None, ck / 1e6 if ck is not None else None))
 
     def start(self):
         if self._th:
-            try:
-                m = self._query("--showmaxpower")
-                for k, v in m.items():
-                    if "power" in k.lower():
-                        try:
-                            self.cap = float(v)
-                            break
-                        except ValueError:
-                            pass
-            except Exception:
-                pass
             self._th.start()
         return self
 
@@ -292,16 +278,17 @@ class BoardSampler:
         if not self._th:
             return None
         self._stop.set()
-        self._th.join(timeout=15)
-        rows = self.rows[2:] if len(self.rows) > 4 else self.rows       # (the first two seconds ramp up)
+        self._th.join(timeout=5)
+        rows = self.rows[4:] if len(self.rows) > 8 else self.rows       # (the first two seconds ramp up)
         if not rows:
             return None
         pw = [r[0] for r in rows if r[0] is not None]
         ck = [r[1] for r in rows if r[1] is not None]
-        return {"power_cap_w": self.cap, "samples": len(rows),
-                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": max(pw) if pw else None,
-                "sclk_mhz_mean": round(sum(ck) / len(ck), 1) if ck else None, "sclk_mhz_min": min(ck) if ck else None,
-                "source": "rocm-smi -d %d --showpower --showclocks --json, once a second during the timed region (rank 0's board)" % self.idx}
+        cap = self._read("power1_cap")
+        return {"power_cap_w": cap / 1e6 if cap else None, "samples": len(rows),
+                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": round(max(pw), 1) if pw else None,
+                "sclk_mhz_mean": round(sum(ck) / len(ck), 1) if ck else None, "sclk_mhz_min": round(min(ck), 1) if ck else None,
+                "source": f"{self.dir}/power1_input, freq1_input, twice a second during the timed region (rank 0's board)"}
 
 
 def latency_leg(samp, dev, lib, model):
@@ -396,7 +383,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=None, help="size of the job table (weak scaling: per rank); default --steps x (--batch-poses // poses per job)")
     ap.add_argument("--store", choices=("device", "host"), default="device", help="dist.run_sharded: pose records in HBM, or streamed to pinned host memory batch by batch")
     ap.add_argument("--no-probe", action="store_true", help="do not measure what the bare matrix pipe sustains on this board (4 s; roofline.frac_of_sustained then uses round 3's constant)")
-    ap.add_argument("--no-board", action="store_true", help="do not sample board power / clock with rocm-smi during the timed region")
+    ap.add_argument("--no-board", action="store_true", help="do not sample board power / clock (amdgpu hwmon files) during the timed region")
     ap.add_argument("--no-speed-shard", action="store_true", help="N > 1: shard the job table evenly instead of by the ranks' measured speed")
     ap.add_argument("--gather", choices=("all", "root"), default="all", help="dist.run_sharded: every rank receives every pose, or rank 0 only")
     args = ap.parse_args()
@@ -591,6 +578,7 @@ def main():
                                    f"({'one shared ' + cfg['shared'] + ', ' if cfg.get('shared') else ''}~{cfg['n_atoms']} pocket atoms / "
                                    f"~{cfg['n_lig']} ligand atoms, {T} denoise steps per pose) through dist.run_sharded",
                        "batch_poses": B, "batches_this_rank": len(done), "poses_this_rank": int(sum(done)),
+                       "batch_seconds_this_rank": [round(b - a, 3) for a, b in zip([t0] + stamps[:-1], stamps)],
                        "poses_total": poses, "denoise_steps": T,
                        "edges_last_step": {"lig": counters[0], "atom": counters[1], "cross": counters[2],
                                            "center": counters[3], "tor": counters[4], "sc_tor": counters[5]},
@@ -601,7 +589,7 @@ def main():
                        "dist_backend": (ddist.dist.get_backend() if ddist.dist.is_initialized() else None),
                        "store": args.store, "gather": args.gather,
                        "edge_budget_regrown_in_timed_region": model.regrown - regrown0,     # DBFR_ERR_CAPACITY -> limits raised -> step resumed
-                       "board": board,      # power cap, power and shader clock of rank 0's board during the timed region (rocm-smi), or None
+                       "board": board,      # power cap, power and shader clock of rank 0's board during the timed region (amdgpu hwmon files), or None
                        "ranks_seen": len(per_rank),
                        "rank_speed": ([round(v, 4) for v in speeds] if speeds else None),     # relative, from one untimed calibration batch; the LPT shard's weights
                        "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
