@@ -14,6 +14,7 @@ void launch_conv2(const Conv2Args& a, hipStream_t st);
 void launch_conv2s(const Conv2Args& a, hipStream_t st);
 void launch_conv2r(const Conv2Args& a, hipStream_t st);
 void launch_conv2h(const Conv2Args& a, hipStream_t st);
+void launch_convz(const ConvZArgs& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
                       const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
 struct ReduceLayerArgs {
@@ -34,6 +35,7 @@ struct GraphArgs {
 };
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
 void launch_edge_log(const GraphArgs& A, int* log_row, hipStream_t st);
+void launch_graph_chunks(const GraphArgs& A, hipStream_t st);
 void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
                           int* tor_batch, int* sc_batch, hipStream_t st);
 void launch_time_embed(const float* t, int G, float emb_scale, float* temb, hipStream_t st);
@@ -120,6 +122,7 @@ static int gemm_from_env() {
   if (!strcmp(e, "split") || !strcmp(e, "1")) return DBFR_GEMM_SPLIT_BF16;
   if (!strcmp(e, "split_l1") || !strcmp(e, "2")) return DBFR_GEMM_SPLIT_BF16_L1;
   if (!strcmp(e, "split_f16") || !strcmp(e, "3")) return DBFR_GEMM_SPLIT_F16;
+  if (!strcmp(e, "reduce_first") || !strcmp(e, "4")) return DBFR_GEMM_REDUCE_FIRST;
   return DBFR_GEMM_F32;
 }
 
@@ -129,6 +132,8 @@ struct dbfr_model {
   ConvW layer[8][4];   // [l][family]: 0 lig, 1 cross_al, 2 atom, 3 cross_la
   ConvW final_conv, tor_conv, sc_conv;
   ConvW2 layer2[8][4], tor_conv2, sc_conv2;   // k_conv2 layouts of the K=144 convs
+  ConvW2 layer2v[8][4];                       // ... of their l = 1 outputs alone (DBFR_GEMM_REDUCE_FIRST: the scalar outputs go through k_convz)
+  ConvZ layerz[8][4], tor_convz, sc_convz;    // reduce-first form of the scalar-output paths (convz.hip)
   int use_conv2;
   int gemm_split;      // DBFR_GEMM_*; non-zero: the 144 x W GEMM of the K=144 convs runs on the bf16 matrix pipe with 3-piece operands (conv2s.hip), any batch size
   int conv_fuse;       // big batches: the four convs of a layer as one k_conv grid (conv.hip: k_conv_layer)
@@ -453,7 +458,9 @@ static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int
 }
 
 // k_conv2 layout (conv2.hip): same channel-owner row order as pack_conv, but ONE tile sequence for all waves.
-static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, int kind, const ConvW& base, ConvW2* o) {
+// vector_only: the rows that feed an l = 0 output irrep are left out (DBFR_GEMM_REDUCE_FIRST serves them through k_convz); only the fp16 pieces
+// are packed then, and a conv without l = 1 outputs (torsion convs) gets n_tiles = 0.
+static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, int kind, const ConvW& base, ConvW2* o, bool vector_only = false) {
   ConvSpec sp = make_conv_spec(kind);
   const int K = sp.K;
   if (K != 144) return fail(DBFR_ERR_ARG, "k_conv2 layout is for the K=144 convs");
@@ -466,6 +473,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   std::vector<Pair> pairs;
   for (int io = 0; io < (int)sp.out.size(); ++io)
     for (int w = 0; w < sp.out[io].mul; ++w) {
+      if (vector_only && sp.out[io].l == 0) continue;
       Pair pr{io, w, {}};
       for (auto& p : sp.paths) if (p.io == io) pr.paths.push_back(&p);
       std::stable_sort(pr.paths.begin(), pr.paths.end(),
@@ -565,9 +573,11 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   memset(o, 0, sizeof *o);
   o->D_in = sp.D_in; o->D_out = sp.D_out; o->n_tiles = n_tiles; o->n_runs = (int)runs.size();
   o->W1p = base.W1p; o->b1 = base.b1;
+  if (!vector_only) {
   o->W2q = upload(m, w2q, &rc);
   o->b2q = upload(m, b2q, &rc);
-  {   // the same fragments cut into three bf16 pieces (conv2s.hip).  Per tile: [3 pieces][4 k-steps of 32][64][8] -- step s = fp32
+  }
+  if (!vector_only) {   // the same fragments cut into three bf16 pieces (conv2s.hip).  Per tile: [3 pieces][4 k-steps of 32][64][8] -- step s = fp32
       // k-steps 2s and 2s+1 of the same lane -- then [3 pieces][64][4] for the last 16 k (fp32 k-step 8)
     const size_t tile_h = 13824 / 2, tail_off = 12288 / 2;
     std::vector<uint16_t> w2s((size_t)n_tiles * tile_h + 512, 0);   // (+ 1 KiB of slack behind the last tile)
@@ -634,6 +644,98 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   return rc;
 }
 
+// Reduce-first form of the scalar-output paths (convz.hip; layout: common.h ConvZ).  c tiles of 16 (path, u_in) pairs per output irrep,
+// scalar-input paths first (48 = 3 full tiles), then the vector-input ones, padded to a tile; W2' = lin.3 row x fold, bias as k = 144,
+// every output ROW (irrep, channel) x its own power of two 2^s (largest |value| into [2^14, 2^15)), cut into two fp16 pieces and stored as the
+// A fragments of step B: [c tile][k tile][k-step v][w tile][piece][lane (n' = channel, g')][i] = W2'[c = 16 ct + (8 g' + i) % 16,
+// k = 16 kt + 2 v + (8 g' + i) / 16, channel 16 wt + n'].
+static int pack_convz(dbfr_model* m, const TMap& tm, const std::string& name, int kind, const ConvW2& base, ConvZ* o) {
+  ConvSpec sp = make_conv_spec(kind);
+  const int K = sp.K;
+  memset(o, 0, sizeof *o);
+  if (K != 144) return fail(DBFR_ERR_ARG, "k_convz is for the K=144 convs");
+  int rc = 0;
+  const float* W2 = need(tm, name + ".fc.lin.3.weight", (int64_t)sp.W * K, &rc);
+  const float* B2 = need(tm, name + ".fc.lin.3.bias", sp.W, &rc);
+  if (rc) return rc;
+  struct Col { const PathDesc* p; int u; };
+  std::vector<std::vector<Col>> cols;      // per scalar output irrep, padded to tiles (p == nullptr: padding)
+  std::vector<int> ios;
+  for (int io = 0; io < (int)sp.out.size(); ++io) {
+    if (sp.out[io].l != 0) continue;
+    if (sp.out[io].mul != NS) return fail(DBFR_ERR_ARG, "scalar output irrep with a multiplicity other than 48 in " + name);
+    std::vector<Col> c;
+    for (int pass = 0; pass < 2; ++pass)
+      for (auto& p : sp.paths) {
+        if (p.io != io || p.l1 != pass) continue;
+        if (p.l1 != p.l2 || p.lo != 0 || p.l1 > 1) return fail(DBFR_ERR_ARG, "unsupported scalar-output path in " + name);
+        for (int u = 0; u < p.mul1; ++u) c.push_back({&p, u});
+      }
+    int n_scalar = 0;
+    for (auto& q : c) n_scalar += q.p->l1 == 0;
+    if (n_scalar % 16) return fail(DBFR_ERR_ARG, "scalar-input columns do not fill whole tiles in " + name);
+    while (c.size() % 16) c.push_back({nullptr, 0});
+    cols.push_back(c);
+    ios.push_back(io);
+  }
+  if (ios.size() > 2) return fail(DBFR_ERR_ARG, "more than two scalar output irreps in " + name);
+  o->n_io = (int)ios.size();
+  int nct_total = 0;
+  for (int i = 0; i < o->n_io; ++i) {
+    o->nct[i] = (int)cols[i].size() / 16;
+    o->ct0[i] = nct_total;
+    nct_total += o->nct[i];
+    int off = 0;
+    for (int j = 0; j < ios[i]; ++j) off += sp.out[j].mul * sp.out[j].dim();
+    o->out_off[i] = off;
+  }
+  if (nct_total > CZ_MAXCT) return fail(DBFR_ERR_ARG, "too many c tiles in " + name);
+  std::vector<uint32_t> cdesc((size_t)std::max(nct_total, 1) * 16, 0u);
+  std::vector<float> rowinv((size_t)std::max(o->n_io, 1) * NS, 1.f);
+  std::vector<uint16_t> w2z((size_t)nct_total * CZ_NKT * 8 * (CZ_TILE_BYTES / 2) + 512, 0);
+  auto h16 = [](float v) { const _Float16 h = (_Float16)v; uint16_t u; memcpy(&u, &h, 2); return u; };
+  for (int i = 0; i < o->n_io; ++i) {
+    const auto& c = cols[i];
+    for (size_t j = 0; j < c.size(); ++j)
+      if (c[j].p) cdesc[(size_t)o->ct0[i] * 16 + j] = (uint32_t)(c[j].p->in_off + c[j].u * (2 * c[j].p->l1 + 1)) | ((uint32_t)c[j].p->l1 << 12) |
+                                                      ((uint32_t)c[j].p->sh_off << 16) | 0x80000000u;
+    auto wval = [&](int cc, int k, int w) -> float {    // W2'[c, k, w]
+      if (cc >= (int)c.size() || !c[cc].p || k > K) return 0.f;
+      const PathDesc* p = c[cc].p;
+      const size_t row = (size_t)p->w_off + (size_t)c[cc].u * p->mulo + w;
+      return p->fold * (k < K ? W2[row * K + k] : B2[row]);
+    };
+    for (int w = 0; w < NS; ++w) {
+      float mx = 0.f;
+      for (int cc = 0; cc < (int)c.size(); ++cc)
+        for (int k = 0; k <= K; ++k) mx = std::max(mx, fabsf(wval(cc, k, w)));
+      int s = 0;
+      if (mx > 0.f) { int e = 0; (void)frexpf(mx, &e); s = std::max(-100, std::min(100, 15 - e)); }
+      rowinv[(size_t)i * NS + w] = ldexpf(1.f, -s);
+      const float sc = ldexpf(1.f, s);
+      const int wt = w >> 4, np = w & 15;
+      for (int ct = 0; ct < o->nct[i]; ++ct)
+        for (int kt = 0; kt < CZ_NKT; ++kt)
+          for (int v = 0; v < 8; ++v)
+            for (int gp = 0; gp < 4; ++gp)
+              for (int t = 0; t < 8; ++t) {
+                const int kl = 32 * v + 8 * gp + t;
+                const float val = wval(16 * ct + (kl & 15), 16 * kt + (kl >> 4), w) * sc;
+                const _Float16 hi = (_Float16)val;
+                const size_t tile = ((size_t)(o->ct0[i] + ct) * CZ_NKT + kt) * 8 + v;
+                const size_t base_h = tile * (CZ_TILE_BYTES / 2) + (size_t)(wt * 2) * 512 + (size_t)(16 * gp + np) * 8 + t;
+                w2z[base_h] = h16(val);
+                w2z[base_h + 512] = h16(val - (float)hi);
+              }
+    }
+  }
+  o->cdesc = upload(m, cdesc, &rc);
+  o->rowinv = upload(m, rowinv, &rc);
+  o->W2z = upload(m, w2z, &rc);
+  o->W1h = base.W1h; o->k1 = base.k1;
+  return rc;
+}
+
 extern "C" int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out) {
   if (!frag || !bias || !out || !k_out || n_tiles <= 0) return fail(DBFR_ERR_ARG, "dbfr_test_pack_f16_tiles: bad argument");
   *k_out = pack_f16_tiles(frag, bias, 0, n_tiles, (uint16_t*)out);
@@ -669,7 +771,7 @@ extern "C" int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t 
 }
 
 extern "C" int dbfr_model_set_gemm(dbfr_model* m, int32_t mode) {
-  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_SPLIT_F16) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
+  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_REDUCE_FIRST) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
   m->gemm_split = mode;
   return DBFR_OK;
 }
@@ -748,14 +850,18 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
       rc = pack_conv(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), &m->layer[l][f]);
       if (!rc) rc = pack_conv2(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer[l][f], &m->layer2[l][f]);
       if (!rc && m->layer2[l][f].f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << l; m->fallback_convs += std::string(fam[f]) + "." + std::to_string(l) + ";"; }
+      if (!rc) rc = pack_conv2(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer[l][f], &m->layer2v[l][f], true);
+      if (!rc) rc = pack_convz(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer2[l][f], &m->layerz[l][f]);
     }
   if (!rc) rc = pack_conv(m, tm, "final_conv", 4, &m->final_conv);
   if (!rc) rc = pack_conv(m, tm, "tor_bond_conv", 5, &m->tor_conv);
   if (!rc) rc = pack_conv2(m, tm, "tor_bond_conv", 5, m->tor_conv, &m->tor_conv2);
   if (!rc && m->tor_conv2.f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << 31; m->fallback_convs += "tor_bond_conv;"; }
+  if (!rc) rc = pack_convz(m, tm, "tor_bond_conv", 5, m->tor_conv2, &m->tor_convz);
   if (!rc && !cfg->no_sc_torsion) rc = pack_conv(m, tm, "sc_tor_bond_conv", 5, &m->sc_conv);
   if (!rc && !cfg->no_sc_torsion) rc = pack_conv2(m, tm, "sc_tor_bond_conv", 5, m->sc_conv, &m->sc_conv2);
   if (!rc && !cfg->no_sc_torsion && m->sc_conv2.f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << 31; m->fallback_convs += "sc_tor_bond_conv;"; }
+  if (!rc && !cfg->no_sc_torsion) rc = pack_convz(m, tm, "sc_tor_bond_conv", 5, m->sc_conv2, &m->sc_convz);
   if (!rc) rc = pack_mlp(m, tm, "lig_node_embedding", cfg->lig_node_features + EMB, NS, NS, true, &m->lig_node_emb);
   if (!rc) rc = pack_mlp(m, tm, "lig_edge_embedding", cfg->lig_edge_features + 2 * EMB, NS, NS, true, &m->lig_edge_emb);
   if (!rc) rc = pack_mlp(m, tm, "atom_edge_embedding", 2 * EMB, NS, NS, true, &m->atom_edge_emb);
@@ -837,7 +943,7 @@ struct Ws {
   int* n_edges6;  // [8] device counters
 };
 
-static void edge_set_take(Bump& b, EdgeSet& S, int cap, int n_targets, int G, int* n_edges, const char* nm) {
+static void edge_set_take(Bump& b, EdgeSet& S, int cap, int n_targets, int G, int n_graphs, int* n_edges, const char* nm) {
   S.cap = cap; S.n_edges = n_edges;
   std::string p(nm);
   S.tgt = b.take<int>(cap, (p + ".tgt").c_str()); S.gth = b.take<int>(cap, (p + ".gth").c_str());
@@ -846,6 +952,7 @@ static void edge_set_take(Bump& b, EdgeSet& S, int cap, int n_targets, int G, in
   S.emb = b.take<float>((size_t)cap * NS, (p + ".emb").c_str());
   S.row_start = b.take<int>(n_targets, (p + ".row_start").c_str()); S.row_cnt = b.take<int>(n_targets, (p + ".row_cnt").c_str());
   S.g_cnt = b.take<int>(G, (p + ".g_cnt").c_str()); S.g_base = b.take<int>(G, (p + ".g_base").c_str());
+  S.chunk0 = b.take<int>(n_graphs + 1, (p + ".chunk0").c_str()); S.gedge0 = b.take<int>(n_graphs + 1, (p + ".gedge0").c_str());
 }
 
 static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim, char* base, size_t cap, Ws* w,
@@ -873,7 +980,7 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   for (int k = 0; k < N_SETS; ++k) {
     if (caps[k] > 0x7fffff00L) return fail(DBFR_ERR_ARG, "batch too large for int32 edge indices; split it");
     static const char* names[N_SETS] = {"ll", "aa", "al", "la", "tor", "sc"};
-    edge_set_take(b, w->set[k], (int)caps[k], ntg[k] + 1, G * dbfr_edge_chunks(B->max_na, B->max_nl), w->n_edges6 ? w->n_edges6 + k : nullptr, names[k]);
+    edge_set_take(b, w->set[k], (int)caps[k], ntg[k] + 1, G * dbfr_edge_chunks(B->max_na, B->max_nl), G, w->n_edges6 ? w->n_edges6 + k : nullptr, names[k]);
     maxcap = std::max(maxcap, caps[k]);
   }
   w->c_tgt = b.take<int>(NL); w->c_gth = b.take<int>(NL); w->c_dist = b.take<float>(NL); w->c_sh = b.take<float>((size_t)NL * SH_LD, "center.sh");
@@ -965,8 +1072,18 @@ static Conv2Desc conv2_desc(const ConvW2& cw, const int* n_edges, int max_edges,
   return d;
 }
 
+static ConvZDesc convz_desc(const Conv2Desc& d, const ConvZ& z, const int* tgt, int D_out, const int* chunk0 = nullptr, const int* gedge0 = nullptr, int n_graph = 0) {
+  ConvZDesc o;
+  o.n_edges = d.n_edges; o.max_edges = d.max_edges; o.tgt = tgt; o.gth = d.gth; o.emb = d.emb; o.sh = d.sh;
+  o.tab1 = d.tab1; o.ld1 = d.ld1; o.idx1 = d.idx1; o.tab2 = d.tab2; o.ld2 = d.ld2; o.idx2 = d.idx2; o.x = d.x; o.ldx = d.ldx;
+  o.w = z; o.msg = d.msg; o.D_out = D_out; o.chunk0 = chunk0; o.gedge0 = gedge0; o.n_graph = n_graph;
+  return o;
+}
+
 // one fused k_conv2 launch over up to four K=144 convs (an interaction layer, or the two torsion heads)
-static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int n, hipStream_t st, bool f16_fallback = false) {
+// DBFR_GEMM_REDUCE_FIRST: `descs` hold the vector-output rows only (ConvW2 packed with vector_only) and `z` (same order) the reduce-first form of
+// the scalar-output rows: k_conv2h for the former (convs without l = 1 outputs are left out), k_convz for the latter, both writing the same message buffers.
+static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int n, hipStream_t st, bool f16_fallback = false, const ConvZDesc* z = nullptr) {
   Conv2Args a;
   memset(&a, 0, sizeof a);
   for (int i = 0; i < n; ++i) a.c[i] = descs[i];
@@ -989,8 +1106,21 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     });
   }
   if (trace_dev) { (void)hipMemsetAsync(trace_dev, 0, 8 * C2_TRACE_CAP * sizeof(unsigned long long), st); a.trace = trace_dev; }
-  if (m->gemm_split == DBFR_GEMM_SPLIT_F16 && !f16_fallback) launch_conv2h(a, st);
-  else if (m->gemm_split == DBFR_GEMM_SPLIT_BF16 || m->gemm_split == DBFR_GEMM_SPLIT_F16) launch_conv2r(a, st);   // (a launch holding a conv whose weights span more than two fp16 pieces hold: three bf16 pieces)
+  if (z) {
+    Conv2Args v = a;
+    v.n_conv = 0;
+    for (int i = 0; i < n; ++i)
+      if (descs[i].w.n_tiles > 0) v.c[v.n_conv++] = descs[i];
+    if (v.n_conv) launch_conv2h(v, st);
+    ConvZArgs za;
+    memset(&za, 0, sizeof za);
+    for (int i = 0; i < n; ++i) za.c[i] = z[i];
+    za.n_conv = n;
+    za.dbg = nullptr;
+    launch_convz(za, st);
+  }
+  else if (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) launch_conv2h(a, st);
+  else if (m->gemm_split == DBFR_GEMM_SPLIT_BF16 || m->gemm_split >= DBFR_GEMM_SPLIT_F16) launch_conv2r(a, st);   // (a launch holding a conv whose weights span more than two fp16 pieces hold: three bf16 pieces)
   else if (m->gemm_split) launch_conv2s(a, st);
   else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);
@@ -1014,6 +1144,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   for (int k = 0; k < N_SETS; ++k) ga.set[k] = w.set[k];
   ga.err = w.err; ga.step = step; ga.lds_nl = ga.lds_na = ga.n_chunk = 0;
   launch_edges(ga, false, st);
+  if (m->gemm_split == DBFR_GEMM_REDUCE_FIRST) launch_graph_chunks(ga, st);   // per-graph chunks of 32 edges for k_convz
   if (m->edge_log && step < m->edge_log_steps) launch_edge_log(ga, m->edge_log + (size_t)step * N_SETS * G, st);
   // ---- embeddings
   {
@@ -1048,13 +1179,17 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     float *lnew = w.lig_x[cur ^ 1], *anew = w.atom_x[cur ^ 1];
     const EdgeSet &LL = w.set[SET_LL], &AA = w.set[SET_AA], &AL = w.set[SET_AL], &LA = w.set[SET_LA];
     if (w.conv2 || l < m->conv2_layers) {   // all four convs of the layer in ONE persistent launch (conv2.hip)
+      const bool rf = m->gemm_split == DBFR_GEMM_REDUCE_FIRST && !((m->layer_fallback >> l) & 1u);
+      const ConvW2* L2 = rf ? m->layer2v[l] : m->layer2[l];
       const Conv2Desc ds[4] = {
-          conv2_desc(m->layer2[l][0], LL.n_edges, LL.cap, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0]),
-          conv2_desc(m->layer2[l][1], AL.n_edges, AL.cap, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[1]),
-          conv2_desc(m->layer2[l][2], AA.n_edges, AA.cap, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg[2]),
-          conv2_desc(m->layer2[l][3], LA.n_edges, LA.cap, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3])};
+          conv2_desc(L2[0], LL.n_edges, LL.cap, LL.gth, LL.emb, LL.sh, lx, Di, LL.tgt, lx, Di, LL.gth, lx, Di, w.msg[0]),
+          conv2_desc(L2[1], AL.n_edges, AL.cap, AL.gth, AL.emb, AL.sh, lx, Di, AL.tgt, ax, Di, AL.gth, ax, Di, w.msg[1]),
+          conv2_desc(L2[2], AA.n_edges, AA.cap, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg[2]),
+          conv2_desc(L2[3], LA.n_edges, LA.cap, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3])};
       const int Ws[4] = {m->layer[l][0].W, m->layer[l][1].W, m->layer[l][2].W, m->layer[l][3].W};
-      conv2_call(m, ds, Ws, 4, st, (m->layer_fallback >> l) & 1u);
+      const ConvZDesc zs[4] = {convz_desc(ds[0], m->layerz[l][0], LL.tgt, Do, LL.chunk0, LL.gedge0, G), convz_desc(ds[1], m->layerz[l][1], AL.tgt, Do, AL.chunk0, AL.gedge0, G),
+                               convz_desc(ds[2], m->layerz[l][2], AA.tgt, Do, AA.chunk0, AA.gedge0, G), convz_desc(ds[3], m->layerz[l][3], LA.tgt, Do, LA.chunk0, LA.gedge0, G)};
+      conv2_call(m, ds, Ws, 4, st, (m->layer_fallback >> l) & 1u, rf ? zs : nullptr);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
       for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
@@ -1150,7 +1285,8 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     const EdgeSet& T = w.set[SET_TOR];
     const EdgeSet& S = w.set[SET_SC];
     const bool do_t = B->NTOR > 0, do_s = !cfg.no_sc_torsion && B->NSC > 0;
-    Conv2Desc ds[2]; int Ws[2]; int nd = 0;
+    const bool rf = m->gemm_split == DBFR_GEMM_REDUCE_FIRST && !((m->layer_fallback >> 31) & 1u);
+    Conv2Desc ds[2]; ConvZDesc zs[2]; int Ws[2]; int nd = 0;
     if (do_t) {
       launch_bond_attr(lx, D, B->bond_src, B->bond_dst, B->tor_bond, 0, B->NTOR, w.tor_attr, st);
       MlpArgs a; memset(&a, 0, sizeof a);
@@ -1158,6 +1294,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_lig_off; a.gs_coeff = m->gs_lig_c; a.out = T.emb;
       launch_mlp(a, st);
       ds[nd] = conv2_desc(m->tor_conv2, T.n_edges, T.cap, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg[0]);
+      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->tor_convz, T.tgt, 2 * NS, T.chunk0, T.gedge0, G); }   // (all outputs of a torsion conv are scalars)
       Ws[nd++] = m->tor_conv.W;
     }
     if (do_s) {
@@ -1167,9 +1304,10 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_atom_off; a.gs_coeff = m->gs_atom_c; a.out = S.emb;
       launch_mlp(a, st);
       ds[nd] = conv2_desc(m->sc_conv2, S.n_edges, S.cap, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg[1]);
+      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->sc_convz, S.tgt, 2 * NS, S.chunk0, S.gedge0, G); }
       Ws[nd++] = m->sc_conv.W;
     }
-    if (nd) conv2_call(m, ds, Ws, nd, st, (m->layer_fallback >> 31) & 1u);
+    if (nd) conv2_call(m, ds, Ws, nd, st, (m->layer_fallback >> 31) & 1u, rf ? zs : nullptr);
     if (do_t) {
       launch_reduce_ln(w.msg[0], T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
       launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, st);
@@ -1450,9 +1588,13 @@ static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t fami
   if (conv2) {
     if (cw->K != 144) return fail(DBFR_ERR_ARG, "k_conv2 serves the K=144 convs");
     const ConvW2* cw2 = layer >= 0 ? &m->layer2[layer][family] : layer == -2 ? &m->tor_conv2 : &m->sc_conv2;
-    const Conv2Desc d = conv2_desc(*cw2, n_edges_dev, n_edges, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg);
+    const bool deep = cw2->f16_depth > f16_depth_ok();
+    const bool rf = m->gemm_split == DBFR_GEMM_REDUCE_FIRST && !deep;   // (the message buffer then holds segment sums in the segments' first rows: include/dbfr.h)
+    Conv2Desc d = conv2_desc(rf && layer >= 0 ? m->layer2v[layer][family] : *cw2, n_edges_dev, n_edges, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg);
+    if (rf && layer < 0) d.w.n_tiles = 0;
+    const ConvZDesc z = convz_desc(d, layer >= 0 ? m->layerz[layer][family] : layer == -2 ? m->tor_convz : m->sc_convz, tgt, cw->D_out);
     const int W = cw->W;
-    conv2_call(m, &d, &W, 1, (hipStream_t)hip_stream, cw2->f16_depth > f16_depth_ok());
+    conv2_call(m, &d, &W, 1, (hipStream_t)hip_stream, deep, rf ? &z : nullptr);
   } else {
     conv_call(m, *cw, n_edges_dev, n_edges, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg, (hipStream_t)hip_stream);
   }

@@ -114,6 +114,40 @@ struct Conv2Args {
 };
 #define C2_TRACE_CAP 4096
 
+// ---- reduce-first form of the SCALAR-OUTPUT paths of a K=144 conv (convz.hip, DBFR_GEMM_REDUCE_FIRST).
+// A message element of an l = 0 output irrep is  sum_c y[e,c] (sum_k W2'[c,k,w] h[e,k] + b2'[c,w])  with c running over the (path, u_in)
+// pairs into that irrep and y[e,c] = x[gth e, u] sh0[e] (scalar input) or xv[gth e, u] . sh1[e] (vector input): linear in y (x) h, and
+// the scatter over the edges of a target node is linear too, so Z[t,c,k] = sum_{e -> t} y[e,c] h'[e,k] (h' = [h | 1]) is formed first
+// and the big GEMM runs once per TARGET (segment of <= 32 edges), not once per edge.
+#define CZ_NKT 10         // k tiles of 16: 144 hidden units + the constant 1 that carries the bias (tile 9, column 0)
+#define CZ_MAXCT 12       // c tiles of 16 over both scalar output irreps (layer convs: 8, torsion convs: 10)
+#define CZ_TILE_BYTES 6144   // W2' of one (c tile, k tile, k-step): [3 w tiles][hi, lo][64 lanes][8 fp16]
+struct ConvZ {
+  int n_io;               // scalar output irreps of this conv (1 or 2)
+  int nct[2];             // c tiles per irrep
+  int ct0[2];             // first c tile of the irrep in cdesc / W2z
+  int out_off[2];         // message column of the irrep's channel 0 (48 channels each)
+  const uint32_t* cdesc;  // [n c tiles][16]: x offset (floats) | l_in << 12 | sh offset << 16 | valid << 31
+  const void* W2z;        // [c tile][k tile][8 k-steps][3 w tiles][hi, lo][64 lanes][8 fp16] x 2^s(w), s per output row
+  const float* rowinv;    // [n_io][48]: 2^-s(w)
+  const void* W1h; int k1;   // lin.0 as in ConvW2
+};
+struct ConvZDesc {
+  const int* n_edges; int max_edges;
+  const int* tgt;         // scatter target of every edge (edges sorted by target)
+  const int* gth;
+  const float* emb; const float* sh;
+  const float* tab1; int ld1; const int* idx1;
+  const float* tab2; int ld2; const int* idx2;
+  const float* x; int ldx;
+  ConvZ w;
+  float* msg; int D_out;
+  const int* chunk0;      // [n_graph + 1] first 32-edge chunk of every graph (chunks are cut per graph: batch-independent sums), or null: one graph
+  const int* gedge0;      // [n_graph + 1] first edge of every graph
+  int n_graph;
+};
+struct ConvZArgs { ConvZDesc c[4]; int n_conv; float* dbg; };   // dbg (developer, DBFR_CONVZ_DEBUG=<file>): workgroup 0 / wave 0 of the first unit dumps h [32 slots][144]
+
 static inline uint16_t dbfr_bf16_rne(float x) {   // round-to-nearest-even fp32 -> bf16 (finite inputs)
   uint32_t u;
   memcpy(&u, &x, 4);
@@ -148,6 +182,8 @@ struct EdgeSet {           // one per-step edge list, grouped (CSR) by scatter-t
   int* row_cnt;        // [n_targets]
   int* g_cnt;          // [G * n_chunk] per-(graph, target chunk) totals (count pass); n_chunk = dbfr_edge_chunks()
   int* g_base;         // [G * n_chunk] base offset of each chunk's first edge (scan)
+  int* chunk0;         // [G + 1] first 32-edge chunk of every graph (k_graph_chunks; chunks never straddle graphs: convz.hip)
+  int* gedge0;         // [G + 1] first edge of every graph
 };
 
 struct ConvArgs {

@@ -1,0 +1,474 @@
+// Reduce-first form of the SCALAR-OUTPUT tensor-product paths of a K = 144 conv (DBFR_GEMM_REDUCE_FIRST; replaces
+// tpscore.py:177-199 for the rows of lin.3 that feed an l = 0 output irrep -- 74 % of W at depth 3, all of W in the torsion convs).
+//
+// What the reference does per edge:  w[e] = W2 h[e] + b2  (144 x W),  m[e, o] = sum_u w[e, (p,u,o)] y_p[e,u]  with y_p[e,u] = x[gth e, u] sh0[e]
+// (scalar input) or xv[gth e, u] . sh1[e] (vector input), then out[t] = mean over the edges of target t.  For a scalar output the whole
+// chain is linear in y (x) h, so the order can be turned round:
+//     Z[t, c, k] = sum_{e -> t} y[e, c] h'[e, k]          (c = (path, u) pairs into the irrep, h' = [h | 1]: the 1 carries b2)
+//     out_sum[t, o] = sum_{c,k} Z[t, c, k] W2'[c, k, o]   (W2' = lin.3 rows x the folded path constant)
+// -- the 144 x W GEMM once per TARGET (segment of <= 32 edges), not once per edge: 8-10 x fewer matrix instructions at the 13-50 edges
+// per node of the pocket / ligand graphs.  The l = 1 outputs stay per edge (k_conv2h on a W2 without these rows): for them Z is three
+// times as large and the saving is nil.
+//
+// Both products run on v_mfma_f32_16x16x32_f16 with fp32 operands cut into two fp16 pieces / three partial products, as in conv2h.hip:
+//   * a wave owns a CHUNK of 32 consecutive edges of one graph (chunks are cut per graph, so what is summed with what never depends on
+//     batch mates); the maximal runs of one target inside the chunk are its SEGMENTS.  Hidden layer transposed, D[edge, unit] = A W1^T:
+//     the radial-MLP inputs are the A operand straight from memory, the W1h tiles of conv2h serve unchanged as B operand, and the result
+//     registers -- unit on the lane, eight edges in registers -- ARE the B operand of step A (contraction over the edges);
+//   * step A, per segment and 16 x 16 tile (c, k): Y masked to the segment's edges (A operand, built per c tile from gathered x rows and the
+//     harmonics) x H; the 16 x 16 block of Z goes, cut into pieces, to LDS in the layout step B reads (column = segment);
+//   * step B, per 256 Z values of every column: the eight waves take one k-step of 32 each, W2' fragments straight from L2 into registers
+//     (every wave another k-step: no LDS ring), columns = the up to 32 segments of the workgroup's eight chunks; partial sums over the
+//     k-steps are added across the waves once per output irrep.
+// Scaling (exact powers of two): inputs per edge, W1 per matrix (conv2h), h per chunk, y per chunk (bound from max |x| max |sh|), Z by the
+// constant 2^-20 (|Z| <= 32 x 2^15 x 2^15), W2' per output ROW (undone on the accumulator rows at the end: no row-depth limit).
+// The message interface is kept: the sum of a segment lands in the message row of the segment's FIRST edge, the scalar columns of its
+// other rows are zero -- k_reduce_ln[_layer] adds the rows of a node and divides by their number as before.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define CH_TILE_BYTES 9280          // W1h tile format of conv2h.hip
+#define CH_TAIL_OFF 8192
+#define CH_BIAS_OFF 9216
+
+#define CZ_COL 528                  // bytes per Z column and piece in LDS: 256 fp16 + 16 (16 columns -> 16 distinct 16-byte bank groups)
+#define CZ_PIECE (32 * CZ_COL)
+#define CZ_BUF (2 * CZ_PIECE)
+#define CZ_ZBYTES (2 * CZ_BUF)      // two buffers: step A of chunk i + 1 writes while step B of chunk i reads
+#define CZ_WAVE_FLOATS (32 * 12 + 32 + 32 + 32 + 32 + 32)   // harmonics [32][12] | sa | ua | gather row offsets | segment ids | first slot of segment j
+#define CZ_ZSCALE (-20)             // |Z| <= 32 edges x 2^15 x 2^15 = 2^35 -> 2^15
+
+__device__ __forceinline__ void cz_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f16x2 h = __builtin_convertvector((f32x2){x0, x1}, f16x2);
+  const f16x2 l = __builtin_convertvector((f32x2){x0 - (float)h[0], x1 - (float)h[1]}, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ float cz_wave_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
+  constexpr int KT = 9;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  char* zb = reinterpret_cast<char*>(lds);
+  float* wl = lds + CZ_ZBYTES / 4 + wave * CZ_WAVE_FLOATS;
+  float* w_sh = wl;                                         // [32][12]
+  float* w_sa = wl + 32 * 12;                               // [32] the edge's factor on its radial-MLP inputs
+  float* w_ua = w_sa + 32;                                  // [32] ... and its inverse
+  int* w_row = reinterpret_cast<int*>(w_ua + 32);           // [32] gth[e] * ldx
+  int* w_seg = w_row + 32;                                  // [32] segment of the slot, -1: no edge
+  int* w_first = w_seg + 32;                                // [32] first slot of segment j
+  int* b_nseg = reinterpret_cast<int*>(lds + CZ_ZBYTES / 4 + NW * CZ_WAVE_FLOATS);   // [NW]
+  int* b_col_edge = b_nseg + NW;                            // [32] message row of the column's segment, -1: column unused
+  float* b_col_inv = reinterpret_cast<float*>(b_col_edge + 32);   // [32] takes the chunk's factors off
+
+  // ---- unit list: NW chunks of 32 edges per unit, conv after conv
+  int nch[4] = {0, 0, 0, 0}, nu[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < a.n_conv) {
+      const ConvZDesc& d = a.c[c];
+      const int E = min(*d.n_edges, d.max_edges);
+      nch[c] = d.chunk0 ? d.chunk0[d.n_graph] : (E + 31) >> 5;
+      nu[c] = (nch[c] + NW - 1) / NW;
+    }
+  const int N = nu[0] + nu[1] + nu[2] + nu[3];
+  for (int unit = blockIdx.x; unit < N; unit += gridDim.x) {
+    int c = 0, ul = unit;
+    if (ul >= nu[0]) { ul -= nu[0]; c = 1; if (ul >= nu[1]) { ul -= nu[1]; c = 2; if (ul >= nu[2]) { ul -= nu[2]; c = 3; } } }
+    const ConvZDesc& d = a.c[c];
+    const ConvZ& W = d.w;
+    const int E = min(*d.n_edges, d.max_edges);
+    // ---- my chunk: edges [es, es + len)
+    const int ch = ul * NW + wave;
+    int es = 0, len = 0;
+    if (ch < nch[c]) {
+      if (d.chunk0) {
+        int lo = 0, hi = d.n_graph - 1;                      // the graph whose chunk range holds ch
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.chunk0[mid] <= ch) lo = mid; else hi = mid - 1; }
+        es = d.gedge0[lo] + 32 * (ch - d.chunk0[lo]);
+        len = min(32, d.gedge0[lo + 1] - es);
+      } else {
+        es = 32 * ch;
+        len = min(32, E - es);
+      }
+      len = max(len, 0);
+    }
+    __syncthreads();   // nothing of the last unit still reads the block-level arrays
+    // ---- slots: lanes 0..31 own slot L (clamped to the chunk's last edge beyond its length; a chunk without edges reads edge 0 of a non-empty conv or nothing)
+    const int sl = lane & 31;
+    const bool have = len > 0;
+    const int e_sl = have ? es + min(sl, len - 1) : 0;
+    int tgt_l = 0, gth_l = 0;
+    if (have) { tgt_l = d.tgt[e_sl]; gth_l = d.gth[e_sl]; }
+    const int tgt_prev = __shfl_up(tgt_l, 1);
+    const bool is_first = lane < 32 && sl < len && (sl == 0 || tgt_l != tgt_prev);
+    const unsigned long long bal = __ballot(is_first);
+    const unsigned firsts = (unsigned)bal;
+    const int nseg = __popc(firsts);
+    const int seg_l = (sl < len) ? __popc(firsts & (0xffffffffu >> (31 - sl))) - 1 : -1;
+    if (lane < 32) {
+      w_row[sl] = gth_l * d.ldx;
+      w_seg[sl] = seg_l;
+      if (is_first) w_first[seg_l] = sl;
+      const float* sp = d.sh + (size_t)e_sl * SH_LD;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) w_sh[sl * 12 + k] = have ? sp[k] : 0.f;
+    }
+    if (lane == 0) b_nseg[wave] = nseg;
+    // ---- zero the scalar columns of the message rows that are not the first of their segment
+    if (have) {
+      const unsigned rest = (len >= 32 ? 0xffffffffu : ((1u << len) - 1u)) & ~firsts;
+      const int per_row = 12 * W.n_io;                       // float4 stores per row
+      for (int s0 = 0; s0 < 32; s0 += 2) {
+        const int s = s0 + (lane >> 5), j = lane & 31;
+        if (((rest >> s) & 1u) && j < per_row) {
+          const int io = j / 12;
+          *reinterpret_cast<f32x4*>(d.msg + (size_t)(es + s) * d.D_out + W.out_off[io] + 4 * (j - 12 * io)) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    // ---- bounds for the y scale: largest |x| over the gathered rows, largest |harmonic|
+    float xmx = 0.f, smx = 0.f;
+    if (have) {
+      const float* xr = d.x + (size_t)gth_l * d.ldx;
+      const int d4 = d.ldx >> 2;
+      for (int j = lane >> 5; j < d4; j += 2) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+        xmx = fmaxf(fmaxf(xmx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
+      if (lane < 32) {
+        const float* sp = d.sh + (size_t)e_sl * SH_LD;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) smx = fmaxf(smx, fabsf(sp[k]));
+      }
+    }
+    xmx = cz_wave_max(xmx); smx = cz_wave_max(smx);
+    int ey = 0;                                              // y is multiplied by 2^ey: |y| <= 3 |x| |sh| < 2^(ex + es + 2) -> below 2^15
+    if (xmx > 0.f && smx > 0.f) ey = max(-100, min(100, 13 - __builtin_amdgcn_frexp_expf(xmx) - __builtin_amdgcn_frexp_expf(smx)));
+    const float sY = __builtin_amdgcn_ldexpf(1.f, ey);
+
+    // ---- hidden layer, transposed: D[edge, unit] = sum_f a[edge, f] W1[unit, f]; A = the edge's inputs (cut per edge), B = W1h tiles
+    u32x4 Hh[CZ_NKT][2];                                     // H pieces [k tile][hi, lo]: lane (unit n, group g), eight edges {4g..4g+3, 16+4g..16+4g+3}
+    int eh = 0;                                              // the factor on h is 2^(15 - ehc + k1) = phi, also what the constant 1 of the bias becomes
+    {
+      const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)W.W1h, 0, KT * CH_TILE_BYTES, 0x00020000);
+      u32x4 Ah[2][2][4];                                     // input pieces [edge tile][hi, lo][k-step of 32]
+      u32x4 Atc[2];                                          // last 16 k: [lo | hi]
+#pragma unroll
+      for (int et = 0; et < 2; ++et) {
+        const int slot = 16 * et + n;
+        const int e = have ? es + min(slot, len - 1) : 0;
+        const float* r0 = d.emb + (size_t)e * NS;
+        const float* r1 = d.tab1 + (size_t)(have ? d.idx1[e] : 0) * d.ld1;
+        const float* r2 = d.tab2 + (size_t)(have ? d.idx2[e] : 0) * d.ld2;
+        f32x4 Ba[KT];
+        float amx = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < KT; ++s4) {
+          const float* src = s4 < 3 ? r0 : s4 < 6 ? r1 : r2;
+          Ba[s4] = have ? *reinterpret_cast<const f32x4*>(src + 16 * (s4 % 3) + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) amx = fmaxf(amx, fabsf(Ba[s4][q]));
+        }
+        amx = fmaxf(amx, __shfl_xor(amx, 16));
+        amx = fmaxf(amx, __shfl_xor(amx, 32));
+        const int ja = max(-14, __builtin_amdgcn_frexp_expf(amx));
+        const float sa = __builtin_amdgcn_ldexpf(1.f, 15 - ja);
+        if (g == 0) { w_sa[slot] = sa; w_ua[slot] = __builtin_amdgcn_ldexpf(1.f, ja - 15); }
+#pragma unroll
+        for (int s4 = 0; s4 < KT; ++s4) {
+          unsigned hi0, lo0, hi1, lo1;
+          cz_split2(Ba[s4][0] * sa, Ba[s4][1] * sa, hi0, lo0);
+          cz_split2(Ba[s4][2] * sa, Ba[s4][3] * sa, hi1, lo1);
+          if (s4 < 8) {
+            Ah[et][0][s4 >> 1][2 * (s4 & 1)] = hi0; Ah[et][0][s4 >> 1][2 * (s4 & 1) + 1] = hi1;
+            Ah[et][1][s4 >> 1][2 * (s4 & 1)] = lo0; Ah[et][1][s4 >> 1][2 * (s4 & 1) + 1] = lo1;
+          } else {
+            Atc[et] = (u32x4){lo0, lo1, hi0, hi1};
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // my rows of a result tile are the edges 16 et + 4 g + q: their factors
+      f32x4 sar[2], uar[2];
+#pragma unroll
+      for (int et = 0; et < 2; ++et) {
+        sar[et] = *reinterpret_cast<const f32x4*>(w_sa + 16 * et + 4 * g);
+        uar[et] = *reinterpret_cast<const f32x4*>(w_ua + 16 * et + 4 * g);
+      }
+      float Hf[KT][2][4];
+      float hmx = 0.f;
+      const int vW = lane * 16;
+#pragma unroll
+      for (int m = 0; m < KT; ++m) {
+        const float bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW1, n * 4, m * CH_TILE_BYTES + CH_BIAS_OFF, 0));
+        f32x4 acc[2];
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[et][q] = bias * sar[et][q];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const f16x8 whi = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + s * 1024, 0));
+          const f16x8 wlo = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + (4 + s) * 1024, 0));
+#pragma unroll
+          for (int et = 0; et < 2; ++et) {
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][1][s]), whi, acc[et], 0, 0, 0);
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][0][s]), wlo, acc[et], 0, 0, 0);
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][0][s]), whi, acc[et], 0, 0, 0);
+          }
+        }
+        {   // k = 128..143: W tail fragment = [hi (4) | lo (4)], input tail = [lo | hi]: one x32 MFMA carries both small products
+          const u32x4 wt = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + CH_TAIL_OFF, 0));
+          // (the large product on the x32 instruction too, upper half of the operands zero: an x16 MFMA that takes as SrcC an accumulator an
+          // x32 MFMA has just written reads stale data on MI355X + ROCm 7.2 -- conv2r.hip -- and 18 half-empty MFMAs per chunk cost nothing)
+          const f16x8 wf = __builtin_bit_cast(f16x8, wt);
+          const f16x8 wh = __builtin_bit_cast(f16x8, (u32x4){wt[0], wt[1], 0u, 0u});
+#pragma unroll
+          for (int et = 0; et < 2; ++et) {
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Atc[et]), wf, acc[et], 0, 0, 0);
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (u32x4){Atc[et][2], Atc[et][3], 0u, 0u}), wh, acc[et], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float v = fmaxf(acc[et][q], 0.f) * uar[et][q];   // = 2^k1 h
+            Hf[m][et][q] = v;
+            hmx = fmaxf(hmx, v);
+          }
+      }
+      if (a.dbg && unit == 0 && wave == 0) {
+        const float k1i = __builtin_amdgcn_ldexpf(1.f, -W.k1);
+#pragma unroll
+        for (int m = 0; m < KT; ++m)
+#pragma unroll
+          for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.dbg[(16 * et + 4 * g + q) * 144 + 16 * m + n] = Hf[m][et][q] * k1i;
+      }
+      hmx = cz_wave_max(hmx);
+      // 2^k1 h < 2^eh; the factor 2^(15 - ehc) on it makes phi = 2^(15 - ehc + k1) on h: ehc >= k1 keeps phi, the image of the bias's 1, inside fp16
+      eh = max(hmx > 0.f ? __builtin_amdgcn_frexp_expf(hmx) : W.k1, W.k1);
+      eh = min(eh, W.k1 + 100);
+      const float sH = __builtin_amdgcn_ldexpf(1.f, 15 - eh);
+#pragma unroll
+      for (int m = 0; m < KT; ++m) {
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        cz_split2(Hf[m][0][0] * sH, Hf[m][0][1] * sH, h0, l0);
+        cz_split2(Hf[m][0][2] * sH, Hf[m][0][3] * sH, h1, l1);
+        cz_split2(Hf[m][1][0] * sH, Hf[m][1][1] * sH, h2, l2);
+        cz_split2(Hf[m][1][2] * sH, Hf[m][1][3] * sH, h3, l3);
+        Hh[m][0] = (u32x4){h0, h1, h2, h3};
+        Hh[m][1] = (u32x4){l0, l1, l2, l3};
+      }
+    }
+    const int ephi = 15 - eh + W.k1;                         // log2 of the factor on h
+    {   // k tile 9: the constant 1 (x phi) of the bias in column 0, for the slots that hold an edge
+      const _Float16 ph = (_Float16)__builtin_amdgcn_ldexpf(1.f, ephi);
+      const unsigned short pb = __builtin_bit_cast(unsigned short, ph);
+      u32x4 hb = {0u, 0u, 0u, 0u};
+      if (n == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
+          if (slot < len) hb[t >> 1] |= (unsigned)pb << (16 * (t & 1));
+        }
+      }
+      Hh[KT][0] = hb;
+      Hh[KT][1] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- my eight slots (registers of the A operand of step A): gather rows, segments
+    int xrow[8], sg[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
+      xrow[t] = w_row[slot];
+      sg[t] = w_seg[slot];
+    }
+    __syncthreads();
+    int maxseg = 0;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) maxseg = max(maxseg, b_nseg[v]);
+    const int npass = (maxseg + 3) >> 2;
+    const float col_inv = __builtin_amdgcn_ldexpf(1.f, -CZ_ZSCALE - ey - ephi);
+
+    for (int pass = 0; pass < npass; ++pass) {
+      int pmax = 0;
+#pragma unroll
+      for (int v = 0; v < NW; ++v) pmax = max(pmax, min(4, b_nseg[v] - 4 * pass));
+      const int ncb = pmax <= 2 ? 1 : 2;                     // column blocks of 16 in step B
+      const int cpw = ncb == 2 ? 4 : 2;                      // columns per wave
+      const int my_n = max(0, min(4, nseg - 4 * pass));
+      __syncthreads();                                       // (the last pass's epilogue has read the column arrays)
+      if (lane < cpw) {
+        const int col = cpw * wave + lane;
+        const bool used = lane < my_n;
+        b_col_edge[col] = used ? es + w_first[4 * pass + lane] : -1;
+        b_col_inv[col] = col_inv;
+      }
+      // masks of my (up to four) segments on the registers of the A operand: halves of a dword = two consecutive slots
+      u32x4 mk[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          mk[jj][r] = (sg[2 * r] == 4 * pass + jj ? 0x0000ffffu : 0u) | (sg[2 * r + 1] == 4 * pass + jj ? 0xffff0000u : 0u);
+
+      for (int io = 0; io < W.n_io; ++io) {
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[wt][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* wbase = reinterpret_cast<const char*>(W.W2z) + (size_t)lane * 16;
+        int gq = W.ct0[io] * CZ_NKT;                         // running (c tile, k tile) index into W2z
+        const int gq_last = (W.ct0[io] + W.nct[io]) * CZ_NKT - 1;
+        u32x4 Wf[3][2];
+        auto fetchW = [&](int q) {
+          const char* p = wbase + ((size_t)q * 8 + wave) * CZ_TILE_BYTES;
+#pragma unroll
+          for (int wt = 0; wt < 3; ++wt)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) Wf[wt][pc] = *reinterpret_cast<const u32x4*>(p + (wt * 2 + pc) * 1024);
+        };
+        fetchW(gq);
+        for (int ct = 0; ct < W.nct[io]; ++ct) {
+          // ---- Y of this c tile: lane (c = n, group g), my eight slots
+          const unsigned cd = W.cdesc[(W.ct0[io] + ct) * 16 + n];
+          const unsigned cd0 = __builtin_amdgcn_readfirstlane(W.cdesc[(W.ct0[io] + ct) * 16]);
+          const int xo = cd & 0xfff, so = (cd >> 16) & 15;
+          const float yv = (cd >> 31) ? sY : 0.f;            // (padding columns: zero)
+          float y[8];
+          if (((cd0 >> 12) & 1u) == 0) {                     // scalar inputs: x[u] sh0
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
+              y[t] = d.x[xrow[t] + xo] * w_sh[slot * 12 + so] * yv;
+            }
+          } else {                                           // vector inputs: xv[u] . sh1
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
+              const float* xp = d.x + xrow[t] + xo;
+              const float* sp = w_sh + slot * 12 + so;
+              y[t] = (xp[0] * sp[0] + xp[1] * sp[1] + xp[2] * sp[2]) * yv;
+            }
+          }
+          u32x4 Yh, Yl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { unsigned hi, lo; cz_split2(y[2 * r], y[2 * r + 1], hi, lo); Yh[r] = hi; Yl[r] = lo; }
+          u32x4 Ym[4][2];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { Ym[jj][0] = Yh & mk[jj]; Ym[jj][1] = Yl & mk[jj]; }
+          const float zs = __builtin_amdgcn_ldexpf(1.f, CZ_ZSCALE);
+#pragma unroll
+          for (int kt = 0; kt < CZ_NKT; ++kt) {
+            char* zw = zb + (gq & 1) * CZ_BUF + (n * 16 + 4 * g) * 2;
+            // ---- step A: Z[c, k] of my segments, cut into pieces, to LDS
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              if (jj < my_n) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ym[jj][0]), __builtin_bit_cast(f16x8, Hh[kt][1]), zero, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ym[jj][1]), __builtin_bit_cast(f16x8, Hh[kt][0]), z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ym[jj][0]), __builtin_bit_cast(f16x8, Hh[kt][0]), z, 0, 0, 0);
+                unsigned zh0, zl0, zh1, zl1;
+                cz_split2(z[0] * zs, z[1] * zs, zh0, zl0);
+                cz_split2(z[2] * zs, z[3] * zs, zh1, zl1);
+                char* p = zw + (cpw * wave + jj) * CZ_COL;
+                *reinterpret_cast<u32x2*>(p) = (u32x2){zh0, zh1};
+                *reinterpret_cast<u32x2*>(p + CZ_PIECE) = (u32x2){zl0, zl1};
+              }
+            }
+            __syncthreads();
+            // ---- step B: my k-step of this (c, k) tile against W2', every column block
+            if (kt < KT || wave == 0) {                      // (k tile 9 holds the bias row only: k-step 0)
+              const char* zr = zb + (gq & 1) * CZ_BUF + n * CZ_COL + (32 * wave + 8 * g) * 2;
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                if (cb < ncb) {
+                  const f16x8 zh = *reinterpret_cast<const f16x8*>(zr + cb * 16 * CZ_COL);
+                  const f16x8 zl = *reinterpret_cast<const f16x8*>(zr + cb * 16 * CZ_COL + CZ_PIECE);
+#pragma unroll
+                  for (int wt = 0; wt < 3; ++wt) {
+                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[wt][0]), zl, acc[wt][cb], 0, 0, 0);
+                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[wt][1]), zh, acc[wt][cb], 0, 0, 0);
+                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[wt][0]), zh, acc[wt][cb], 0, 0, 0);
+                  }
+                }
+              }
+            }
+            ++gq;
+            fetchW(min(gq, gq_last));
+          }
+        }
+        // ---- the output irrep is complete: add the eight waves' partial sums, take the factors off, store into the segments' first rows
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(zb) + wave * (24 * 64);
+#pragma unroll
+        for (int wt = 0; wt < 3; ++wt)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[((wt * 2 + cb) * 4 + q) * 64 + lane] = acc[wt][cb][q];
+        __syncthreads();
+        for (int idx = tid; idx < 16 * ncb * 48; idx += 64 * NW) {
+          const int col = idx / 48, w = idx - 48 * col;
+          const int e = b_col_edge[col];
+          if (e >= 0) {
+            const int r = w & 15;
+            const float* rp = reinterpret_cast<const float*>(zb) + (((w >> 4) * 2 + (col >> 4)) * 4 + (r & 3)) * 64 + 16 * (r >> 2) + (col & 15);
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < NW; ++v) s += rp[v * (24 * 64)];
+            d.msg[(size_t)e * d.D_out + W.out_off[io] + w] = s * b_col_inv[col] * W.rowinv[io * 48 + w];
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+size_t convz_lds_bytes() { return CZ_ZBYTES + 8 * CZ_WAVE_FLOATS * sizeof(float) + (8 + 32 + 32) * sizeof(int); }
+
+void launch_convz(const ConvZArgs& a0, hipStream_t st) {
+  constexpr int NW = 8;
+  ConvZArgs a = a0;
+  static float* dbg_dev = nullptr;
+  static const char* dbg_file = getenv("DBFR_CONVZ_DEBUG");
+  if (dbg_file && !dbg_dev) {
+    if (hipMalloc(&dbg_dev, 32 * 144 * sizeof(float)) != hipSuccess) dbg_dev = nullptr;
+    else atexit([] {
+      std::vector<float> h(32 * 144);
+      if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), dbg_dev, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        if (FILE* f = fopen(getenv("DBFR_CONVZ_DEBUG"), "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+    });
+  }
+  a.dbg = dbg_dev;
+  const size_t lds = convz_lds_bytes();
+  if (dbfr_launch_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convz<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        "k_convz: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return;
+  hipLaunchKernelGGL((k_convz<NW>), dim3(dbfr_current_cu_count()), dim3(64 * NW), lds, st, a);
+}

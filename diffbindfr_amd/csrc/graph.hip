@@ -418,6 +418,45 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
   }
 }
 
+// Per-graph chunks of 32 edges for the reduce-first conv (convz.hip): gedge0[g] = first edge of graph g in the set, chunk0[g] = number of chunks of
+// the graphs before it (a chunk never holds edges of two graphs, so which edges are summed together does not depend on batch mates).  One block per set.
+__global__ __launch_bounds__(256) void k_graph_chunks(GraphArgs A) {
+  __shared__ int sc[256];
+  const EdgeSet& S = A.set[blockIdx.x];
+  const int G = A.b.G;
+  if (S.cap == 0) { for (int g = threadIdx.x; g <= G; g += 256) { S.chunk0[g] = 0; S.gedge0[g] = 0; } return; }
+  const int E = min(*S.n_edges, S.cap);
+  int running = 0;
+  for (int g0 = 0; g0 < G; g0 += 256) {
+    const int g = g0 + threadIdx.x;
+    int lo = 0, v = 0;
+    if (g < G) {
+      lo = min(S.g_base[g * A.n_chunk], E);
+      const int hi = g + 1 < G ? min(S.g_base[(g + 1) * A.n_chunk], E) : E;
+      v = (hi - lo + 31) >> 5;
+      S.gedge0[g] = lo;
+    }
+    sc[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int w = threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+      __syncthreads();
+      sc[threadIdx.x] += w;
+      __syncthreads();
+    }
+    if (g < G) S.chunk0[g] = running + sc[threadIdx.x] - v;
+    running += sc[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { S.chunk0[G] = running; S.gedge0[G] = E; }
+}
+
+void launch_graph_chunks(const GraphArgs& A0, hipStream_t st) {
+  GraphArgs A = A0;
+  A.n_chunk = edge_chunks_of(A.b);
+  hipLaunchKernelGGL(k_graph_chunks, dim3(N_SETS), dim3(256), 0, st, A);
+}
+
 // dbfr_model_set_edge_log: per-graph edge counts of this step, log[k * G + g] = sum over the graph's target chunks
 __global__ void k_edge_log(GraphArgs A, int* log) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;

@@ -102,7 +102,7 @@ def conv_paths(kind):
     return wn.value, [list(tab[10 * i:10 * i + 10]) for i in range(n)]
 
 
-GEMM_MODES = {"f32": 0, "split": 1, "split_l1": 2, "split_f16": 3}     # include/dbfr.h: DBFR_GEMM_*
+GEMM_MODES = {"f32": 0, "split": 1, "split_l1": 2, "split_f16": 3, "reduce_first": 4}     # include/dbfr.h: DBFR_GEMM_*
 
 
 @INTERACTION.register_module(name=["TensorProductModelHIP"])

@@ -421,6 +421,7 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 #define DBFR_GEMM_SPLIT_BF16 1
 #define DBFR_GEMM_SPLIT_BF16_L1 2
 #define DBFR_GEMM_SPLIT_F16 3
+#define DBFR_GEMM_REDUCE_FIRST 4
 #define DBFR_GEMM_DEFAULT DBFR_GEMM_SPLIT_F16
 int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
 /* DBFR_GEMM_SPLIT_F16 holds a weight row to 22 significant bits while the row's largest |w| is within 2^17 of the largest |w| of its
