@@ -43,6 +43,10 @@ from diffbindfr_amd.packing import PackedBatch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact fp32
+PIPE_RF = dict(kernel="k_convz + k_conv2h (one launch pair per interaction layer / for the two torsion heads): the rows of lin.3 that feed a scalar output "
+                      "irrep reduce-first (Z = sum over a target's edges of y (x) h, then the 144 x W GEMM once per target segment), the vector-output rows per edge",
+               instruction="v_mfma_f32_16x16x32_f16", products=3, peak=2500.0, hidden_on_pipe=True, sustained=1937.0,
+               arithmetic="three fp16 x fp16 partial products per fp32 product (two fp16 pieces per operand, exact power-of-two scalings), fp32 accumulation")
 PMC_FILE = {"f32": "profiles/r2_pmc_k_conv.json", "split": "profiles/r2_pmc_k_conv2r.json", "split_l1": "profiles/r2_pmc_k_conv2s.json",
             "split_f16": "profiles/r4_pmc_k_conv2h.json"}
 PMC_FILE_CFG5 = {"split_f16": "profiles/r4_cfg5_pmc_k_conv2h.json"}
@@ -185,7 +189,7 @@ def cpu_baseline(cfg_id, samp, dev, n_poses=1, batched=(2, 2), batched_steps=5):
     return out
 
 
-PMC_KERNEL = {"split_f16": "k_conv2h", "split": "k_conv2r", "split_l1": "k_conv2s"}
+PMC_KERNEL = {"split_f16": "k_conv2h", "split": "k_conv2r", "split_l1": "k_conv2s", "reduce_first": "k_conv"}
 
 
 def measure_traffic(mode, args):
@@ -494,7 +498,7 @@ def main():
         fb = C.c_double()
         L.check(lib.dbfr_profile_fused_bytes(h, C.byref(fb)))
         alg = fl.value / (ms.value * 1e-3) / 1e12            # algorithmic fp32 flops 2*144*(144+W) per edge / kernel time
-        P = PIPE[mode]
+        P = PIPE_RF if mode == "reduce_first" else PIPE[mode]
         # what the named matrix instruction executes: `products` MFMA-flops per algorithmic flop of the 144 x W GEMM (97.6 % of the
         # conv's flops); in k_conv2r / k_conv2s the 144 x 144 hidden layer stays on the fp32 instruction inside the same kernel and is
         # not counted, k_conv2h runs it on the same three-product form (W1h tiles)
@@ -508,7 +512,7 @@ def main():
                     "(separate passes, counters only), per launch of this kernel; traffic = 2 x FETCH_SIZE (gfx950 correction for 16-byte-per-"
                     "lane reads, MI355X_MICROARCH.md) + WRITE_SIZE")
         else:
-            pmc_rel = PMC_FILE[mode] if args.config == 2 else PMC_FILE_CFG5.get(mode) if args.config == 5 else None
+            pmc_rel = PMC_FILE.get(mode) if args.config == 2 else PMC_FILE_CFG5.get(mode) if args.config == 5 else None
             pmc = os.path.join(ROOT, pmc_rel) if pmc_rel else None
             if pmc and os.path.exists(pmc) and args.batch_poses == 640:
                 pj = json.load(open(pmc))     # separate rocprofv3 --pmc passes (tools/prof_r3.sh), NOT measured in this run
@@ -583,7 +587,7 @@ def main():
                        "edges_last_step": {"lig": counters[0], "atom": counters[1], "cross": counters[2],
                                            "center": counters[3], "tor": counters[4], "sc_tor": counters[5]},
                        "weights": "seeded random init of the reference architecture (22.9 M params)",
-                       "arithmetic": "fp32 in, fp32 out; radial MLP's 144 x W GEMM: " + PIPE[mode]["arithmetic"],
+                       "arithmetic": "fp32 in, fp32 out; radial MLP's 144 x W GEMM: " + (PIPE_RF if mode == "reduce_first" else PIPE[mode])["arithmetic"],
                        "parallelism": f"dp{world}: jobs LPT-sharded, poses of a job on one GPU, ragged [ligand | atom14] records gathered at the end "
                                       f"(all_gather_into_tensor in windows of 256 MiB per rank)",
                        "dist_backend": (ddist.dist.get_backend() if ddist.dist.is_initialized() else None),

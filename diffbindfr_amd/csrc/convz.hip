@@ -42,11 +42,18 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define CH_TAIL_OFF 8192
 #define CH_BIAS_OFF 9216
 
-#define CZ_COL 528                  // bytes per Z column and piece in LDS: 256 fp16 + 16 (16 columns -> 16 distinct 16-byte bank groups)
-#define CZ_PIECE (32 * CZ_COL)
-#define CZ_BUF (2 * CZ_PIECE)
-#define CZ_ZBYTES (2 * CZ_BUF)      // two buffers: step A of chunk i + 1 writes while step B of chunk i reads
-#define CZ_WAVE_FLOATS (32 * 12 + 32 + 32 + 32 + 32 + 32)   // harmonics [32][12] | sa | ua | gather row offsets | segment ids | first slot of segment j
+// Z in LDS, per buffer: [k tile of the pair][piece][column block][k-step v: 1040 B][lane group g'': 256 B][column: 16 B][8 fp16].  Step B reads, for its
+// k-step, 16 B per lane with the columns contiguous; step A writes 8 B per lane (k_local = 2 v + h -> second half of the 16 B, c_local = 4 g'' + q) with the
+// 16 lanes of a write spread over the k-steps: the 1040-byte stride (4 dwords mod 32 banks) makes both conflict-free.
+#define CZ_VSTRIDE 1040
+#define CZ_CB (8 * CZ_VSTRIDE)      // one column block of one piece
+#define CZ_NCB 3                    // column blocks of 16 per pass: the segments of the workgroup's eight chunks take consecutive columns
+#define CZ_PIECE (CZ_NCB * CZ_CB)
+#define CZ_TILE (2 * CZ_PIECE)      // one (c, k) tile: both pieces, all column blocks
+#define CZ_KPB 1                    // k tiles per barrier
+#define CZ_BUF (CZ_KPB * CZ_TILE)
+#define CZ_ZBYTES (2 * CZ_BUF)      // two buffers: step A of the next tile writes while step B of this one reads
+#define CZ_WAVE_FLOATS (32 * 12 + 32 + 32 + 32 + 32 + 32 + 32 * 16)   // harmonics [32][12] | sa | ua | gather row offsets | segment ids | first slot of segment j | masks [32 segments][4 lane groups][4 dwords]
 #define CZ_ZSCALE (-20)             // |Z| <= 32 edges x 2^15 x 2^15 = 2^35 -> 2^15
 
 __device__ __forceinline__ void cz_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -61,7 +68,12 @@ __device__ __forceinline__ float cz_wave_max(float v) {
   return v;
 }
 
-template <int NW>
+template <int I, int N, typename F>
+__device__ __forceinline__ void cz_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); cz_static_for<I + 1, N>(f); }
+}
+
+template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no W2' fetch beyond the first tile, 2 no barriers in the tile loop, 4 no step A, 8 no step B, 16 no y gathers, 32 prologue only
 __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
   constexpr int KT = 9;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -75,9 +87,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
   int* w_row = reinterpret_cast<int*>(w_ua + 32);           // [32] gth[e] * ldx
   int* w_seg = w_row + 32;                                  // [32] segment of the slot, -1: no edge
   int* w_first = w_seg + 32;                                // [32] first slot of segment j
+  unsigned* w_mask = reinterpret_cast<unsigned*>(w_first + 32);   // [32][4][4] segment j's mask on the A-operand registers of lane group g
   int* b_nseg = reinterpret_cast<int*>(lds + CZ_ZBYTES / 4 + NW * CZ_WAVE_FLOATS);   // [NW]
-  int* b_col_edge = b_nseg + NW;                            // [32] message row of the column's segment, -1: column unused
-  float* b_col_inv = reinterpret_cast<float*>(b_col_edge + 32);   // [32] takes the chunk's factors off
+  int* b_col_edge = b_nseg + NW;                            // [48] message row of the column's segment, -1: column unused
+  float* b_col_inv = reinterpret_cast<float*>(b_col_edge + 16 * CZ_NCB);   // [48] takes the chunk's factors off
 
   // ---- unit list: NW chunks of 32 edges per unit, conv after conv
   int nch[4] = {0, 0, 0, 0}, nu[4] = {0, 0, 0, 0};
@@ -297,151 +310,192 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       Hh[KT][0] = hb;
       Hh[KT][1] = (u32x4){0u, 0u, 0u, 0u};
     }
-    __builtin_amdgcn_wave_barrier();
-    // ---- my eight slots (registers of the A operand of step A): gather rows, segments
-    int xrow[8], sg[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
-      xrow[t] = w_row[slot];
-      sg[t] = w_seg[slot];
+    // ---- masks of my segments on the registers of the A operand (halves of a dword = two consecutive slots), for every lane group
+    for (int idx = lane; idx < nseg * 16; idx += 64) {
+      const int j = idx >> 4, gg = (idx >> 2) & 3, r = idx & 3, t0 = 2 * r;
+      const int s0 = t0 < 4 ? 4 * gg + t0 : 16 + 4 * gg + (t0 - 4);
+      w_mask[idx] = (w_seg[s0] == j ? 0x0000ffffu : 0u) | (w_seg[s0 + 1] == j ? 0xffff0000u : 0u);
     }
+    __builtin_amdgcn_wave_barrier();
     __syncthreads();
-    int maxseg = 0;
+    // ---- columns: the segments of the eight chunks side by side, 48 per pass
+    int cbase = 0, total = 0;
 #pragma unroll
-    for (int v = 0; v < NW; ++v) maxseg = max(maxseg, b_nseg[v]);
-    const int npass = (maxseg + 3) >> 2;
+    for (int v = 0; v < NW; ++v) { const int c = b_nseg[v]; if (v < wave) cbase += c; total += c; }
+    cbase = __builtin_amdgcn_readfirstlane(cbase); total = __builtin_amdgcn_readfirstlane(total);   // (wave-uniform: scalar loop bounds below)
+    const int nseg_u = __builtin_amdgcn_readfirstlane(nseg);
+    const int npass = (total + 16 * CZ_NCB - 1) / (16 * CZ_NCB);
     const float col_inv = __builtin_amdgcn_ldexpf(1.f, -CZ_ZSCALE - ey - ephi);
-
+    const float zs = __builtin_amdgcn_ldexpf(1.f, CZ_ZSCALE);
+    if (ABL & 32) continue;
     for (int pass = 0; pass < npass; ++pass) {
-      int pmax = 0;
-#pragma unroll
-      for (int v = 0; v < NW; ++v) pmax = max(pmax, min(4, b_nseg[v] - 4 * pass));
-      const int ncb = pmax <= 2 ? 1 : 2;                     // column blocks of 16 in step B
-      const int cpw = ncb == 2 ? 4 : 2;                      // columns per wave
-      const int my_n = max(0, min(4, nseg - 4 * pass));
+      const int c_lo = 16 * CZ_NCB * pass;
+      const int ncb = min(CZ_NCB, (total - c_lo + 15) >> 4);   // column blocks of 16 in step B
+      const int j0 = max(0, c_lo - cbase), j1 = min(nseg_u, c_lo + 16 * CZ_NCB - cbase);   // my segments of this pass: columns cbase + j - c_lo
       __syncthreads();                                       // (the last pass's epilogue has read the column arrays)
-      if (lane < cpw) {
-        const int col = cpw * wave + lane;
-        const bool used = lane < my_n;
-        b_col_edge[col] = used ? es + w_first[4 * pass + lane] : -1;
-        b_col_inv[col] = col_inv;
+      for (int c = tid; c < 16 * CZ_NCB; c += 64 * NW) b_col_edge[c] = -1;
+      __syncthreads();
+      for (int j = j0 + lane; j < j1; j += 64) {
+        b_col_edge[cbase + j - c_lo] = es + w_first[j];
+        b_col_inv[cbase + j - c_lo] = col_inv;
       }
-      // masks of my (up to four) segments on the registers of the A operand: halves of a dword = two consecutive slots
-      u32x4 mk[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          mk[jj][r] = (sg[2 * r] == 4 * pass + jj ? 0x0000ffffu : 0u) | (sg[2 * r + 1] == 4 * pass + jj ? 0xffff0000u : 0u);
-
       for (int io = 0; io < W.n_io; ++io) {
-        f32x4 acc[3][2];
+        f32x4 acc[3][CZ_NCB];
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) acc[wt][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int cb = 0; cb < CZ_NCB; ++cb) acc[wt][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const char* wbase = reinterpret_cast<const char*>(W.W2z) + (size_t)lane * 16;
         int gq = W.ct0[io] * CZ_NKT;                         // running (c tile, k tile) index into W2z
         const int gq_last = (W.ct0[io] + W.nct[io]) * CZ_NKT - 1;
-        u32x4 Wf[3][2];
-        auto fetchW = [&](int q) {
+        u32x4 Wf[2][3][2];                                   // W2' fragments of my k-step: [tile parity][w tile][hi, lo], fetched one whole tile ahead
+        auto fetchW = [&](auto par_c, int q, bool bias_tile) {
+          constexpr int par = decltype(par_c)::value;
+          if ((ABL & 1) && q != W.ct0[io] * CZ_NKT) return;
+          // (no branch around these loads, not even for the k tile 9 whose fragments only wave 0 uses: behind a conditional fetch hipcc's wait-count
+          // pass assumes the loads were NOT issued and makes step B wait for vmcnt(0), i.e. for the fragments requested a moment ago)
+          (void)bias_tile;
           const char* p = wbase + ((size_t)q * 8 + wave) * CZ_TILE_BYTES;
 #pragma unroll
           for (int wt = 0; wt < 3; ++wt)
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) Wf[wt][pc] = *reinterpret_cast<const u32x4*>(p + (wt * 2 + pc) * 1024);
+            for (int pc = 0; pc < 2; ++pc) Wf[par][wt][pc] = *reinterpret_cast<const u32x4*>(p + (wt * 2 + pc) * 1024);
         };
-        fetchW(gq);
-        for (int ct = 0; ct < W.nct[io]; ++ct) {
-          // ---- Y of this c tile: lane (c = n, group g), my eight slots
-          const unsigned cd = W.cdesc[(W.ct0[io] + ct) * 16 + n];
-          const unsigned cd0 = __builtin_amdgcn_readfirstlane(W.cdesc[(W.ct0[io] + ct) * 16]);
-          const int xo = cd & 0xfff, so = (cd >> 16) & 15;
-          const float yv = (cd >> 31) ? sY : 0.f;            // (padding columns: zero)
+        u32x4 Yh = {0u, 0u, 0u, 0u}, Yl = {0u, 0u, 0u, 0u};   // Y pieces of the current c tile (masked per segment where they are used)
+        // Y of a c tile: lane (c = n, group g), my eight slots.  The gathers of a scalar-input tile are requested several tiles before they are
+        // used (load_x -> finish_Y); the one vector-input tile per irrep is gathered where it is needed.
+        float xv[8];
+        unsigned cd_n = 0, cd_0 = 0;
+        auto load_x = [&](int ct) {
+          if (j1 <= j0 || (ABL & 16)) return;
+          cd_n = W.cdesc[(W.ct0[io] + ct) * 16 + n];
+          cd_0 = __builtin_amdgcn_readfirstlane(W.cdesc[(W.ct0[io] + ct) * 16]);
+          if (((cd_0 >> 12) & 1u) == 0) {
+            const int xo = cd_n & 0xfff;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xv[t] = d.x[w_row[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)] + xo];
+          }
+        };
+        auto finish_Y = [&]() {
+          if (j1 <= j0 || (ABL & 16)) return;
+          const int xo = cd_n & 0xfff, so = (cd_n >> 16) & 15;
+          const float yv = (cd_n >> 31) ? sY : 0.f;          // (padding columns: zero)
           float y[8];
-          if (((cd0 >> 12) & 1u) == 0) {                     // scalar inputs: x[u] sh0
+          if (((cd_0 >> 12) & 1u) == 0) {                    // scalar inputs: x[u] sh0
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
               const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
-              y[t] = d.x[xrow[t] + xo] * w_sh[slot * 12 + so] * yv;
+              y[t] = xv[t] * w_sh[slot * 12 + so] * yv;
             }
           } else {                                           // vector inputs: xv[u] . sh1
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
               const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
-              const float* xp = d.x + xrow[t] + xo;
+              const float* xp = d.x + w_row[slot] + xo;
               const float* sp = w_sh + slot * 12 + so;
               y[t] = (xp[0] * sp[0] + xp[1] * sp[1] + xp[2] * sp[2]) * yv;
             }
           }
-          u32x4 Yh, Yl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) { unsigned hi, lo; cz_split2(y[2 * r], y[2 * r + 1], hi, lo); Yh[r] = hi; Yl[r] = lo; }
-          u32x4 Ym[4][2];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) { Ym[jj][0] = Yh & mk[jj]; Ym[jj][1] = Yl & mk[jj]; }
-          const float zs = __builtin_amdgcn_ldexpf(1.f, CZ_ZSCALE);
-#pragma unroll
-          for (int kt = 0; kt < CZ_NKT; ++kt) {
-            char* zw = zb + (gq & 1) * CZ_BUF + (n * 16 + 4 * g) * 2;
-            // ---- step A: Z[c, k] of my segments, cut into pieces, to LDS
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              if (jj < my_n) {
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ym[jj][0]), __builtin_bit_cast(f16x8, Hh[kt][1]), zero, 0, 0, 0);
-                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ym[jj][1]), __builtin_bit_cast(f16x8, Hh[kt][0]), z, 0, 0, 0);
-                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ym[jj][0]), __builtin_bit_cast(f16x8, Hh[kt][0]), z, 0, 0, 0);
-                unsigned zh0, zl0, zh1, zl1;
-                cz_split2(z[0] * zs, z[1] * zs, zh0, zl0);
-                cz_split2(z[2] * zs, z[3] * zs, zh1, zl1);
-                char* p = zw + (cpw * wave + jj) * CZ_COL;
-                *reinterpret_cast<u32x2*>(p) = (u32x2){zh0, zh1};
-                *reinterpret_cast<u32x2*>(p + CZ_PIECE) = (u32x2){zl0, zl1};
-              }
+        };
+        // step A of one (c, k) tile: Z[c, k] of my segments, two at a time (their three-product chains side by side), cut into pieces, to LDS
+        auto stepA = [&](auto kt_c, int buf) {
+          constexpr int kt = decltype(kt_c)::value;
+          if (ABL & 4) return;
+          char* zw0 = zb + buf * CZ_BUF + (n >> 1) * CZ_VSTRIDE + g * 256 + (n & 1) * 8;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          const f16x8 hh = __builtin_bit_cast(f16x8, Hh[kt][0]), hl = __builtin_bit_cast(f16x8, Hh[kt][1]);
+          for (int j = j0; j < j1; j += 2) {
+            const bool two = j + 1 < j1;
+            const u32x4 m0 = *reinterpret_cast<const u32x4*>(w_mask + (j * 4 + g) * 4);
+            const u32x4 m1 = two ? *reinterpret_cast<const u32x4*>(w_mask + ((j + 1) * 4 + g) * 4) : (u32x4){0u, 0u, 0u, 0u};
+            const f16x8 yh0 = __builtin_bit_cast(f16x8, Yh & m0), yl0 = __builtin_bit_cast(f16x8, Yl & m0);
+            const f16x8 yh1 = __builtin_bit_cast(f16x8, Yh & m1), yl1 = __builtin_bit_cast(f16x8, Yl & m1);
+            f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh0, hl, zero, 0, 0, 0);
+            f32x4 z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh1, hl, zero, 0, 0, 0);
+            z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl0, hh, z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl1, hh, z1, 0, 0, 0);
+            z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh0, hh, z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh1, hh, z1, 0, 0, 0);
+            const int col = cbase + j - c_lo;
+            {
+              unsigned zh0, zl0, zh1, zl1;
+              cz_split2(z0[0] * zs, z0[1] * zs, zh0, zl0);
+              cz_split2(z0[2] * zs, z0[3] * zs, zh1, zl1);
+              char* zw = zw0 + (col >> 4) * CZ_CB + (col & 15) * 16;
+              *reinterpret_cast<u32x2*>(zw) = (u32x2){zh0, zh1};
+              *reinterpret_cast<u32x2*>(zw + CZ_PIECE) = (u32x2){zl0, zl1};
             }
-            __syncthreads();
-            // ---- step B: my k-step of this (c, k) tile against W2', every column block
-            if (kt < KT || wave == 0) {                      // (k tile 9 holds the bias row only: k-step 0)
-              const char* zr = zb + (gq & 1) * CZ_BUF + n * CZ_COL + (32 * wave + 8 * g) * 2;
+            if (two) {
+              unsigned zh0, zl0, zh1, zl1;
+              cz_split2(z1[0] * zs, z1[1] * zs, zh0, zl0);
+              cz_split2(z1[2] * zs, z1[3] * zs, zh1, zl1);
+              char* zw = zw0 + ((col + 1) >> 4) * CZ_CB + ((col + 1) & 15) * 16;
+              *reinterpret_cast<u32x2*>(zw) = (u32x2){zh0, zh1};
+              *reinterpret_cast<u32x2*>(zw + CZ_PIECE) = (u32x2){zl0, zl1};
+            }
+          }
+        };
+        using K0 = std::integral_constant<int, 0>;
+        // While step B reads tile i from buffer i & 1, step A of tile i + 1 is written into the other buffer; one barrier per tile.
+        fetchW(K0{}, gq, false);
+        load_x(0);
+        finish_Y();
+        stepA(K0{}, gq & 1);
+        __syncthreads();
+        for (int ct = 0; ct < W.nct[io]; ++ct) {
+          cz_static_for<0, CZ_NKT>([&](auto kt_c) {
+            constexpr int kt = decltype(kt_c)::value;
+            const bool mine = kt < KT || wave == 0;          // (k tile 9 holds the bias row only: k-step 0)
+            // ---- the NEXT tile's W2' fragments set out into the other register set: a whole tile ahead of their use
+            fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last), kt + 1 == KT);
+            // ---- step B of tile (ct, kt): my k-step's Z pieces of the first column block (requested first: the step A below runs under their latency)
+            const char* zr = zb + (gq & 1) * CZ_BUF + wave * CZ_VSTRIDE + g * 256 + n * 16;
+            f16x8 zh[2], zl[2];
+            if (mine) { zh[0] = *reinterpret_cast<const f16x8*>(zr); zl[0] = *reinterpret_cast<const f16x8*>(zr + CZ_PIECE); }
+            // ---- step A of the next tile into the other buffer
+            if constexpr (kt + 1 < CZ_NKT) stepA(std::integral_constant<int, (kt + 1) % CZ_NKT>{}, (gq + 1) & 1);
+            else if (ct + 1 < W.nct[io]) { finish_Y(); stepA(K0{}, (gq + 1) & 1); }
+            if constexpr (kt == 4) if (ct + 1 < W.nct[io]) load_x(ct + 1);   // (this c tile's last step A is issued at kt = 8; Yh / Yl are rewritten at kt = 9)
+            if (mine && !(ABL & 8)) {
 #pragma unroll
-              for (int cb = 0; cb < 2; ++cb) {
+              for (int cb = 0; cb < CZ_NCB; ++cb)
                 if (cb < ncb) {
-                  const f16x8 zh = *reinterpret_cast<const f16x8*>(zr + cb * 16 * CZ_COL);
-                  const f16x8 zl = *reinterpret_cast<const f16x8*>(zr + cb * 16 * CZ_COL + CZ_PIECE);
+                  if (cb + 1 < ncb) {                        // the next block's pieces travel under this block's MFMAs
+                    zh[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB);
+                    zl[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB + CZ_PIECE);
+                  }
 #pragma unroll
                   for (int wt = 0; wt < 3; ++wt) {
-                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[wt][0]), zl, acc[wt][cb], 0, 0, 0);
-                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[wt][1]), zh, acc[wt][cb], 0, 0, 0);
-                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[wt][0]), zh, acc[wt][cb], 0, 0, 0);
+                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zl[cb & 1], acc[wt][cb], 0, 0, 0);
+                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][1]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
+                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
                   }
                 }
-              }
             }
             ++gq;
-            fetchW(min(gq, gq_last));
-          }
+            if (!(ABL & 2)) __syncthreads();                 // the next tile's Z is complete; this tile's buffer may be written again
+          });
         }
         // ---- the output irrep is complete: add the eight waves' partial sums, take the factors off, store into the segments' first rows
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(zb) + wave * (24 * 64);
+        float* red = reinterpret_cast<float*>(zb) + wave * (12 * CZ_NCB * 64);
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int cb = 0; cb < CZ_NCB; ++cb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[((wt * 2 + cb) * 4 + q) * 64 + lane] = acc[wt][cb][q];
+            for (int q = 0; q < 4; ++q) red[((wt * CZ_NCB + cb) * 4 + q) * 64 + lane] = acc[wt][cb][q];
         __syncthreads();
         for (int idx = tid; idx < 16 * ncb * 48; idx += 64 * NW) {
           const int col = idx / 48, w = idx - 48 * col;
           const int e = b_col_edge[col];
           if (e >= 0) {
             const int r = w & 15;
-            const float* rp = reinterpret_cast<const float*>(zb) + (((w >> 4) * 2 + (col >> 4)) * 4 + (r & 3)) * 64 + 16 * (r >> 2) + (col & 15);
+            const float* rp = reinterpret_cast<const float*>(zb) + (((w >> 4) * CZ_NCB + (col >> 4)) * 4 + (r & 3)) * 64 + 16 * (r >> 2) + (col & 15);
             float s = 0.f;
 #pragma unroll
-            for (int v = 0; v < NW; ++v) s += rp[v * (24 * 64)];
+            for (int v = 0; v < NW; ++v) s += rp[v * (12 * CZ_NCB * 64)];
             d.msg[(size_t)e * d.D_out + W.out_off[io] + w] = s * b_col_inv[col] * W.rowinv[io * 48 + w];
           }
         }
@@ -451,7 +505,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
   }
 }
 
-size_t convz_lds_bytes() { return CZ_ZBYTES + 8 * CZ_WAVE_FLOATS * sizeof(float) + (8 + 32 + 32) * sizeof(int); }
+size_t convz_lds_bytes() { return CZ_ZBYTES + 8 * CZ_WAVE_FLOATS * sizeof(float) + (8 + 2 * 16 * CZ_NCB) * sizeof(int); }
 
 void launch_convz(const ConvZArgs& a0, hipStream_t st) {
   constexpr int NW = 8;
@@ -468,7 +522,12 @@ void launch_convz(const ConvZArgs& a0, hipStream_t st) {
   }
   a.dbg = dbg_dev;
   const size_t lds = convz_lds_bytes();
-  if (dbfr_launch_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convz<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        "k_convz: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return;
-  hipLaunchKernelGGL((k_convz<NW>), dim3(dbfr_current_cu_count()), dim3(64 * NW), lds, st, a);
+#define V(x) { if (dbfr_launch_check(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convz<NW, x>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "k_convz: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return; \
+               hipLaunchKernelGGL((k_convz<NW, x>), dim3(dbfr_current_cu_count()), dim3(64 * NW), lds, st, a); return; }
+#ifdef DBFR_DEV_VARIANTS
+  static int abl = getenv("DBFR_CONVZ_ABL") ? atoi(getenv("DBFR_CONVZ_ABL")) : 0;
+  if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 4) V(4) if (abl == 8) V(8) if (abl == 16) V(16) if (abl == 32) V(32) if (abl == 12) V(12) if (abl == 5) V(5)
+#endif
+  V(0)
+#undef V
 }

@@ -60,7 +60,7 @@ def seg(m, tgt, Nt):
 
 
 ok = True
-for (layer, fam, name, E, Nt, Ng) in [(3, 2, "atom_conv_layers.3", 77, 13, 17), (3, 2, "atom_conv_layers.3", 3000, 180, 200), (0, 0, "lig_conv_layers.0", 900, 60, 64),
+for (layer, fam, name, E, Nt, Ng) in [] if "--timeonly" in sys.argv else [(3, 2, "atom_conv_layers.3", 77, 13, 17), (3, 2, "atom_conv_layers.3", 3000, 180, 200), (0, 0, "lig_conv_layers.0", 900, 60, 64),
                                       (1, 2, "atom_conv_layers.1", 1500, 400, 90), (2, 1, "cross_al_conv_layers.2", 2000, 40, 300), (5, 3, "cross_la_conv_layers.5", 2500, 900, 50),
                                       (-2, 0, "tor_bond_conv", 1200, 70, 80)]:
     c = inputs(name, E, Nt, Ng)
@@ -83,7 +83,7 @@ for (layer, fam, name, E, Nt, Ng) in [(3, 2, "atom_conv_layers.3", 77, 13, 17), 
         print("   non-finite columns", nanc[:20], "n =", len(nanc))
 print("OK" if ok else "MISMATCH")
 
-if "--time" in sys.argv:
+if "--time" in sys.argv or "--timeonly" in sys.argv:
     for (layer, fam, name, E, Nt, Ng) in [(3, 2, "atom_conv_layers.3", 650000, 50000, 65000), (3, 1, "cross_al_conv_layers.3", 650000, 13000, 65000), (0, 0, "lig_conv_layers.0", 650000, 45000, 45000)]:
         c = inputs(name, E, Nt, Ng)
         for mode in ("split_f16", "reduce_first"):
