@@ -77,6 +77,7 @@ void launch_extract_templates(int n_res, const int* aatype, const float* pos14, 
 void launch_select_pocket(int n_prot, int n_res_total, const int* res_ptr, int m, const float* pos, const float* mask, const int* ref_ptr,
                           const float* ref, float cut2, int max_neighbors, float* d2, unsigned char* out, hipStream_t st);
 void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double fused_bytes_per_edge, double* counter, hipStream_t st);
+void launch_acc_executed(const int* n_edges, double flops_per_edge, double* counter, hipStream_t st);
 // HBM bytes per edge of the FUSED conv (what the kernels of this library have to move): edge record (48 embedding floats, 9 harmonics,
 // 3 indices), two gathered 48-float rows for the radial MLP, the gathered D_in-float input row, the D_out-float message
 static inline double fused_bytes(int D_in, int D_out) { return 4.0 * (48 + 9 + 3 + 48 + 48 + D_in + D_out); }
@@ -154,6 +155,7 @@ struct dbfr_model {
   size_t ev_used;
   double* flops_dev;
   double fused_bytes_last;   // third counter as of the last dbfr_profile_read (before its reset)
+  double executed_last;      // fourth counter (flops the matrix pipe executed in the K=144 conv launches), likewise
   double conv_ms_acc; int64_t conv_launches_acc;
   // side streams for small batches: the four convs of an interaction layer (and the three heads) are independent
   hipStream_t side[3];
@@ -832,7 +834,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   for (int i = 0; i < n_tensors; ++i) tm[tensors[i].name] = &tensors[i];
   dbfr_model* m = new dbfr_model();
   m->cfg = *cfg;
-  m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
+  m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->executed_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
   m->streams_ready = false;
   m->edge_log = nullptr; m->edge_log_steps = 0; m->layer_fallback = 0;
   // which fused-conv kernel the K=144 convs use: k_conv2 (persistent, one launch per layer, tail split) wins while a layer
@@ -896,7 +898,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
     if (!rc) { *gs[i].off = upload(m, std::vector<float>(off, off + EMB), &rc); *gs[i].c = upload(m, std::vector<float>(c, c + 1), &rc); }
   }
   if (!rc) m->a14_group = upload(m, std::vector<int>(kAtom14ToGroup, kAtom14ToGroup + 21 * 14), &rc);
-  if (!rc) { m->flops_dev = upload(m, std::vector<double>(3, 0.0), &rc); }
+  if (!rc) { m->flops_dev = upload(m, std::vector<double>(4, 0.0), &rc); }
   if (!rc) { m->queue = upload(m, std::vector<int>(4, 0), &rc); }
   if (rc) { dbfr_model_destroy(m); return rc; }
   *out = m;
@@ -1116,6 +1118,7 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     for (int i = 0; i < n; ++i) za.c[i] = z[i];
     za.n_conv = n;
     za.dbg = nullptr;
+    za.executed = m->profile ? m->flops_dev + 3 : nullptr;      // k_convz counts the matrix instructions it issues (one atomic per wave and unit)
     launch_convz(za, st);
   }
   else if (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) launch_conv2h(a, st);
@@ -1124,8 +1127,15 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
   else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);
   if (m->profile)
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
       launch_acc_flops(descs[i].n_edges, 2.0 * 144 * (144.0 + Ws[i]), 4.0 * (Ws[i] + descs[i].w.D_in + 9) + 16.0, fused_bytes(descs[i].w.D_in, descs[i].w.D_out), m->flops_dev, st);
+      // what the matrix pipe executes in the per-edge kernel of this launch: `products` MFMA flops per flop of the hidden layer and of the W2 rows it walks
+      // (reduce-first: the vector-output rows only; the split kernels of round 2 keep the hidden layer on the fp32 instruction)
+      const double rows = 16.0 * descs[i].w.n_tiles;
+      const bool f16 = (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) || z;
+      const double ex = m->gemm_split == DBFR_GEMM_F32 ? 2.0 * 144 * (144.0 + rows) : f16 ? 3.0 * 2.0 * 144 * (144.0 + rows) : 2.0 * 144 * 144.0 + 6.0 * 2.0 * 144 * rows;
+      if (!z || descs[i].w.n_tiles > 0) launch_acc_executed(descs[i].n_edges, ex, m->flops_dev + 3, st);
+    }
 }
 
 static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, const dbfr_scores* out, Ws& w,
@@ -1527,14 +1537,21 @@ extern "C" int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_l
     if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) { m->conv_ms_acc += ms; m->conv_launches_acc++; }
   }
   m->ev_used = 0;
-  double fl[3] = {0, 0, 0};
+  double fl[4] = {0, 0, 0, 0};
   HIPCHECK(hipMemcpy(fl, m->flops_dev, sizeof fl, hipMemcpyDeviceToHost));
   m->fused_bytes_last = fl[2];
+  m->executed_last = fl[3];
   if (conv_ms) *conv_ms = m->conv_ms_acc;
   if (conv_launches) *conv_launches = m->conv_launches_acc;
   if (conv_flops) *conv_flops = fl[0];
   if (ref_form_bytes) *ref_form_bytes = fl[1];
-  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, 3 * sizeof(double))); }
+  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, 4 * sizeof(double))); }
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_profile_executed_flops(const dbfr_model* m, double* executed_flops) {
+  if (!m || !executed_flops) return fail(DBFR_ERR_ARG, "null argument");
+  *executed_flops = m->executed_last;
   return DBFR_OK;
 }
 

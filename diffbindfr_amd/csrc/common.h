@@ -146,7 +146,7 @@ struct ConvZDesc {
   const int* gedge0;      // [n_graph + 1] first edge of every graph
   int n_graph;
 };
-struct ConvZArgs { ConvZDesc c[4]; int n_conv; float* dbg; };   // dbg (developer, DBFR_CONVZ_DEBUG=<file>): workgroup 0 / wave 0 of the first unit dumps h [32 slots][144]
+struct ConvZArgs { ConvZDesc c[4]; int n_conv; float* dbg; double* executed; };   // executed (profiling only): += flops of the matrix instructions issued   // dbg (developer, DBFR_CONVZ_DEBUG=<file>): workgroup 0 / wave 0 of the first unit dumps h [32 slots][144]
 
 static inline uint16_t dbfr_bf16_rne(float x) {   // round-to-nearest-even fp32 -> bf16 (finite inputs)
   uint32_t u;

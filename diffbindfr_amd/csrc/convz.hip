@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     const float col_inv = __builtin_amdgcn_ldexpf(1.f, -CZ_ZSCALE - ey - ephi);
     const float zs = __builtin_amdgcn_ldexpf(1.f, CZ_ZSCALE);
     if (ABL & 32) continue;
+    long long n_mfma = 2 * KT * 14;                          // (profiling) matrix instructions this wave issues in this unit: the hidden layer ...
     for (int pass = 0; pass < npass; ++pass) {
       const int c_lo = 16 * CZ_NCB * pass;
       const int ncb = min(CZ_NCB, (total - c_lo + 15) >> 4);   // column blocks of 16 in step B
@@ -340,6 +341,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
         b_col_inv[cbase + j - c_lo] = col_inv;
       }
       for (int io = 0; io < W.n_io; ++io) {
+        // ... step A: 3 per (segment, tile), step B: 9 per (column block, tile) -- of the k tile 9 by wave 0 only
+        n_mfma += (long long)W.nct[io] * (3LL * CZ_NKT * max(j1 - j0, 0) + 9LL * ncb * (KT + (wave == 0)));
         f32x4 acc[3][CZ_NCB];
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt)
@@ -454,26 +457,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
             const char* zr = zb + (gq & 1) * CZ_BUF + wave * CZ_VSTRIDE + g * 256 + n * 16;
             f16x8 zh[2], zl[2];
             if (mine) { zh[0] = *reinterpret_cast<const f16x8*>(zr); zl[0] = *reinterpret_cast<const f16x8*>(zr + CZ_PIECE); }
-            // ---- step A of the next tile into the other buffer
-            if constexpr (kt + 1 < CZ_NKT) stepA(std::integral_constant<int, (kt + 1) % CZ_NKT>{}, (gq + 1) & 1);
-            else if (ct + 1 < W.nct[io]) { finish_Y(); stepA(K0{}, (gq + 1) & 1); }
-            if constexpr (kt == 4) if (ct + 1 < W.nct[io]) load_x(ct + 1);   // (this c tile's last step A is issued at kt = 8; Yh / Yl are rewritten at kt = 9)
-            if (mine && !(ABL & 8)) {
+            // ---- step A of the next tile into the other buffer, and step B of this one: the two waves of a SIMD (w, w + 4) take them in opposite
+            // order -- step A is vector-pipe work (masks, cutting Z into pieces), step B matrix-pipe work, and behind a barrier both waves would
+            // otherwise want the same pipe at the same time
+            auto nextA = [&] {
+              if constexpr (kt + 1 < CZ_NKT) stepA(std::integral_constant<int, (kt + 1) % CZ_NKT>{}, (gq + 1) & 1);
+              else if (ct + 1 < W.nct[io]) { finish_Y(); stepA(K0{}, (gq + 1) & 1); }
+              if constexpr (kt == 4) if (ct + 1 < W.nct[io]) load_x(ct + 1);   // (this c tile's last step A is issued at kt = 8; Yh / Yl are rewritten at kt = 9)
+            };
+            auto thisB = [&] {
+              if (mine && !(ABL & 8)) {
 #pragma unroll
-              for (int cb = 0; cb < CZ_NCB; ++cb)
-                if (cb < ncb) {
-                  if (cb + 1 < ncb) {                        // the next block's pieces travel under this block's MFMAs
-                    zh[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB);
-                    zl[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB + CZ_PIECE);
-                  }
+                for (int cb = 0; cb < CZ_NCB; ++cb)
+                  if (cb < ncb) {
+                    if (cb + 1 < ncb) {                      // the next block's pieces travel under this block's MFMAs
+                      zh[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB);
+                      zl[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB + CZ_PIECE);
+                    }
 #pragma unroll
-                  for (int wt = 0; wt < 3; ++wt) {
-                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zl[cb & 1], acc[wt][cb], 0, 0, 0);
-                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][1]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
-                    acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
+                    for (int wt = 0; wt < 3; ++wt) {
+                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zl[cb & 1], acc[wt][cb], 0, 0, 0);
+                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][1]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
+                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
+                    }
                   }
-                }
-            }
+              }
+            };
+            if (wave < NW / 2 && !(ABL & 64)) { nextA(); thisB(); } else { thisB(); nextA(); }
             ++gq;
             if (!(ABL & 2)) __syncthreads();                 // the next tile's Z is complete; this tile's buffer may be written again
           });
@@ -502,6 +512,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
         __syncthreads();
       }
     }
+    if (a.executed && lane == 0) atomicAdd(a.executed, 16384.0 * (double)n_mfma);   // 16 x 16 x 32 x 2 flops per instruction
   }
 }
 
@@ -526,7 +537,7 @@ void launch_convz(const ConvZArgs& a0, hipStream_t st) {
                hipLaunchKernelGGL((k_convz<NW, x>), dim3(dbfr_current_cu_count()), dim3(64 * NW), lds, st, a); return; }
 #ifdef DBFR_DEV_VARIANTS
   static int abl = getenv("DBFR_CONVZ_ABL") ? atoi(getenv("DBFR_CONVZ_ABL")) : 0;
-  if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 4) V(4) if (abl == 8) V(8) if (abl == 16) V(16) if (abl == 32) V(32) if (abl == 12) V(12) if (abl == 5) V(5)
+  if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 4) V(4) if (abl == 8) V(8) if (abl == 16) V(16) if (abl == 32) V(32) if (abl == 12) V(12) if (abl == 5) V(5) if (abl == 64) V(64)
 #endif
   V(0)
 #undef V

@@ -664,6 +664,10 @@ __global__ void k_acc_flops(const int* n_edges, double flops_per_edge, double by
   atomicAdd(&counter[1], bytes_per_edge * (double)*n_edges);
   atomicAdd(&counter[2], fused_bytes_per_edge * (double)*n_edges);
 }
+__global__ void k_acc_executed(const int* n_edges, double flops_per_edge, double* counter) { atomicAdd(counter, flops_per_edge * (double)*n_edges); }
+void launch_acc_executed(const int* n_edges, double flops_per_edge, double* counter, hipStream_t st) {
+  hipLaunchKernelGGL(k_acc_executed, dim3(1), dim3(1), 0, st, n_edges, flops_per_edge, counter);
+}
 void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double fused_bytes_per_edge, double* counter, hipStream_t st) {
   hipLaunchKernelGGL(k_acc_flops, dim3(1), dim3(1), 0, st, n_edges, flops_per_edge, bytes_per_edge, fused_bytes_per_edge, counter);
 }

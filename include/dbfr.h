@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define DBFR_ABI_VERSION 3   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
-                                3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only) */
+#define DBFR_ABI_VERSION 4   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
+                                3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only);
+                                4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_test_conv2's message rows in that mode hold segment sums */
 
 typedef enum {
   DBFR_OK = 0,
@@ -415,14 +416,24 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
  *                            hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x32_f16, the two small ones and the large one in separate
  *                            fp32 accumulators: half the matrix instructions of SPLIT_BF16.  Kernel k_conv2h (csrc/conv2h.hip);
  *                            accuracy table: profiles/r3_split_experiments.txt.
- * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_l1 | split_f16) says otherwise.
+ *   DBFR_GEMM_REDUCE_FIRST   the arithmetic of SPLIT_F16 with the ORDER of the work changed for the rows of lin.3 that feed a scalar (l = 0)
+ *                            output irrep (74 % of the rows at depth 3, all rows of the torsion convs): a scalar message element is linear in
+ *                            y (x) h (y = the tensor-product input coupled with the harmonics, h = the hidden layer), and so is the scatter over
+ *                            the edges of a target node, so Z[t,c,k] = sum_{e -> t} y[e,c] h[e,k] is formed first and the 144 x W GEMM runs
+ *                            once per TARGET SEGMENT (<= 32 consecutive edges of one target inside a 32-edge chunk of one graph), not once per
+ *                            edge: 8-10 x fewer matrix instructions for those rows.  Kernel k_convz (csrc/convz.hip); the l = 1 outputs stay
+ *                            per edge on k_conv2h.  Every lin.3 output row carries its own power-of-two factor there (no row-depth limit).
+ *                            MESSAGE BUFFER in this mode: the scalar columns of a segment's FIRST message row hold the segment's SUM, those of
+ *                            its other rows are zero (vector columns: per edge as before) -- the per-node reduction (sum of a node's rows /
+ *                            their number) is unchanged.  Chunks are cut per graph: what is summed with what never depends on batch mates.
+ * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_l1 | split_f16 | reduce_first) says otherwise.
  * A workspace is laid out for the mode it was sized in: set the mode before dbfr_workspace_bytes.                       */
 #define DBFR_GEMM_F32 0
 #define DBFR_GEMM_SPLIT_BF16 1
 #define DBFR_GEMM_SPLIT_BF16_L1 2
 #define DBFR_GEMM_SPLIT_F16 3
 #define DBFR_GEMM_REDUCE_FIRST 4
-#define DBFR_GEMM_DEFAULT DBFR_GEMM_SPLIT_F16
+#define DBFR_GEMM_DEFAULT DBFR_GEMM_REDUCE_FIRST
 int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
 /* DBFR_GEMM_SPLIT_F16 holds a weight row to 22 significant bits while the row's largest |w| is within 2^17 of the largest |w| of its
  * tensor-product run (one power-of-two factor per run; lin.0: per matrix).  dbfr_model_create measures every run of every conv; a conv
@@ -468,6 +479,9 @@ int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_launches, do
 /* HBM bytes the FUSED conv has to move for the launches the last dbfr_profile_read reported (read before its reset):
  * 4 (48 + 9 + 3 + 48 + 48 + D_in + D_out) per edge = edge record, two gathered radial-MLP rows, gathered input row, message. */
 int dbfr_profile_fused_bytes(const dbfr_model* m, double* fused_form_bytes);
+/* Flops the matrix pipe EXECUTED in the launches the last dbfr_profile_read reported: per edge `products` x 2 x 144 x (144 + rows walked) in the per-edge
+ * kernels (products: 1 fp32 instruction, 3 two-piece fp16, 6 three-piece bf16), the instructions k_convz issued x 16384 in DBFR_GEMM_REDUCE_FIRST.   */
+int dbfr_profile_executed_flops(const dbfr_model* m, double* executed_flops);
 
 /* What the fp16 matrix pipe of the CURRENT device sustains: a bare stream of v_mfma_f32_16x16x32_f16 (the instruction of DBFR_GEMM_SPLIT_F16)
  * with random operands on every compute unit, two waves per SIMD, for `seconds` (0 < seconds <= 60; the rate is taken over the second half,
