@@ -47,7 +47,7 @@ PIPE_RF = dict(kernel="k_convz + k_conv2h (one launch pair per interaction layer
                       "irrep reduce-first (Z = sum over a target's edges of y (x) h, then the 144 x W GEMM once per target segment), the vector-output rows per edge",
                instruction="v_mfma_f32_16x16x32_f16", products=3, peak=2500.0, hidden_on_pipe=True, sustained=1937.0,
                arithmetic="three fp16 x fp16 partial products per fp32 product (two fp16 pieces per operand, exact power-of-two scalings), fp32 accumulation")
-PMC_FILE = {"f32": "profiles/r2_pmc_k_conv.json", "split": "profiles/r2_pmc_k_conv2r.json", "split_l1": "profiles/r2_pmc_k_conv2s.json",
+PMC_FILE = {"f32": "profiles/r2_pmc_k_conv.json", "split": "profiles/r2_pmc_k_conv2r.json",
             "split_f16": "profiles/r4_pmc_k_conv2h.json"}
 PMC_FILE_CFG5 = {"split_f16": "profiles/r4_cfg5_pmc_k_conv2h.json"}
 HALF_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
@@ -63,8 +63,6 @@ PIPE = {
                   instruction="v_mfma_f32_16x16x32_bf16 (+ _16x16x16_bf16 for the last 16 k)", products=6, peak=HALF_MATRIX_PEAK_TFLOPS,
                   arithmetic="six bf16 x bf16 partial products per fp32 product (operands cut into three bf16 pieces, exact), fp32 accumulation -- "
                              "error vs fp64 <= the fp32 MFMA's"),
-    "split_l1": dict(kernel="k_conv2s (as k_conv2r, W2 pieces through L1)", instruction="v_mfma_f32_16x16x32_bf16 (+ _16x16x16_bf16)", products=6,
-                     peak=HALF_MATRIX_PEAK_TFLOPS, arithmetic="six bf16 x bf16 partial products per fp32 product, fp32 accumulation"),
     "split_f16": dict(kernel="k_conv2h (persistent; all four convs of an interaction layer, or the two torsion-head convs, per launch): fused radial MLP "
                              "+ tensor product; W2 pieces through an LDS ring, one copy per tile per CU, two barriers per tile",
                       instruction="v_mfma_f32_16x16x32_f16 (+ _16x16x16_f16 for the last 16 k)", products=3, peak=HALF_MATRIX_PEAK_TFLOPS,
@@ -189,7 +187,7 @@ def cpu_baseline(cfg_id, samp, dev, n_poses=1, batched=(2, 2), batched_steps=5):
     return out
 
 
-PMC_KERNEL = {"split_f16": "k_conv2h", "split": "k_conv2r", "split_l1": "k_conv2s", "reduce_first": "k_conv"}
+PMC_KERNEL = {"split_f16": "k_conv2h", "split": "k_conv2r", "reduce_first": "k_conv"}
 
 
 def measure_traffic(mode, args):
@@ -259,6 +257,16 @@ class BoardSampler:
         self.rows = []
         self._stop = threading.Event()
         self._th = threading.Thread(target=self._run, daemon=True) if self.dir else None
+        # which limiter holds the clock: the firmware's violation accumulators (amdsmi_get_violation_status through the amdsmi package ROCm ships,
+        # tools/board_limiter.py), read once before and once after the timed region -- two library calls, nothing launched on the GPU
+        self.lim, self.v0 = None, None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import board_limiter
+            self.lim = board_limiter.Limiter(0, bdf=want if self.dir else None)
+            self._bl = board_limiter
+        except Exception:
+            self.lim = None
 
     def _read(self, name):
         try:
@@ -274,6 +282,8 @@ class BoardSampler:
                 self.rows.append((pw / 1e6 if pw is not None else None, ck / 1e6 if ck is not None else None))
 
     def start(self):
+        if self.lim is not None:
+            self.v0 = self.lim.violation()
         if self._th:
             self._th.start()
         return self
@@ -289,7 +299,19 @@ class BoardSampler:
         pw = [r[0] for r in rows if r[0] is not None]
         ck = [r[1] for r in rows if r[1] is not None]
         cap = self._read("power1_cap")
-        return {"power_cap_w": cap / 1e6 if cap else None, "samples": len(rows),
+        limiter = None
+        if self.lim is not None:
+            try:
+                limiter = self._bl.accumulator_shares(self.v0, self.lim.violation())
+                if limiter:
+                    limiter = {k: v for k, v in limiter.items() if not k.startswith("delta_") or k in ("delta_ppt_pwr",)}
+                    limiter["what"] = ("share of the power-management firmware's control iterations during the timed region in which each controller held the "
+                                       "clock down (amdsmi_get_violation_status accumulators, after - before): ppt_pwr = package power tracking, socket / vr / hbm "
+                                       "_thrm = thermal, prochot")
+                self.lim.close()
+            except Exception:
+                limiter = None
+        return {"power_cap_w": cap / 1e6 if cap else None, "samples": len(rows), "limiter": limiter,
                 "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": round(max(pw), 1) if pw else None,
                 "sclk_mhz_mean": round(sum(ck) / len(ck), 1) if ck else None, "sclk_mhz_min": round(min(ck), 1) if ck else None,
                 "source": f"{self.dir}/power1_input, freq1_input, twice a second during the timed region (rank 0's board)"}
@@ -334,28 +356,43 @@ def spawn_ranks(n, argv):
     launcher started)."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+    import threading
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", LOCAL_WORLD_SIZE=str(n))
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports (RCCL needs it)
     base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    # the rendezvous port: the socket that found it stays bound (SO_REUSEADDR) until the children are started, so that a second bench
+    # started at the same moment cannot be handed the same number
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    base["MASTER_PORT"] = str(sk.getsockname()[1])
     procs = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0 = ""
-    try:
-        out0, _ = procs[0].communicate()
-    finally:
-        rcs = []
-        for r, p in enumerate(procs):
-            try:
-                rcs.append(p.wait(timeout=None if procs[0].returncode == 0 else 60))
-            except subprocess.TimeoutExpired:          # rank 0 failed and this rank hangs in a collective: end it (exact pid)
-                p.kill()
-                rcs.append(p.wait())
+    sk.close()
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)      # rank 0's pipe is drained by a thread ...
+    reader.start()
+    rcs = [None] * n
+    while any(c is None for c in rcs):      # ... while ALL children are watched: the first one to fail ends the others (exact pids) instead of
+        for r, p in enumerate(procs):       # leaving them in a collective until its timeout
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(c not in (None, 0) for c in rcs):
+            deadline = time.time() + 15
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    out0 = out0[0] if out0 else ""
     lines = [l for l in out0.splitlines() if l.startswith('{"metric"')]
     for l in out0.splitlines():
         if not l.startswith('{"metric"'):
@@ -385,12 +422,19 @@ def main():
     ap.add_argument("--cpu-poses", type=int, default=None)
     ap.add_argument("--cpu-batched-steps", type=int, default=5)
     ap.add_argument("--jobs", type=int, default=None, help="size of the job table (weak scaling: per rank); default --steps x (--batch-poses // poses per job)")
-    ap.add_argument("--store", choices=("device", "host"), default="device", help="dist.run_sharded: pose records in HBM, or streamed to pinned host memory batch by batch")
+    ap.add_argument("--store", choices=("device", "host"), default=None, help="dist.run_sharded: pose records in HBM, or streamed to pinned host memory batch by batch "
+                                                                             "(default: device; host for the screening configs 3 / 4 on more than one GPU)")
     ap.add_argument("--no-probe", action="store_true", help="do not measure what the bare matrix pipe sustains on this board (4 s; roofline.frac_of_sustained then uses round 3's constant)")
     ap.add_argument("--no-board", action="store_true", help="do not sample board power / clock (amdgpu hwmon files) during the timed region")
     ap.add_argument("--no-speed-shard", action="store_true", help="N > 1: shard the job table evenly instead of by the ranks' measured speed")
-    ap.add_argument("--gather", choices=("all", "root"), default="all", help="dist.run_sharded: every rank receives every pose, or rank 0 only")
+    ap.add_argument("--gather", choices=("all", "root"), default=None, help="dist.run_sharded: every rank receives every pose, or rank 0 only (default: all; root for "
+                                                                          "the screening configs 3 / 4 on more than one GPU: 10 k ligands x 40 poses are written out by one rank)")
     args = ap.parse_args()
+    screen = args.config in (3, 4) and args.gpus > 1
+    if args.store is None:
+        args.store = "host" if screen else "device"
+    if args.gather is None:
+        args.gather = "root" if screen else "all"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher: be one
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -425,13 +469,14 @@ def main():
     # N > 1: boards hold clocks up to 5 % apart at the power cap, and a statically sharded job takes as long as its slowest rank.  Every
     # rank times ONE more untimed batch of the same jobs (workspace and code already warm), the times are all-gathered and the job table
     # is LPT-sharded by measured speed (dist.rank_speeds): faster boards take proportionally more jobs.  The poses do not depend on it.
-    speeds = None
+    speeds, calib_s = None, None
     if world > 1 and args.warmup > 0 and not args.no_speed_shard:      # (with --warmup 0 the batch would time one-off set-up costs)
         ddist.barrier()
         tc = time.perf_counter()
         samp.run_complexes(warm, ppc, dev, seed=12345)
         torch.cuda.synchronize(dev)
-        speeds = ddist.rank_speeds(time.perf_counter() - tc, dev)
+        calib_s = time.perf_counter() - tc
+        speeds = ddist.rank_speeds(calib_s, dev)
     shards, reps = ddist.shard_jobs(jobs, ppc, world, speeds)
     t_up = time.perf_counter()
     for j in shards[rank]:                       # per-complex records resident in HBM before the timed region
@@ -477,7 +522,8 @@ def main():
     t_sampled = (stamps[-1] - t0) if stamps else 0.0
     # what every rank did, all-gathered: the line shows that the collective saw `world` ranks, and on which devices
     per_rank = ddist.all_gather_vec([rank, dev.index, float(sum(done)), len(done), t_local, t_sampled,
-                                     torch.cuda.max_memory_allocated(dev) / 2 ** 30, t_up, asm_s[0]], dev)
+                                     torch.cuda.max_memory_allocated(dev) / 2 ** 30, t_up, asm_s[0],
+                                     (len(warm) * ppc / calib_s) if calib_s else 0.0], dev)
     n_steps = max(int(v[3]) for v in per_rank) if args.jobs else args.steps      # --jobs: a step is still one batch; the slowest rank's count
     counters = (C.c_int64 * 8)()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -500,7 +546,7 @@ def main():
         alg = fl.value / (ms.value * 1e-3) / 1e12            # algorithmic fp32 flops 2*144*(144+W) per edge / kernel time
         P = PIPE_RF if mode == "reduce_first" else PIPE[mode]
         # what the named matrix instruction executes: `products` MFMA-flops per algorithmic flop of the 144 x W GEMM (97.6 % of the
-        # conv's flops); in k_conv2r / k_conv2s the 144 x 144 hidden layer stays on the fp32 instruction inside the same kernel and is
+        # conv's flops); in k_conv2r the 144 x 144 hidden layer stays on the fp32 instruction inside the same kernel and is
         # not counted, k_conv2h runs it on the same three-product form (W1h tiles)
         ex = alg if mode == "f32" else P["products"] * (1.0 if P.get("hidden_on_pipe") else W2_SHARE) * alg
         exe = C.c_double()
@@ -611,7 +657,13 @@ def main():
                        "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
                                      "sampling_s": round(v[5], 4), "gather_and_unpack_s": round(v[4] - v[5], 4),
                                      "torch_peak_hbm_gib": round(v[6], 3), "records_upload_s_before_timing": round(v[7], 4),
-                                     "assemble_host_s": round(v[8], 4)} for v in per_rank],
+                                     "assemble_host_s": round(v[8], 4),
+                                     "poses_per_sec_sampling": round(v[2] / v[5], 2) if v[5] > 0 else None,      # this rank's own rate over its batches
+                                     "poses_per_sec_calibration_batch": round(v[9], 2) if v[9] > 0 else None}    # one untimed batch before the timed region
+                                    for v in per_rank],
+                       # whole-job rate / sum of what the ranks sustained while sampling: what sharding imbalance, the gather and the barriers cost
+                       "parallel_efficiency": (round((poses / elapsed) / sum(v[2] / v[5] for v in per_rank if v[5] > 0), 4)
+                                               if world > 1 and any(v[5] > 0 for v in per_rank) else None),
                        "hbm_note": "torch_peak_hbm_gib = torch.cuda.max_memory_allocated over the timed region: record halves, packed batch, tapes, "
                                    "trajectories, the library's workspace (a torch tensor); + 0.28 GiB of packed weights the library allocates itself"},
             "roofline": roof,

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
 
 #include "common.h"
@@ -11,7 +12,6 @@
 void launch_conv(const ConvArgs& a, hipStream_t st);
 void launch_conv_layer(const ConvArgs* c4, hipStream_t st);
 void launch_conv2(const Conv2Args& a, hipStream_t st);
-void launch_conv2s(const Conv2Args& a, hipStream_t st);
 void launch_conv2r(const Conv2Args& a, hipStream_t st);
 void launch_conv2h(const Conv2Args& a, hipStream_t st);
 void launch_convz(const ConvZArgs& a, hipStream_t st);
@@ -31,8 +31,9 @@ struct GraphArgs {
   int lig_cap, atom_cap, dynamic_cross;
   EdgeSet set[N_SETS];
   int* err;
-  int step, lds_nl, lds_na, n_chunk;
+  int step, lds_nl, lds_na, n_chunk, lanes;
 };
+void dbfr_edge_form(const dbfr_batch& b, int* n_chunk, int* lanes);
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
 void launch_edge_log(const GraphArgs& A, int* log_row, hipStream_t st);
 void launch_graph_chunks(const GraphArgs& A, hipStream_t st);
@@ -105,15 +106,15 @@ static int take_launch_error() {
   return DBFR_ERR_HIP;
 }
 int dbfr_current_cu_count() {
-  static int cache[64] = {0};
+  static std::atomic<int> cache[64];                     // (zero-initialised; host threads driving different devices may fill it concurrently)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!cache[dev]) {
-    int n = 0;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (!n) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cache[dev] = n;
+    cache[dev].store(n, std::memory_order_relaxed);
   }
-  return cache[dev];
+  return n;
 }
 
 // DBFR_GEMM = f32 | split: which matrix instruction carries the 144 x W GEMM of the K=144 convs (dbfr_model_set_gemm overrides)
@@ -121,7 +122,6 @@ static int gemm_from_env() {
   const char* e = getenv("DBFR_GEMM");
   if (!e || !*e) return DBFR_GEMM_DEFAULT;
   if (!strcmp(e, "split") || !strcmp(e, "1")) return DBFR_GEMM_SPLIT_BF16;
-  if (!strcmp(e, "split_l1") || !strcmp(e, "2")) return DBFR_GEMM_SPLIT_BF16_L1;
   if (!strcmp(e, "split_f16") || !strcmp(e, "3")) return DBFR_GEMM_SPLIT_F16;
   if (!strcmp(e, "reduce_first") || !strcmp(e, "4")) return DBFR_GEMM_REDUCE_FIRST;
   return DBFR_GEMM_F32;
@@ -142,7 +142,7 @@ struct dbfr_model {
   int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
   std::string fallback_convs;   // ';'-separated names of the convs whose weights two fp16 pieces cannot hold (dbfr_model_fallback_convs)
   uint32_t layer_fallback;      // bit l: interaction layer l goes through k_conv2r in DBFR_GEMM_SPLIT_F16 mode; bit 31: the torsion heads
-  int* edge_log; int edge_log_steps;   // dbfr_model_set_edge_log: caller-owned device buffer [steps][6][G], or null
+  int* edge_log; int edge_log_steps, edge_log_graphs;   // dbfr_model_set_edge_log: caller-owned device buffer [steps][6][graphs], or null
   Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
   Mlp2 tr_final, rot_final, tor_final, sc_final;
   const float* atom_emb[5]; int atom_dims[5];
@@ -579,7 +579,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   o->W2q = upload(m, w2q, &rc);
   o->b2q = upload(m, b2q, &rc);
   }
-  if (!vector_only) {   // the same fragments cut into three bf16 pieces (conv2s.hip).  Per tile: [3 pieces][4 k-steps of 32][64][8] -- step s = fp32
+  if (!vector_only) {   // the same fragments cut into three bf16 pieces (conv2r.hip).  Per tile: [3 pieces][4 k-steps of 32][64][8] -- step s = fp32
       // k-steps 2s and 2s+1 of the same lane -- then [3 pieces][64][4] for the last 16 k (fp32 k-step 8)
     const size_t tile_h = 13824 / 2, tail_off = 12288 / 2;
     std::vector<uint16_t> w2s((size_t)n_tiles * tile_h + 512, 0);   // (+ 1 KiB of slack behind the last tile)
@@ -765,14 +765,14 @@ extern "C" int dbfr_model_fallback_convs(const dbfr_model* m, char* names, size_
   return n;
 }
 
-extern "C" int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap) {
-  if (!m || (log_dev && n_steps_cap <= 0)) return fail(DBFR_ERR_ARG, "dbfr_model_set_edge_log: bad argument");
-  m->edge_log = log_dev; m->edge_log_steps = log_dev ? n_steps_cap : 0;
+extern "C" int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap, int32_t n_graphs_cap) {
+  if (!m || (log_dev && (n_steps_cap <= 0 || n_graphs_cap <= 0))) return fail(DBFR_ERR_ARG, "dbfr_model_set_edge_log: bad argument");
+  m->edge_log = log_dev; m->edge_log_steps = log_dev ? n_steps_cap : 0; m->edge_log_graphs = log_dev ? n_graphs_cap : 0;
   return DBFR_OK;
 }
 
 extern "C" int dbfr_model_set_gemm(dbfr_model* m, int32_t mode) {
-  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_REDUCE_FIRST) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument");
+  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_REDUCE_FIRST || mode == 2) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument (mode 2, the L1 variant of the bf16 split, was retired with ABI 4)");
   m->gemm_split = mode;
   return DBFR_OK;
 }
@@ -836,7 +836,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   m->cfg = *cfg;
   m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->executed_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
   m->streams_ready = false;
-  m->edge_log = nullptr; m->edge_log_steps = 0; m->layer_fallback = 0;
+  m->edge_log = nullptr; m->edge_log_steps = 0; m->edge_log_graphs = 0; m->layer_fallback = 0;
   // which fused-conv kernel the K=144 convs use: k_conv2 (persistent, one launch per layer, tail split) wins while a layer
   // is only a few rounds of workgroups (predict.py-sized batches), k_conv (conv.hip) at bench-sized batches.
   // DBFR_CONV2 = 0 / 1 forces one of them, default -1 = by batch size
@@ -1123,7 +1123,6 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
   }
   else if (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) launch_conv2h(a, st);
   else if (m->gemm_split == DBFR_GEMM_SPLIT_BF16 || m->gemm_split >= DBFR_GEMM_SPLIT_F16) launch_conv2r(a, st);   // (a launch holding a conv whose weights span more than two fp16 pieces hold: three bf16 pieces)
-  else if (m->gemm_split) launch_conv2s(a, st);
   else launch_conv2(a, st);
   if (m->profile == 1) (void)hipEventRecord(e1, st);
   if (m->profile)
@@ -1151,10 +1150,17 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   ga.cross_cut2 = cfg.dynamic_max_cross ? 1.0f : cfg.cross_cutoff * cfg.cross_cutoff;
   ga.lig_cap = cfg.lig_max_neighbors; ga.atom_cap = cfg.atom_max_neighbors; ga.dynamic_cross = cfg.dynamic_max_cross;
   for (int k = 0; k < N_SETS; ++k) ga.set[k] = w.set[k];
-  ga.err = w.err; ga.step = step; ga.lds_nl = ga.lds_na = ga.n_chunk = 0;
+  ga.err = w.err; ga.step = step; ga.lds_nl = ga.lds_na = 0;
+  dbfr_edge_form(*B, &ga.n_chunk, &ga.lanes);      // one choice of the edge builder's form for every launcher of this call
   launch_edges(ga, false, st);
+  // (a launcher that could not prepare its launch left the edge sets unbuilt: nothing below may run on them)
+  if (int lrc = take_launch_error()) return lrc;
   if (m->gemm_split == DBFR_GEMM_REDUCE_FIRST) launch_graph_chunks(ga, st);   // per-graph chunks of 32 edges for k_convz
-  if (m->edge_log && step < m->edge_log_steps) launch_edge_log(ga, m->edge_log + (size_t)step * N_SETS * G, st);
+  if (m->edge_log && step < m->edge_log_steps) {
+    // the log rows are laid out for the graph count the caller sized the buffer for: a batch with another count would write past it
+    if (G != m->edge_log_graphs) return fail(DBFR_ERR_ARG, "dbfr_model_set_edge_log: the buffer was sized for " + std::to_string(m->edge_log_graphs) + " graphs, this batch has " + std::to_string(G));
+    launch_edge_log(ga, m->edge_log + (size_t)step * N_SETS * G, st);
+  }
   // ---- embeddings
   {
     MlpArgs a; memset(&a, 0, sizeof a);
@@ -1366,6 +1372,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
 
 static int begin(dbfr_model* m, const dbfr_batch* B, void* workspace, size_t wbytes, const dbfr_limits* lim, Ws* w,
                  hipStream_t st) {
+  g_launch_err = false;                                  // (a flag an earlier, failed call left on this thread is not this call's)
   int rc = check_batch(m, B);
   if (rc) return rc;
   if (!workspace) return fail(DBFR_ERR_ARG, "null workspace");
@@ -1599,6 +1606,7 @@ static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t fami
                           const int32_t* idx1, const float* tab2, int32_t ld2, const int32_t* idx2, const float* x, int32_t ldx,
                           float* msg, void* hip_stream) {
   if (!m) return fail(DBFR_ERR_ARG, "null model");
+  g_launch_err = false;
   const ConvW* cw = pick_conv(m, layer, family);
   if (!cw) return fail(DBFR_ERR_ARG, "no such conv");
   if (conv2) {

@@ -83,7 +83,7 @@ struct ConvW2 {
   const float* b1;
   const float* W2q;   // [n_tiles][K/16][64][4]
   const float* b2q;   // [n_tiles*16]
-  const void* W2s;    // [n_tiles] x 13824 B: W2q cut into three bf16 pieces for k_conv2s (conv2s.hip; layout: api.cpp pack_conv2)
+  const void* W2s;    // [n_tiles] x 13824 B: W2q cut into three bf16 pieces for k_conv2r (conv2r.hip; layout: api.cpp pack_conv2)
   const void* W1h;    // [9] x 9280 B: lin.0 (W1p's tiles, bias rows) in the W2h tile format with the one factor 2^k1, for k_conv2h's hidden layer
   int k1;
   int f16_depth;      // largest row depth of the fp16 packing (api.cpp pack_f16_tiles): above F16_ROW_DEPTH_OK the conv is served by k_conv2r

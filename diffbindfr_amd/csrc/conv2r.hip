@@ -1,8 +1,16 @@
-// Fused tensor-product convolution, split-bf16 GEMM (see conv2s.hip for the arithmetic), W2 through an LDS ring.
+// Fused tensor-product convolution, split-bf16 GEMM, W2 through an LDS ring (round 2; since round 3 the range-guard fall-back of k_conv2h).
 //
-// k_conv2s lets every one of the eight waves of the workgroup fetch the same 13.5 KiB of W2 pieces per tile through the
-// vector L1: 64 B/clk of L1 bandwidth are ~80 % busy with it and the sweep waits for its loads (no re-load: 279, with: 194
-// fp32-equivalent TFLOP/s on one big conv).  Here ONE copy per tile enters the CU:
+// Arithmetic: every fp32 operand of the radial MLP's 144 x W GEMM is cut into three bf16 pieces, a = a1 + a2 + a3 (round-to-nearest each
+// time; 3 x 8 significand bits hold all 24 bits of an fp32 number, so the sum is exact and bf16 has fp32's exponent range: no scaling).  W2 is
+// cut once at model creation (api.cpp pack_conv2), the hidden layer h in registers right after its ReLU.  A product a b = sum_ij a_i b_j; each
+// a_i b_j (8 x 8 bits) is exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16; the six partial products with i + j <= 4 are evaluated,
+// smallest first, the three dropped ones are below 2^-23 |a b| (tools/exp/split_bf16.hip: error vs fp64 one third of the fp32 instruction's).
+// k = 144 = 4 k-steps of 32 + 16 on the x16 instruction; the hidden layer's MFMA result registers are, piece by piece, the B operand of the W2
+// tiles (step s, lane group g, slot j = hidden unit 16 (2 s + (j >> 2)) + 4 g + (j & 3)): no transpose, no LDS.  The first GEMM (144 x 144)
+// stays on the fp32 instruction.  (Round 2 also shipped k_conv2s, the same arithmetic with every wave fetching its own copy of the W2 pieces
+// through the vector L1 -- ~10 % slower, the L1 80 % busy with eight identical 13.5-KiB fetches per tile; retired in round 5, git history has it.)
+//
+// ONE copy of a tile enters the CU:
 //   * an LDS ring of five slots, one per k-step of a tile (4 x three 1-KiB pieces, the last 16 k, + the tile's 16 bias
 //     values), laid out like the tile in memory.  It is filled by the waves themselves in 512-byte shares: one 8-byte load per
 //     lane into a staging register pair, one ds_write_b64 two k-steps later (why not LDS-DMA, and why without a single
@@ -10,13 +18,13 @@
 //   * a wave keeps only TWO k-steps of W2 fragments in registers (the one its MFMAs read, the next one arriving from the ring
 //     by ds_read_b128, lane-linear = conflict-free) instead of a whole tile, which pays for a second accumulator set:
 //     both edge blocks run through a k-step together (two accumulator chains, fragments read once per tile), and the
-//     contraction of tile i - 1 is hand-interleaved into the issue gaps of tile i's 60 MFMAs (conv2s.hip explains why the
-//     wave has to hide it itself);
+//     contraction of tile i - 1 is hand-interleaved into the issue gaps of tile i's 60 MFMAs (two waves per SIMD share the matrix
+//     pipe: a wave has to hide its own vector work);
 //   * slot s is read by everybody during k-step s - 1, re-filled with the next tile's k-step s during k-step s + 2 and read
 //     again two k-steps later; an s_barrier at the start of k-steps 0, 2 and 4 is all the ordering that needs (`turn` below).
 //     Three barriers per tile, rarely waited for: the waves of a workgroup do identical work.
 // Everything else (unit queue, hidden layer in registers, x rows / harmonics in wave-private LDS, channel-owner accumulation,
-// tail split, bitwise independence from the unit -> workgroup assignment) is conv2s.hip's.
+// tail split, bitwise independence from the unit -> workgroup assignment) is k_conv2's (conv2.hip).
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2r(Conv2Args a) {
         for (int i = 0; i < 3; ++i) FT[i] = *reinterpret_cast<const s16x4*>(ring + C3_TAIL_OFF + i * 512 + lane * 8);
       });
       turn(I4{});
-      // k = 128..143 on v_mfma_f32_16x16x16_bf16.  Hazard (MI355X + ROCm 7.2, conv2s.hip): an x16 MFMA taking as SrcC an
+      // k = 128..143 on v_mfma_f32_16x16x16_bf16.  Hazard (MI355X + ROCm 7.2, first met in round 2): an x16 MFMA taking as SrcC an
       // accumulator an x32 MFMA has just written reads stale data; 16 wait states put any pass count behind us.
       asm volatile("s_nop 15");
       __builtin_amdgcn_sched_barrier(0);

@@ -37,6 +37,8 @@ struct GraphArgs {
   int step;               // sampler step index (0 for dbfr_score)
   int lds_nl, lds_na;     // LDS staging capacities (>= max_nl / max_na of the batch)
   int n_chunk;            // EDGE_CHUNK-target chunks per graph every set is split into (own workgroup each)
+  int lanes;              // lanes per target of the edge builder (1 | 4); n_chunk and lanes are chosen ONCE per call (dbfr_edge_form) and
+                          // shared by every launcher below: the g_cnt / g_base layout depends on both
 };
 
 __device__ __forceinline__ float d2_rn(float ax, float ay, float az, float bx, float by, float bz) {
@@ -394,6 +396,8 @@ static int edge_lanes(const dbfr_batch& b) {
   return wg1 >= 2L * dbfr_current_cu_count() ? 1 : 4;      // four lanes while the coarse form would leave the chip mostly empty
 }
 
+void dbfr_edge_form(const dbfr_batch& b, int* n_chunk, int* lanes) { *lanes = edge_lanes(b); *n_chunk = edge_chunks_of(b); }
+
 void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
   (void)with_heads_only;
   GraphArgs A = A0;
@@ -406,8 +410,8 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
                           reinterpret_cast<const void*>(&k_edges<false, 4>), reinterpret_cast<const void*>(&k_edges<true, 4>)})
       if (dbfr_launch_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64), "k_edges: hipFuncSetAttribute(MaxDynamicSharedMemorySize)")) return;
   }
-  A.n_chunk = edge_chunks_of(A.b);      // <= what plan() in api.cpp sized g_cnt / g_base for (dbfr_edge_chunks)
-  if (edge_lanes(A.b) == 1) {
+  if (A.n_chunk <= 0) dbfr_edge_form(A.b, &A.n_chunk, &A.lanes);      // n_chunk <= what plan() in api.cpp sized g_cnt / g_base for (dbfr_edge_chunks)
+  if (A.lanes == 1) {
     hipLaunchKernelGGL((k_edges<false, 1>), dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
     hipLaunchKernelGGL(k_edges_scan, dim3(N_SETS), dim3(256), 0, st, A);
     hipLaunchKernelGGL((k_edges<true, 1>), dim3(A.b.G * A.n_chunk, N_SETS), dim3(256), lds, st, A);
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256) void k_graph_chunks(GraphArgs A) {
 
 void launch_graph_chunks(const GraphArgs& A0, hipStream_t st) {
   GraphArgs A = A0;
-  A.n_chunk = edge_chunks_of(A.b);
+  if (A.n_chunk <= 0) dbfr_edge_form(A.b, &A.n_chunk, &A.lanes);
   hipLaunchKernelGGL(k_graph_chunks, dim3(N_SETS), dim3(256), 0, st, A);
 }
 
@@ -470,7 +474,7 @@ __global__ void k_edge_log(GraphArgs A, int* log) {
 
 void launch_edge_log(const GraphArgs& A0, int* log_row, hipStream_t st) {
   GraphArgs A = A0;
-  A.n_chunk = edge_chunks_of(A.b);
+  if (A.n_chunk <= 0) dbfr_edge_form(A.b, &A.n_chunk, &A.lanes);
   hipLaunchKernelGGL(k_edge_log, dim3((A.b.G + 255) / 256, N_SETS), dim3(256), 0, st, A, log_row);
 }
 

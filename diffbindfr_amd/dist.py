@@ -42,6 +42,11 @@ def init(backend=None):
             dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))   # first barrier, errors surface here and not mid-run)
             torch.cuda.set_device(dev)
             kw["device_id"] = dev
+        # an explicit rendezvous / collective timeout (default 10 minutes, DBFR_DIST_TIMEOUT_S): a rank that never arrives fails the job with a
+        # message instead of leaving the others in a barrier for the library default of 30 minutes
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("DBFR_DIST_TIMEOUT_S", "600")))
+        pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         if rank == 0:       # one line, so that an RCCL start-up failure can be told from a sampler failure in the driver's log
             ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
@@ -49,6 +54,26 @@ def init(backend=None):
                   f"master={os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']} "
                   f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
     return rank, world, local
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """One rank per GPU shares the node's host cores with the other ranks: the host side of a batch (assemble: record halves ->
+    packed batch, a few ms of numpy / torch-CPU work per batch) runs on this rank's own contiguous slice of the cores the process may
+    use, so that eight ranks neither bounce between NUMA nodes nor oversubscribe one another's cores.  DBFR_DIST_PIN=0 switches it
+    off; a launcher that already restricted the affinity to fewer cores than a slice is left alone.  Returns the cores or None."""
+    if os.environ.get("DBFR_DIST_PIN", "1") == "0" or local_world <= 1 or not hasattr(os, "sched_getaffinity"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(per, int(os.environ.get("OMP_NUM_THREADS", str(per))))))
+        return mine
+    except OSError:
+        return None
 
 
 def complex_cost(n_atoms, n_lig, n_cab=None):

@@ -124,7 +124,7 @@ def load():
     lib.dbfr_model_create.argtypes = [C.POINTER(ModelCfg), C.POINTER(Tensor), i32, C.POINTER(vp)]
     lib.dbfr_model_destroy.argtypes = [vp]
     lib.dbfr_model_destroy.restype = None
-    lib.dbfr_model_set_edge_log.argtypes = [vp, vp, i32]
+    lib.dbfr_model_set_edge_log.argtypes = [vp, vp, i32, i32]
     lib.dbfr_model_fallback_convs.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.dbfr_model_set_gemm.argtypes = [vp, i32]
     lib.dbfr_model_get_gemm.argtypes = [vp]

@@ -102,7 +102,7 @@ def conv_paths(kind):
     return wn.value, [list(tab[10 * i:10 * i + 10]) for i in range(n)]
 
 
-GEMM_MODES = {"f32": 0, "split": 1, "split_l1": 2, "split_f16": 3, "reduce_first": 4}     # include/dbfr.h: DBFR_GEMM_*
+GEMM_MODES = {"f32": 0, "split": 1, "split_f16": 3, "reduce_first": 4}     # include/dbfr.h: DBFR_GEMM_*
 
 
 @INTERACTION.register_module(name=["TensorProductModelHIP"])
@@ -115,7 +115,9 @@ class TensorProductModelHIP(nn.Module):
         assert not g("use_second_order_repr", False), "use_second_order_repr=True is not supported"
         self.no_sc_torsion = bool(g("no_sc_torsion", False))
         # which matrix instruction carries the radial MLP's big GEMM: None = the library's default (or $DBFR_GEMM),
-        # "f32" = v_mfma_f32_16x16x4_f32, "split" = three bf16 pieces per fp32 operand on v_mfma_f32_16x16x32_bf16, "split_l1" = the same without the LDS ring, "split_f16" = two fp16 pieces / three products on v_mfma_f32_16x16x32_f16 (include/dbfr.h)
+        # "f32" = v_mfma_f32_16x16x4_f32, "split" = three bf16 pieces per fp32 operand on v_mfma_f32_16x16x32_bf16,
+        # "split_f16" = two fp16 pieces / three products on v_mfma_f32_16x16x32_f16, "reduce_first" (the default) = the same arithmetic with the
+        # scalar-output rows reduced over a target's edges before the big GEMM (include/dbfr.h)
         self.gemm = g("gemm", None)
         ns, nv = int(g("ns", 48)), int(g("nv", 12))
         se, de = int(g("sigma_embed_dim", 32)), int(g("distance_embed_dim", 32))
@@ -231,6 +233,10 @@ class TensorProductModelHIP(nn.Module):
             L.check(lib.dbfr_model_create(C.byref(self.mcfg), arr, len(sd), C.byref(h)))
         if self.gemm is not None:
             L.check(lib.dbfr_model_set_gemm(h, GEMM_MODES[self.gemm]))
+        log = getattr(self, "_edge_log", None)
+        if isinstance(log, dict) and ("cuda", idx) in log:      # the edge-count read-out survives a re-pack
+            t = log[("cuda", idx)]
+            L.check(lib.dbfr_model_set_edge_log(h, C.c_void_p(t.data_ptr()), t.shape[0], t.shape[2]))
         self._handles[idx] = (fp, h)
         return h
 
@@ -249,13 +255,16 @@ class TensorProductModelHIP(nn.Module):
         (``dbfr_model_set_edge_log``): returns the device int32 tensor [n_steps, 6, G] the library fills -- sets in the order
         (ligand, pocket, cross lig<-atom, cross atom<-lig, ligand torsion, side-chain torsion).  ``n_steps = 0`` switches it off."""
         dev = torch.device(device)
+        if not isinstance(getattr(self, "_edge_log", None), dict):
+            self._edge_log = {}                              # per device: every handle writes into its own tensor
+        key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
         if n_steps <= 0:
-            L.check(L.load().dbfr_model_set_edge_log(self.handle(dev), None, 0))
-            self._edge_log = None
+            L.check(L.load().dbfr_model_set_edge_log(self.handle(dev), None, 0, 0))
+            self._edge_log.pop(key, None)
             return None
         log = torch.zeros(n_steps, 6, G, dtype=torch.int32, device=dev)
-        L.check(L.load().dbfr_model_set_edge_log(self.handle(dev), C.c_void_p(log.data_ptr()), n_steps))
-        self._edge_log = log          # (kept alive while the library holds the pointer)
+        L.check(L.load().dbfr_model_set_edge_log(self.handle(dev), C.c_void_p(log.data_ptr()), n_steps, G))
+        self._edge_log[key] = log          # (kept alive while the library holds the pointer; a re-packed handle gets it again: handle())
         return log
 
     def set_gemm(self, mode):

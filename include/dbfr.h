@@ -32,7 +32,7 @@ extern "C" {
 
 #define DBFR_ABI_VERSION 4   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
                                 3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only);
-                                4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_test_conv2's message rows in that mode hold segment sums */
+                                4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_model_set_edge_log takes the graph capacity; DBFR_GEMM_SPLIT_BF16_L1 (k_conv2s) retired; dbfr_test_conv2's message rows in that mode hold segment sums */
 
 typedef enum {
   DBFR_OK = 0,
@@ -198,13 +198,14 @@ int dbfr_capacity_report(void* workspace, void* hip_stream, int32_t* first_faile
 
 /* Per-graph read-out of the per-step graphs (dbfr_status_sync's counters are per batch).  With log != NULL every step s < n_steps_cap of
  * the dbfr_sample / dbfr_sample_range calls that follow on this model writes the edge count of graph g in edge set k to
- * log[(s * 6 + k) * G + g] (device int32, caller-owned, >= n_steps_cap * 6 * G entries, G = the batch's graph count), k = {0 ligand
+ * log[(s * 6 + k) * G + g] (device int32, caller-owned, n_steps_cap * 6 * n_graphs_cap entries; a batch whose graph count G differs from
+ * n_graphs_cap is refused with DBFR_ERR_ARG instead of written past the buffer), k = {0 ligand
  * (bonds + radius_graph, tpscore.py:586), 1 pocket (:613), 2 cross lig<-atom, 3 cross atom<-lig (the same pairs, :655-660), 4 ligand
  * torsion (:721), 5 side-chain torsion (:747)}; dbfr_score writes row s = 0.  A set that overflowed its capacity still reports the count
  * it needed.  log == NULL switches the read-out off (the default).  The counts make a hard-cutoff event visible: two runs whose
  * coordinates differ in the 5th decimal build different graphs exactly where a pair sits within rounding distance of a cutoff
  * (tests/test_examples.py).                                                                                                        */
-int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap);
+int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap, int32_t n_graphs_cap);
 
 /* ---- pose initialisation, on the device.
  * Replaces the per-pose real-time transforms LigInit + SCProtInit +
@@ -408,8 +409,6 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
  *                            third of the fp32 instruction's (tools/exp/split_bf16.hip; the tests hold all modes to the same
  *                            tolerances), 2.4x less matrix-pipe time; serves every batch size.  Kernel k_conv2r
  *                            (csrc/conv2r.hip): the W2 pieces reach the waves through an LDS ring, one copy per tile per CU;
- *   DBFR_GEMM_SPLIT_BF16_L1  the same arithmetic with every wave fetching its W2 pieces through the vector L1 (k_conv2s,
- *                            csrc/conv2s.hip): the simpler kernel, ~10 % slower, kept for comparison;
  *   DBFR_GEMM_SPLIT_F16      every operand cut into TWO fp16 pieces (hi = fp16(x), lo = fp16(x - hi): 23 of fp32's 24 significand
  *                            bits) after an exact power-of-two scaling that keeps the pieces inside fp16's exponent range (W2: per
  *                            tensor-product run, at model creation; activations: per edge, in the kernel), three partial products
@@ -426,11 +425,11 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
  *                            MESSAGE BUFFER in this mode: the scalar columns of a segment's FIRST message row hold the segment's SUM, those of
  *                            its other rows are zero (vector columns: per edge as before) -- the per-node reduction (sum of a node's rows /
  *                            their number) is unchanged.  Chunks are cut per graph: what is summed with what never depends on batch mates.
- * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_l1 | split_f16 | reduce_first) says otherwise.
+ * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_f16 | reduce_first) says otherwise.
  * A workspace is laid out for the mode it was sized in: set the mode before dbfr_workspace_bytes.                       */
 #define DBFR_GEMM_F32 0
 #define DBFR_GEMM_SPLIT_BF16 1
-#define DBFR_GEMM_SPLIT_BF16_L1 2
+/* (2 was DBFR_GEMM_SPLIT_BF16_L1, k_conv2s: retired with ABI 4, the number stays unused) */
 #define DBFR_GEMM_SPLIT_F16 3
 #define DBFR_GEMM_REDUCE_FIRST 4
 #define DBFR_GEMM_DEFAULT DBFR_GEMM_REDUCE_FIRST

@@ -2,11 +2,15 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from diffbindfr_amd import dist as ddist
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
 def _free_port():
@@ -52,3 +56,19 @@ def test_gather_over_gloo_world2():
     assert v0 == v1 == [[0.0, 10.0, 0.0], [1.0, 11.0, 0.5]]            # every rank sees every rank's numbers, in rank order
     assert sorted(int(x[0]) for x in a0) == [0, 1, 2, 3, 4]            # every complex gathered exactly once
     assert f0 == [[0.0] * 3] * 2 + [[1.0] * 3] * 2
+
+
+def test_ranks_pin_themselves_to_disjoint_core_slices():
+    """dist.pin_rank_to_cores (8-GPU insurance): eight local ranks take eight disjoint, equally long slices of the cores this process may use;
+    run in child processes so that the test process keeps its own affinity."""
+    import json
+    import subprocess
+    import sys
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 8:
+        pytest.skip("needs sched_setaffinity and at least eight cores")
+    code = ("import json, os, sys; sys.path.insert(0, %r); from diffbindfr_amd import dist as d; "
+            "print(json.dumps([d.pin_rank_to_cores(int(sys.argv[1]), 8), sorted(os.sched_getaffinity(0))]))" % ROOT)
+    got = [json.loads(subprocess.run([sys.executable, "-c", code, str(r)], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]) for r in (0, 3, 7)]
+    for mine, aff in got:
+        assert mine == aff and len(mine) == len(os.sched_getaffinity(0)) // 8
+    assert not (set(got[0][0]) & set(got[1][0])) and not (set(got[1][0]) & set(got[2][0]))

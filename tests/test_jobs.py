@@ -415,6 +415,8 @@ def test_bench_spawns_its_own_ranks():
     assert c["dist_backend"] == "gloo" and c["ranks_seen"] == 2 and c["poses_total"] == 640
     assert sorted(p["rank"] for p in c["per_rank"]) == [0, 1] and sum(p["poses"] for p in c["per_rank"]) == 640
     assert all(p["elapsed_s"] > 0 for p in c["per_rank"])
+    assert all(p["poses_per_sec_sampling"] > 0 and p["poses_per_sec_calibration_batch"] > 0 for p in c["per_rank"])
+    assert 0.3 < c["parallel_efficiency"] <= 1.0 + 1e-6
     # the job table was sharded by the ranks' measured speed (one untimed calibration batch, all-gathered): weights around 1, within +-10 %
     assert len(c["rank_speed"]) == 2 and all(0.9 <= v <= 1.1 for v in c["rank_speed"]) and abs(sum(c["rank_speed"]) - 2.0) < 0.05
     # a launcher environment that contradicts the command line is refused, not silently run
