@@ -650,7 +650,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
 // scalar-input paths first (48 = 3 full tiles), then the vector-input ones, padded to a tile; W2' = lin.3 row x fold, bias as k = 144,
 // every output ROW (irrep, channel) x its own power of two 2^s (largest |value| into [2^14, 2^15)), cut into two fp16 pieces and stored as the
 // A fragments of step B: [c tile][k tile][k-step v][w tile][piece][lane (n' = channel, g')][i] = W2'[c = 16 ct + 4 g' + i % 4,
-// k = 16 kt + 2 v + i / 4, channel 16 wt + n'] -- the order in which step A leaves Z in LDS.
+// k = 16 kt + v + 8 (i / 4), channel 16 wt + n'] -- the order in which step A leaves Z in LDS.
 static int pack_convz(dbfr_model* m, const TMap& tm, const std::string& name, int kind, const ConvW2& base, ConvZ* o) {
   ConvSpec sp = make_conv_spec(kind);
   const int K = sp.K;
@@ -721,7 +721,7 @@ static int pack_convz(dbfr_model* m, const TMap& tm, const std::string& name, in
           for (int v = 0; v < 8; ++v)
             for (int gp = 0; gp < 4; ++gp)
               for (int t = 0; t < 8; ++t) {
-                const float val = wval(16 * ct + 4 * gp + (t & 3), 16 * kt + 2 * v + (t >> 2), w) * sc;   // Z slot (v, g'' = gp, t): k_local = 2 v + t / 4, c_local = 4 g'' + t % 4 (convz.hip)
+                const float val = wval(16 * ct + 4 * gp + (t & 3), 16 * kt + v + 8 * (t >> 2), w) * sc;   // Z slot (v, g'' = gp, t): k_local = v + 8 (t / 4), c_local = 4 g'' + t % 4 (convz.hip)
                 const _Float16 hi = (_Float16)val;
                 const size_t tile = ((size_t)(o->ct0[i] + ct) * CZ_NKT + kt) * 8 + v;
                 const size_t base_h = tile * (CZ_TILE_BYTES / 2) + (size_t)(wt * 2) * 512 + (size_t)(16 * gp + np) * 8 + t;

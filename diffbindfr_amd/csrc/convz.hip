@@ -42,14 +42,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define CH_TAIL_OFF 8192
 #define CH_BIAS_OFF 9216
 
-// Z in LDS, per buffer: [k tile of the pair][piece][column block][k-step v: 1040 B][lane group g'': 256 B][column: 16 B][8 fp16].  Step B reads, for its
-// k-step, 16 B per lane with the columns contiguous; step A writes 8 B per lane (k_local = 2 v + h -> second half of the 16 B, c_local = 4 g'' + q) with the
-// 16 lanes of a write spread over the k-steps: the 1040-byte stride (4 dwords mod 32 banks) makes both conflict-free.
-#define CZ_VSTRIDE 1040
-#define CZ_CB (8 * CZ_VSTRIDE)      // one column block of one piece
+// Z in LDS (fp32, as step A's accumulators leave it), per buffer and column block: [k-step v: 2064 B][lane group g'': 512 B][half h: 256 B][column: 16 B]
+// = 4 values.  Step A's lane (k_local n, group g) writes its four values c_local = 4 g + q as ONE 16-byte store to (v = n & 7, g'' = g,
+// h = n >> 3); step B's lane (column, g'') reads the two halves of its k-step and cuts them into fp16 pieces itself -- the cutting is spread
+// evenly over the eight waves instead of sitting on the wave with the most segments.  The 2064-byte stride (4 dwords mod 32 banks) makes
+// the stores conflict-free, the 256-byte halves / 512-byte groups (0 mod 64 banks) the loads.
+#define CZ_VSTRIDE 2064
+#define CZ_CB (8 * CZ_VSTRIDE)      // one column block
 #define CZ_NCB 3                    // column blocks of 16 per pass: the segments of the workgroup's eight chunks take consecutive columns
-#define CZ_PIECE (CZ_NCB * CZ_CB)
-#define CZ_TILE (2 * CZ_PIECE)      // one (c, k) tile: both pieces, all column blocks
+#define CZ_TILE (CZ_NCB * CZ_CB)    // one (c, k) tile: all column blocks
 #define CZ_KPB 1                    // k tiles per barrier
 #define CZ_BUF (CZ_KPB * CZ_TILE)
 #define CZ_ZBYTES (2 * CZ_BUF)      // two buffers: step A of the next tile writes while step B of this one reads
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       const float* sp = d.sh + (size_t)e_sl * SH_LD;
 #pragma unroll
       for (int k = 0; k < 9; ++k) w_sh[sl * 12 + k] = have ? sp[k] : 0.f;
+      w_sh[sl * 12 + 9] = w_sh[sl * 12 + 10] = w_sh[sl * 12 + 11] = 0.f;
     }
     if (lane == 0) b_nseg[wave] = nseg;
     // ---- zero the scalar columns of the message rows that are not the first of their segment
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
         auto stepA = [&](auto kt_c, int buf) {
           constexpr int kt = decltype(kt_c)::value;
           if (ABL & 4) return;
-          char* zw0 = zb + buf * CZ_BUF + (n >> 1) * CZ_VSTRIDE + g * 256 + (n & 1) * 8;
+          char* zw0 = zb + buf * CZ_BUF + (n & 7) * CZ_VSTRIDE + g * 512 + (n >> 3) * 256;
           const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
           const f16x8 hh = __builtin_bit_cast(f16x8, Hh[kt][0]), hl = __builtin_bit_cast(f16x8, Hh[kt][1]);
           for (int j = j0; j < j1; j += 2) {
@@ -422,22 +424,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
             z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh0, hh, z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh1, hh, z1, 0, 0, 0);
             const int col = cbase + j - c_lo;
-            {
-              unsigned zh0, zl0, zh1, zl1;
-              cz_split2(z0[0] * zs, z0[1] * zs, zh0, zl0);
-              cz_split2(z0[2] * zs, z0[3] * zs, zh1, zl1);
-              char* zw = zw0 + (col >> 4) * CZ_CB + (col & 15) * 16;
-              *reinterpret_cast<u32x2*>(zw) = (u32x2){zh0, zh1};
-              *reinterpret_cast<u32x2*>(zw + CZ_PIECE) = (u32x2){zl0, zl1};
-            }
-            if (two) {
-              unsigned zh0, zl0, zh1, zl1;
-              cz_split2(z1[0] * zs, z1[1] * zs, zh0, zl0);
-              cz_split2(z1[2] * zs, z1[3] * zs, zh1, zl1);
-              char* zw = zw0 + ((col + 1) >> 4) * CZ_CB + ((col + 1) & 15) * 16;
-              *reinterpret_cast<u32x2*>(zw) = (u32x2){zh0, zh1};
-              *reinterpret_cast<u32x2*>(zw + CZ_PIECE) = (u32x2){zl0, zl1};
-            }
+            *reinterpret_cast<f32x4*>(zw0 + (col >> 4) * CZ_CB + (col & 15) * 16) = z0;
+            if (two) *reinterpret_cast<f32x4*>(zw0 + ((col + 1) >> 4) * CZ_CB + ((col + 1) & 15) * 16) = z1;
           }
         };
         using K0 = std::integral_constant<int, 0>;
@@ -454,9 +442,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
             // ---- the NEXT tile's W2' fragments set out into the other register set: a whole tile ahead of their use
             fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last), kt + 1 == KT);
             // ---- step B of tile (ct, kt): my k-step's Z pieces of the first column block (requested first: the step A below runs under their latency)
-            const char* zr = zb + (gq & 1) * CZ_BUF + wave * CZ_VSTRIDE + g * 256 + n * 16;
-            f16x8 zh[2], zl[2];
-            if (mine) { zh[0] = *reinterpret_cast<const f16x8*>(zr); zl[0] = *reinterpret_cast<const f16x8*>(zr + CZ_PIECE); }
+            const char* zr = zb + (gq & 1) * CZ_BUF + wave * CZ_VSTRIDE + g * 512 + n * 16;
+            f32x4 zf[2][2];                                  // [block parity][half]: my k-step's eight Z values of a column block, fp32
+            if (mine) { zf[0][0] = *reinterpret_cast<const f32x4*>(zr); zf[0][1] = *reinterpret_cast<const f32x4*>(zr + 256); }
             // ---- step A of the next tile into the other buffer, and step B of this one: the two waves of a SIMD (w, w + 4) take them in opposite
             // order -- step A is vector-pipe work (masks, cutting Z into pieces), step B matrix-pipe work, and behind a barrier both waves would
             // otherwise want the same pipe at the same time
@@ -470,15 +458,24 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
 #pragma unroll
                 for (int cb = 0; cb < CZ_NCB; ++cb)
                   if (cb < ncb) {
-                    if (cb + 1 < ncb) {                      // the next block's pieces travel under this block's MFMAs
-                      zh[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB);
-                      zl[(cb + 1) & 1] = *reinterpret_cast<const f16x8*>(zr + (cb + 1) * CZ_CB + CZ_PIECE);
+                    if (cb + 1 < ncb) {                      // the next block's values travel under this block's MFMAs
+                      zf[(cb + 1) & 1][0] = *reinterpret_cast<const f32x4*>(zr + (cb + 1) * CZ_CB);
+                      zf[(cb + 1) & 1][1] = *reinterpret_cast<const f32x4*>(zr + (cb + 1) * CZ_CB + 256);
                     }
+                    // x 2^-20 (|Z| <= 32 x 2^15 x 2^15), cut into two fp16 pieces: the B operand of my k-step
+                    unsigned ph[4], pl[4];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                      const f32x4 v = zf[cb & 1][hf];
+                      cz_split2(v[0] * zs, v[1] * zs, ph[2 * hf], pl[2 * hf]);
+                      cz_split2(v[2] * zs, v[3] * zs, ph[2 * hf + 1], pl[2 * hf + 1]);
+                    }
+                    const f16x8 zh = __builtin_bit_cast(f16x8, (u32x4){ph[0], ph[1], ph[2], ph[3]}), zl = __builtin_bit_cast(f16x8, (u32x4){pl[0], pl[1], pl[2], pl[3]});
 #pragma unroll
                     for (int wt = 0; wt < 3; ++wt) {
-                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zl[cb & 1], acc[wt][cb], 0, 0, 0);
-                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][1]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
-                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zh[cb & 1], acc[wt][cb], 0, 0, 0);
+                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zl, acc[wt][cb], 0, 0, 0);
+                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][1]), zh, acc[wt][cb], 0, 0, 0);
+                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zh, acc[wt][cb], 0, 0, 0);
                     }
                   }
               }

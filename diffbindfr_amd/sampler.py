@@ -86,17 +86,18 @@ class DiffBindFRHIP(nn.Module):
         return self._sched
 
     @torch.no_grad()
-    def sample_packed(self, pb, noise, visualize=False, sync=True):
+    def sample_packed(self, pb, noise, visualize=False, sync=True, stop=None):
         """Run the sampler on an already packed batch.  ``noise``: dict of device tensors
         tr[T,G,3], rot[T,G,3], tor[T,max(NTOR,1)], sc[T,max(NSC,1)].  Returns device tensors
-        (lig_traj [T',NL,3], atom14_traj [T',NR,14,3]) with T' = 1 unless ``visualize``."""
+        (lig_traj [T',NL,3], atom14_traj [T',NR,14,3]) with T' = 1 unless ``visualize``.  ``stop``: run steps [0, stop) only
+        (dbfr_sample_range); ``pb`` then holds the state entering step ``stop``."""
         lib = L.load()
         model = self.diffusion_model
         dev = pb.lig_pos.device
         if dev.type != "cuda":
             raise L.DbfrError("DiffBindFRHIP needs a ROCm device (no CPU path)")
         recs, steps = self.schedule()
-        T = len(recs)
+        T = len(recs) if stop is None else max(1, min(int(stop), len(recs)))
         d = pb.dims
         with torch.cuda.device(dev):        # everything the library creates (streams, events, weights) follows the current device
             a14 = torch.zeros(d["NR"], 14, 3, device=dev)
@@ -198,7 +199,7 @@ class DiffBindFRHIP(nn.Module):
 
     @torch.no_grad()
     def run_complexes(self, records, poses, device="cuda:0", seed=None, visualize=False, tr_sigma_max=10.0, job_ids=None,
-                      seeds=None, pose_ranges=None, tapes=None):
+                      seeds=None, pose_ranges=None, tapes=None, stop=None):
         """``sample_complexes`` without the per-graph split: (packed batch, lig [T,NL,3], atom14 [T,NR,14,3]) on the device;
         graphs are complex-major, so the poses of complex c are rows ``pb.lig_ptr_host[g0] .. [g0 + poses_c]``.
         ``pose_ranges`` / ``tapes``: see ``draw_tapes`` (a job cut into several batches by ``dist.run_sharded``; recorded tapes)."""
@@ -214,7 +215,7 @@ class DiffBindFRHIP(nn.Module):
             pb = assemble.assemble(recs, poses, dev)
             init, z = self.draw_tapes(recs, poses, seeds, dev, tr_sigma_max, pose_ranges, tapes)
             assemble.init_poses(self.diffusion_model, pb, init)
-            lig, a14 = self.sample_packed(pb, z, visualize=visualize)
+            lig, a14 = self.sample_packed(pb, z, visualize=visualize, stop=stop)
         return pb, lig, a14
 
     def _split(self, pb, lig, a14):

@@ -82,14 +82,16 @@ def sde_step(data, sc, scores, z, t_idx, atom14_to_group):
 
 
 def sample(params, mcfg, scfg, data, noise, atom14_to_group, torus_seed=0, visualize=False,
-           score_tap=None):
+           score_tap=None, first_step=0):
     """Returns (lig_traj [T,N_l_total,3], atom14_traj [T,N_res_total,14,3]) with T=1
     unless ``visualize`` (scFlex.py:193-194,227-230).  ``score_tap(t_idx, scores)`` is an
-    optional callback (used by parity tests to compare per-step scores)."""
+    optional callback (used by parity tests to compare per-step scores).  ``first_step``: resume the
+    reverse SDE at that step from the state ``data`` holds (tests/test_examples.py: the oracle re-run from
+    the library's own coordinates after a hard-cutoff event); the noise tape is indexed by the absolute step."""
     G = int(data.lig_node_batch.max().item()) + 1
     lig_out, a14_out = [], []
     with torch.no_grad():
-        for t_idx in range(scfg.actual_steps):
+        for t_idx in range(first_step, scfg.actual_steps):
             sc = schedule.step_scalars(scfg, t_idx, torus_seed)
             _data = set_time(copy.deepcopy(data), sc, G)
             scores = score_model.forward(params, mcfg, _data)

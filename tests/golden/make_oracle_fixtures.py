@@ -1,12 +1,16 @@
 """Fixtures the ORACLE generates (no reference needed, so this runs anywhere -- e.g. on the GPU box's 128 host threads):
 
-    python tests/golden/make_oracle_fixtures.py [out_dir [5] [2]]
+    python tests/golden/make_oracle_fixtures.py [out_dir [5] [2] [25] [55]]
 
   cfg5_traj.npz   BASELINE.json configs[4] (large pocket: ~600 pocket atoms / ~80 ligand atoms, flexible side chains), one complex x
                   one pose, all 20 reverse-diffusion steps through oracle/sampler.py (pinned on the reference's own sample(), see
                   make_golden.py): collated batch + noise tape + ligand trajectory + first / last atom14 frame.  Replayed by
                   tests/test_gpu_parity.py::test_cfg_shape_trajectory_matches_the_oracle_fixture at 1e-3 A.
   cfg2_traj.npz   the same for configs[1] (PoseBusters shape: ~200 pocket atoms / ~30 ligand atoms) -- the shape the bench line is quoted on.
+  cfg2_batch_traj.npz (argument 25)  configs[1] as a BATCH: 3 complexes of ragged sizes x 2 poses (6 graphs) in one collated batch, 20 steps --
+                  batch-level indexing (CSR pointers, per-graph chunks of the reduce-first conv, per-graph noise) at the BASELINE shape against
+                  the oracle, not only against the library itself.
+  cfg5_batch_traj.npz (argument 55)  configs[4] likewise: 2 complexes x 2 poses.
 """
 import copy
 import os
@@ -26,8 +30,8 @@ def npy(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
 
-def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False):
-    """One complex x one pose of the named config through all 20 steps.  `robust`: the reference algorithm's graphs have hard cutoffs, so a
+def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False, n_complex=1, poses=1, tag="traj"):
+    """n_complex x poses graphs (default: one complex x one pose) of the named config through all 20 steps.  `robust`: the reference algorithm's graphs have hard cutoffs, so a
     trajectory that passes within rounding distance of a cutoff event jumps by 1e-3 .. 1e-2 A under ANY rounding-sized change
     (tests/tools/example_sensitivity.py) and is useless as a 1e-3 A fixture; a seed is accepted only if a second oracle run from initial
     ligand coordinates moved by N(0, 1e-5 A) stays within 3e-4 A of the first at every step (otherwise the next seed is tried)."""
@@ -37,7 +41,7 @@ def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False):
     scfg = schedule.default_sample_cfg()
     a14g = torch.from_numpy(T["atom14_to_group"]).long()
     for attempt in range(8):
-        d = synthetic.make_batch(cfg_id, n_complex=1, poses=1, seed=seed + 1000 * attempt)
+        d = synthetic.make_batch(cfg_id, n_complex=n_complex, poses=poses, seed=seed + 1000 * attempt)
         G = d.num_graphs
         n_tor, n_sc = int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum())
         noise = sampler.draw_noise(scfg.actual_steps, G, n_tor, n_sc, seed=noise_seed)
@@ -50,7 +54,7 @@ def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False):
         d2 = copy.deepcopy(d)
         d2.lig_pos = d.lig_pos + 1e-5 * torch.randn(d.lig_pos.shape, generator=torch.Generator().manual_seed(9))
         lig2, _ = sampler.sample(params, mcfg, scfg, d2, noise, a14g, visualize=True)
-        dev = (lig2 - lig).norm(dim=-1).amax(dim=1)
+        dev = (lig2 - lig).norm(dim=-1).amax(dim=1)      # (over the atoms of ALL graphs: one graph near a cutoff rejects the seed)
         print("  second run from initial coordinates moved by N(0, 1e-5 A): max deviation per step", " ".join(f"{x:.0e}" for x in dev.tolist()))
         if float(dev.max()) < 3e-4:
             break
@@ -65,7 +69,7 @@ def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False):
                traj_lig=npy(lig).astype(np.float32), atom14_step0=npy(a14[0]).astype(np.float32), final_atom14=npy(a14[-1]).astype(np.float32))
     for k in ("default_frame", "rigid_group_positions"):
         out[k] = out[k].astype(np.float32)
-    path = os.path.join(out_dir, f"cfg{cfg_id}_traj.npz")
+    path = os.path.join(out_dir, f"cfg{cfg_id}_{tag}.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path) // 1024, "KiB")
 
@@ -73,8 +77,12 @@ def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False):
 if __name__ == "__main__":
     out_dir = sys.argv[1] if len(sys.argv) > 1 else HERE
     os.makedirs(out_dir, exist_ok=True)
-    which = [int(x) for x in sys.argv[2:]] or [5, 2]
+    which = [int(x) for x in sys.argv[2:]] or [5, 2, 25, 55]
     if 5 in which:
         cfg_trajectory(out_dir, 5, 505, 55)      # (the arguments cfg5_traj.npz was generated with)
     if 2 in which:
         cfg_trajectory(out_dir, 2, 202, 22, robust=True)
+    if 25 in which:
+        cfg_trajectory(out_dir, 2, 212, 23, robust=True, n_complex=3, poses=2, tag="batch_traj")
+    if 55 in which:
+        cfg_trajectory(out_dir, 5, 515, 56, robust=True, n_complex=2, poses=2, tag="batch_traj")

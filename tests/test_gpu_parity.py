@@ -737,17 +737,20 @@ def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, 
     assert err["split_f16"] <= err["f32"] and rms["split_f16"] <= rms["f32"], (err, rms)
 
 
-@pytest.mark.parametrize("cfg_id,min_atoms,min_lig", [(5, 500, 60), (2, 150, 20)])
-def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms, min_lig):
+@pytest.mark.parametrize("cfg_id,min_atoms,min_lig,tag", [(5, 500, 60, "traj"), (2, 150, 20, "traj"), (2, 3 * 150, 3 * 20, "batch_traj"), (5, 2 * 500, 2 * 60, "batch_traj")])
+def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms, min_lig, tag):
     """BASELINE configs[4] (~600 pocket atoms / ~80 ligand atoms) and configs[1] (~200 / ~30: the shape the bench line is quoted on) at
     their own shapes: tests/golden/cfg{5,2}_traj.npz hold one complex x one pose taken through all 20 steps by the ORACLE
     (tests/golden/make_oracle_fixtures.py, generated offline on host cores).  The HIP sampler must follow the ligand trajectory and
-    end on the same side chains within 1e-3 A, in every GEMM mode."""
+    end on the same side chains within 1e-3 A, in every GEMM mode.  `batch_traj` (round 5): the same for a BATCH at those shapes -- 3 ragged
+    complexes x 2 poses of configs[1], 2 x 2 of configs[4], one collated batch through the oracle -- so that batch-level indexing (CSR
+    pointers, the per-graph edge chunks of the reduce-first conv, per-graph noise rows) is held to the oracle at full shape, not only to the
+    library itself (default mode + the fp32 instruction)."""
     import os
     from tests.helpers import GOLDEN
-    path = os.path.join(GOLDEN, f"cfg{cfg_id}_traj.npz")
+    path = os.path.join(GOLDEN, f"cfg{cfg_id}_{tag}.npz")
     if not os.path.exists(path):
-        pytest.skip(f"cfg{cfg_id}_traj.npz not generated (tests/golden/make_oracle_fixtures.py)")
+        pytest.skip(f"cfg{cfg_id}_{tag}.npz not generated (tests/golden/make_oracle_fixtures.py)")
     d, z = load_golden_batch(path)
     assert int(d.rec_atm_pos.shape[0]) >= min_atoms and int(d.lig_pos.shape[0]) >= min_lig
     params = sm.init_params(sm.default_cfg(), seed=int(z["params_seed"]))
@@ -756,7 +759,7 @@ def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms,
     samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
     noise = {k: torch.from_numpy(z[f"noise_{k}"]).to(dev).contiguous() for k in ("tr", "rot", "tor", "sc")}
     noise = {k: (v if v.shape[1] else torch.zeros(v.shape[0], 1, device=dev)) for k, v in noise.items()}
-    for mode in ("split_f16", "split", "f32"):
+    for mode in (("reduce_first", "split_f16", "split", "f32") if tag == "traj" else ("reduce_first", "f32")):
         model.set_gemm(mode)
         pb = PackedBatch(namespace_to(d, dev), dev)
         lig, a14 = samp.sample_packed(pb, noise, visualize=True)
