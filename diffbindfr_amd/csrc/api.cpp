@@ -37,6 +37,7 @@ void dbfr_edge_form(const dbfr_batch& b, int* n_chunk, int* lanes);
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
 void launch_edge_log(const GraphArgs& A, int* log_row, hipStream_t st);
 void launch_graph_chunks(const GraphArgs& A, hipStream_t st);
+void launch_row_absmax(const float* x, int ld, int D, const int* ptr, int G, float* out, hipStream_t st);
 void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
                           int* tor_batch, int* sc_batch, hipStream_t st);
 void launch_time_embed(const float* t, int G, float emb_scale, float* temb, hipStream_t st);
@@ -941,6 +942,7 @@ struct Ws {
   // centre set
   int *c_tgt, *c_gth, *c_row_start, *c_row_cnt, *c_n; float *c_dist, *c_sh, *c_emb;
   float* msg[4]; int multi; int conv2; float* gp; float *tor_attr, *sc_attr, *tor_feat, *sc_feat;
+  float *xmax_l, *xmax_a;   // [G] largest |feature| of every graph's ligand / pocket nodes in the current layer (k_row_absmax; k_convz's y scale)
   int* n_edges6;  // [8] device counters
 };
 
@@ -1004,6 +1006,7 @@ static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim
   } else
   for (int i = 0; i < 4; ++i) w->msg[i] = (i == 0 || w->multi) ? b.take<float>((size_t)maxcap * MAXD, i == 0 ? "msg" : nullptr) : nullptr;
   w->gp = b.take<float>((size_t)G * 12, "gp");
+  w->xmax_l = b.take<float>(G, "xmax_l"); w->xmax_a = b.take<float>(G, "xmax_a");
   w->tor_attr = b.take<float>((size_t)(B->NTOR + 1) * NS, "tor_attr"); w->sc_attr = b.take<float>((size_t)(B->NSC + 1) * NS);
   w->tor_feat = b.take<float>((size_t)(B->NTOR + 1) * 2 * NS, "tor_feat"); w->sc_feat = b.take<float>((size_t)(B->NSC + 1) * 2 * NS);
   *need_bytes = b.off + 256;
@@ -1073,11 +1076,12 @@ static Conv2Desc conv2_desc(const ConvW2& cw, const int* n_edges, int max_edges,
   return d;
 }
 
-static ConvZDesc convz_desc(const Conv2Desc& d, const ConvZ& z, const int* tgt, int D_out, const int* chunk0 = nullptr, const int* gedge0 = nullptr, int n_graph = 0) {
+static ConvZDesc convz_desc(const Conv2Desc& d, const ConvZ& z, const int* tgt, int D_out, const int* chunk0 = nullptr, const int* gedge0 = nullptr, int n_graph = 0,
+                            const float* xmax = nullptr) {
   ConvZDesc o;
   o.n_edges = d.n_edges; o.max_edges = d.max_edges; o.tgt = tgt; o.gth = d.gth; o.emb = d.emb; o.sh = d.sh;
   o.tab1 = d.tab1; o.ld1 = d.ld1; o.idx1 = d.idx1; o.tab2 = d.tab2; o.ld2 = d.ld2; o.idx2 = d.idx2; o.x = d.x; o.ldx = d.ldx;
-  o.w = z; o.msg = d.msg; o.D_out = D_out; o.chunk0 = chunk0; o.gedge0 = gedge0; o.n_graph = n_graph;
+  o.w = z; o.msg = d.msg; o.D_out = D_out; o.chunk0 = chunk0; o.gedge0 = gedge0; o.n_graph = n_graph; o.xmax = xmax;
   return o;
 }
 
@@ -1202,8 +1206,12 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
           conv2_desc(L2[2], AA.n_edges, AA.cap, AA.gth, AA.emb, AA.sh, ax, Di, AA.tgt, ax, Di, AA.gth, ax, Di, w.msg[2]),
           conv2_desc(L2[3], LA.n_edges, LA.cap, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3])};
       const int Ws[4] = {m->layer[l][0].W, m->layer[l][1].W, m->layer[l][2].W, m->layer[l][3].W};
-      const ConvZDesc zs[4] = {convz_desc(ds[0], m->layerz[l][0], LL.tgt, Do, LL.chunk0, LL.gedge0, G), convz_desc(ds[1], m->layerz[l][1], AL.tgt, Do, AL.chunk0, AL.gedge0, G),
-                               convz_desc(ds[2], m->layerz[l][2], AA.tgt, Do, AA.chunk0, AA.gedge0, G), convz_desc(ds[3], m->layerz[l][3], LA.tgt, Do, LA.chunk0, LA.gedge0, G)};
+      if (rf) {   // the y scale of k_convz: largest |x| per graph and node set (x = the rows a conv gathers: LL, LA read ligand rows, AL, AA pocket rows)
+        launch_row_absmax(lx, Di, Di, B->lig_ptr, G, w.xmax_l, st);
+        launch_row_absmax(ax, Di, Di, B->atm_ptr, G, w.xmax_a, st);
+      }
+      const ConvZDesc zs[4] = {convz_desc(ds[0], m->layerz[l][0], LL.tgt, Do, LL.chunk0, LL.gedge0, G, w.xmax_l), convz_desc(ds[1], m->layerz[l][1], AL.tgt, Do, AL.chunk0, AL.gedge0, G, w.xmax_a),
+                               convz_desc(ds[2], m->layerz[l][2], AA.tgt, Do, AA.chunk0, AA.gedge0, G, w.xmax_a), convz_desc(ds[3], m->layerz[l][3], LA.tgt, Do, LA.chunk0, LA.gedge0, G, w.xmax_l)};
       conv2_call(m, ds, Ws, 4, st, (m->layer_fallback >> l) & 1u, rf ? zs : nullptr);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
@@ -1302,6 +1310,10 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     const bool do_t = B->NTOR > 0, do_s = !cfg.no_sc_torsion && B->NSC > 0;
     const bool rf = m->gemm_split == DBFR_GEMM_REDUCE_FIRST && !((m->layer_fallback >> 31) & 1u);
     Conv2Desc ds[2]; ConvZDesc zs[2]; int Ws[2]; int nd = 0;
+    if (rf) {
+      launch_row_absmax(lx, D, D, B->lig_ptr, G, w.xmax_l, st);
+      launch_row_absmax(ax, D, D, B->atm_ptr, G, w.xmax_a, st);
+    }
     if (do_t) {
       launch_bond_attr(lx, D, B->bond_src, B->bond_dst, B->tor_bond, 0, B->NTOR, w.tor_attr, st);
       MlpArgs a; memset(&a, 0, sizeof a);
@@ -1309,7 +1321,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_lig_off; a.gs_coeff = m->gs_lig_c; a.out = T.emb;
       launch_mlp(a, st);
       ds[nd] = conv2_desc(m->tor_conv2, T.n_edges, T.cap, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg[0]);
-      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->tor_convz, T.tgt, 2 * NS, T.chunk0, T.gedge0, G); }   // (all outputs of a torsion conv are scalars)
+      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->tor_convz, T.tgt, 2 * NS, T.chunk0, T.gedge0, G, w.xmax_l); }   // (all outputs of a torsion conv are scalars)
       Ws[nd++] = m->tor_conv.W;
     }
     if (do_s) {
@@ -1319,7 +1331,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_atom_off; a.gs_coeff = m->gs_atom_c; a.out = S.emb;
       launch_mlp(a, st);
       ds[nd] = conv2_desc(m->sc_conv2, S.n_edges, S.cap, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg[1]);
-      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->sc_convz, S.tgt, 2 * NS, S.chunk0, S.gedge0, G); }
+      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->sc_convz, S.tgt, 2 * NS, S.chunk0, S.gedge0, G, w.xmax_a); }
       Ws[nd++] = m->sc_conv.W;
     }
     if (nd) conv2_call(m, ds, Ws, nd, st, (m->layer_fallback >> 31) & 1u, rf ? zs : nullptr);

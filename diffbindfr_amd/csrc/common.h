@@ -145,6 +145,7 @@ struct ConvZDesc {
   const int* chunk0;      // [n_graph + 1] first 32-edge chunk of every graph (chunks are cut per graph: batch-independent sums), or null: one graph
   const int* gedge0;      // [n_graph + 1] first edge of every graph
   int n_graph;
+  const float* xmax;      // [n_graph] largest |x| over the rows of every graph (k_row_absmax), or null: the kernel reads the chunk's gathered rows itself
 };
 struct ConvZArgs { ConvZDesc c[4]; int n_conv; float* dbg; double* executed; };   // executed (profiling only): += flops of the matrix instructions issued   // dbg (developer, DBFR_CONVZ_DEBUG=<file>): workgroup 0 / wave 0 of the first unit dumps h [32 slots][144]
 

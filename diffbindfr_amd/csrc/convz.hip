@@ -93,6 +93,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
   int* b_col_edge = b_nseg + NW;                            // [48] message row of the column's segment, -1: column unused
   float* b_col_inv = reinterpret_cast<float*>(b_col_edge + 16 * CZ_NCB);   // [48] takes the chunk's factors off
 
+  // developer timeline (ABL & 128, DBFR_CONVZ_DEBUG=<file>): s_memtime stamps of workgroup 0's first unit, [wave][stamp] unsigned long long in a.dbg
+  int tr_n = 0;
+  auto stamp = [&](int tag) {
+    if constexpr ((ABL & 128) != 0) {
+      if (a.dbg && blockIdx.x == 0 && lane == 0 && tr_n < 1000) {
+        unsigned long long* t = reinterpret_cast<unsigned long long*>(a.dbg) + wave * 1024;
+        t[tr_n++] = (__builtin_amdgcn_s_memtime() << 8) | (unsigned)tag;
+      }
+    }
+  };
   // ---- unit list: NW chunks of 32 edges per unit, conv after conv
   int nch[4] = {0, 0, 0, 0}, nu[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -112,11 +122,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     const int E = min(*d.n_edges, d.max_edges);
     // ---- my chunk: edges [es, es + len)
     const int ch = ul * NW + wave;
-    int es = 0, len = 0;
+    int es = 0, len = 0, gidx = 0;
     if (ch < nch[c]) {
       if (d.chunk0) {
         int lo = 0, hi = d.n_graph - 1;                      // the graph whose chunk range holds ch
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.chunk0[mid] <= ch) lo = mid; else hi = mid - 1; }
+        gidx = lo;
         es = d.gedge0[lo] + 32 * (ch - d.chunk0[lo]);
         len = min(32, d.gedge0[lo + 1] - es);
       } else {
@@ -126,6 +137,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       len = max(len, 0);
     }
     __syncthreads();   // nothing of the last unit still reads the block-level arrays
+    if (unit != (int)blockIdx.x) tr_n = 1000;                // (the first unit only)
+    stamp(1);
     // ---- slots: lanes 0..31 own slot L (clamped to the chunk's last edge beyond its length; a chunk without edges reads edge 0 of a non-empty conv or nothing)
     const int sl = lane & 31;
     const bool have = len > 0;
@@ -163,11 +176,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     // ---- bounds for the y scale: largest |x| over the gathered rows, largest |harmonic|
     float xmx = 0.f, smx = 0.f;
     if (have) {
-      const float* xr = d.x + (size_t)gth_l * d.ldx;
-      const int d4 = d.ldx >> 2;
-      for (int j = lane >> 5; j < d4; j += 2) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * j);
-        xmx = fmaxf(fmaxf(xmx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      if (d.xmax) xmx = d.xmax[gidx];                       // per graph, computed once per layer (k_row_absmax): no pass over the gathered rows here
+      else {
+        const float* xr = d.x + (size_t)gth_l * d.ldx;
+        const int d4 = d.ldx >> 2;
+        for (int j = lane >> 5; j < d4; j += 2) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * j);
+          xmx = fmaxf(fmaxf(xmx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
       }
       if (lane < 32) {
         const float* sp = d.sh + (size_t)e_sl * SH_LD;
@@ -180,6 +196,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     if (xmx > 0.f && smx > 0.f) ey = max(-100, min(100, 13 - __builtin_amdgcn_frexp_expf(xmx) - __builtin_amdgcn_frexp_expf(smx)));
     const float sY = __builtin_amdgcn_ldexpf(1.f, ey);
 
+    stamp(2);
     // ---- hidden layer, transposed: D[edge, unit] = sum_f a[edge, f] W1[unit, f]; A = the edge's inputs (cut per edge), B = W1h tiles
     u32x4 Hh[CZ_NKT][2];                                     // H pieces [k tile][hi, lo]: lane (unit n, group g), eight edges {4g..4g+3, 16+4g..16+4g+3}
     int eh = 0;                                              // the factor on h is 2^(15 - ehc + k1) = phi, also what the constant 1 of the bias becomes
@@ -232,47 +249,60 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       float Hf[KT][2][4];
       float hmx = 0.f;
       const int vW = lane * 16;
-#pragma unroll
-      for (int m = 0; m < KT; ++m) {
-        const float bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW1, n * 4, m * CH_TILE_BYTES + CH_BIAS_OFF, 0));
-        f32x4 acc[2];
-#pragma unroll
-        for (int et = 0; et < 2; ++et)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[et][q] = bias * sar[et][q];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const f16x8 whi = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + s * 1024, 0));
-          const f16x8 wlo = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + (4 + s) * 1024, 0));
+      // W1 fragments: step i = 5 m + s (s < 4: the k-step of 32 of tile m, hi and lo piece; s = 4: the tile's last 16 k [hi | lo] and, in the second
+      // register, my unit's bias) through a ring of three register pairs, requested TWO steps ahead of their MFMAs (a load next to its use waits
+      // out the L1 / L2 latency 45 times per chunk: 59 k of the unit's 270 k cycles in the timeline of round 5)
+      u32x4 F[3][2];
+      auto ldF = [&](auto ic) {
+        constexpr int i = decltype(ic)::value, m = i / 5, sx = i % 5;
+        if constexpr (sx < 4) {
+          F[i % 3][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + sx * 1024, 0));
+          F[i % 3][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + (4 + sx) * 1024, 0));
+        } else {
+          F[i % 3][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + CH_TAIL_OFF, 0));
+          F[i % 3][1][0] = __builtin_amdgcn_raw_buffer_load_b32(rW1, n * 4, m * CH_TILE_BYTES + CH_BIAS_OFF, 0);
+        }
+      };
+      ldF(std::integral_constant<int, 0>{});
+      ldF(std::integral_constant<int, 1>{});
+      // (tile m's bias arrives with its LAST step; the accumulators start from zero and the bias x the edge's factor is added behind the tile)
+      f32x4 acc[2];
+      cz_static_for<0, 5 * KT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, m = i / 5, sx = i % 5;
+        if constexpr (i + 2 < 5 * KT) ldF(std::integral_constant<int, (i + 2 < 5 * KT ? i + 2 : 0)>{});
+        if constexpr (sx == 0) { acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if constexpr (sx < 4) {
+          const f16x8 whi = __builtin_bit_cast(f16x8, F[i % 3][0]), wlo = __builtin_bit_cast(f16x8, F[i % 3][1]);
 #pragma unroll
           for (int et = 0; et < 2; ++et) {
-            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][1][s]), whi, acc[et], 0, 0, 0);
-            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][0][s]), wlo, acc[et], 0, 0, 0);
-            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][0][s]), whi, acc[et], 0, 0, 0);
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][1][sx]), whi, acc[et], 0, 0, 0);
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][0][sx]), wlo, acc[et], 0, 0, 0);
+            acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Ah[et][0][sx]), whi, acc[et], 0, 0, 0);
           }
-        }
-        {   // k = 128..143: W tail fragment = [hi (4) | lo (4)], input tail = [lo | hi]: one x32 MFMA carries both small products
-          const u32x4 wt = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rW1, vW, m * CH_TILE_BYTES + CH_TAIL_OFF, 0));
-          // (the large product on the x32 instruction too, upper half of the operands zero: an x16 MFMA that takes as SrcC an accumulator an
-          // x32 MFMA has just written reads stale data on MI355X + ROCm 7.2 -- conv2r.hip -- and 18 half-empty MFMAs per chunk cost nothing)
+        } else {
+          // k = 128..143: W tail fragment = [hi (4) | lo (4)], input tail = [lo | hi]: one x32 MFMA carries both small products; the large product
+          // on the x32 instruction too, upper half of the operands zero (an x16 MFMA that takes as SrcC an accumulator an x32 MFMA has just
+          // written reads stale data on MI355X + ROCm 7.2 -- conv2r.hip -- and 18 half-empty MFMAs per chunk cost nothing)
+          const u32x4 wt = F[i % 3][0];
           const f16x8 wf = __builtin_bit_cast(f16x8, wt);
           const f16x8 wh = __builtin_bit_cast(f16x8, (u32x4){wt[0], wt[1], 0u, 0u});
+          const float bias = __builtin_bit_cast(float, F[i % 3][1][0]);
 #pragma unroll
           for (int et = 0; et < 2; ++et) {
             acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Atc[et]), wf, acc[et], 0, 0, 0);
             acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (u32x4){Atc[et][2], Atc[et][3], 0u, 0u}), wh, acc[et], 0, 0, 0);
           }
+#pragma unroll
+          for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float v = fmaxf(acc[et][q] + bias * sar[et][q], 0.f) * uar[et][q];   // = 2^k1 h
+              Hf[m][et][q] = v;
+              hmx = fmaxf(hmx, v);
+            }
         }
-#pragma unroll
-        for (int et = 0; et < 2; ++et)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float v = fmaxf(acc[et][q], 0.f) * uar[et][q];   // = 2^k1 h
-            Hf[m][et][q] = v;
-            hmx = fmaxf(hmx, v);
-          }
-      }
-      if (a.dbg && unit == 0 && wave == 0) {
+      });
+      if (!(ABL & 128) && a.dbg && unit == 0 && wave == 0) {
         const float k1i = __builtin_amdgcn_ldexpf(1.f, -W.k1);
 #pragma unroll
         for (int m = 0; m < KT; ++m)
@@ -312,6 +342,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       Hh[KT][0] = hb;
       Hh[KT][1] = (u32x4){0u, 0u, 0u, 0u};
     }
+    stamp(3);
     // ---- masks of my segments on the registers of the A operand (halves of a dword = two consecutive slots), for every lane group
     for (int idx = lane; idx < nseg * 16; idx += 64) {
       const int j = idx >> 4, gg = (idx >> 2) & 3, r = idx & 3, t0 = 2 * r;
@@ -411,6 +442,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
           char* zw0 = zb + buf * CZ_BUF + (n & 7) * CZ_VSTRIDE + g * 512 + (n >> 3) * 256;
           const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
           const f16x8 hh = __builtin_bit_cast(f16x8, Hh[kt][0]), hl = __builtin_bit_cast(f16x8, Hh[kt][1]);
+          auto zcol = [&](int col) { return zw0 + (col >> 4) * CZ_CB + (col & 15) * 16; };
+          // (tried: four segments side by side while three or more are left -- 158 spilled registers, 442 -> 422 poses/s)
           for (int j = j0; j < j1; j += 2) {
             const bool two = j + 1 < j1;
             const u32x4 m0 = *reinterpret_cast<const u32x4*>(w_mask + (j * 4 + g) * 4);
@@ -424,8 +457,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
             z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh0, hh, z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh1, hh, z1, 0, 0, 0);
             const int col = cbase + j - c_lo;
-            *reinterpret_cast<f32x4*>(zw0 + (col >> 4) * CZ_CB + (col & 15) * 16) = z0;
-            if (two) *reinterpret_cast<f32x4*>(zw0 + ((col + 1) >> 4) * CZ_CB + ((col + 1) & 15) * 16) = z1;
+            *reinterpret_cast<f32x4*>(zcol(col)) = z0;
+            if (two) *reinterpret_cast<f32x4*>(zcol(col + 1)) = z1;
           }
         };
         using K0 = std::integral_constant<int, 0>;
@@ -480,9 +513,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
                   }
               }
             };
-            if (wave < NW / 2 && !(ABL & 64)) { nextA(); thisB(); } else { thisB(); nextA(); }
+            stamp(10);
+            if (wave < NW / 2 && !(ABL & 64)) { nextA(); stamp(11); thisB(); stamp(12); } else { thisB(); stamp(12); nextA(); stamp(11); }
             ++gq;
             if (!(ABL & 2)) __syncthreads();                 // the next tile's Z is complete; this tile's buffer may be written again
+            stamp(13);
           });
         }
         // ---- the output irrep is complete: add the eight waves' partial sums, take the factors off, store into the segments' first rows
@@ -521,9 +556,9 @@ void launch_convz(const ConvZArgs& a0, hipStream_t st) {
   static float* dbg_dev = nullptr;
   static const char* dbg_file = getenv("DBFR_CONVZ_DEBUG");
   if (dbg_file && !dbg_dev) {
-    if (hipMalloc(&dbg_dev, 32 * 144 * sizeof(float)) != hipSuccess) dbg_dev = nullptr;
+    if (hipMalloc(&dbg_dev, 8 * 1024 * 8) != hipSuccess || hipMemset(dbg_dev, 0, 8 * 1024 * 8) != hipSuccess) dbg_dev = nullptr;
     else atexit([] {
-      std::vector<float> h(32 * 144);
+      std::vector<float> h(8 * 1024 * 2);
       if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), dbg_dev, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
         if (FILE* f = fopen(getenv("DBFR_CONVZ_DEBUG"), "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
     });
@@ -534,7 +569,7 @@ void launch_convz(const ConvZArgs& a0, hipStream_t st) {
                hipLaunchKernelGGL((k_convz<NW, x>), dim3(dbfr_current_cu_count()), dim3(64 * NW), lds, st, a); return; }
 #ifdef DBFR_DEV_VARIANTS
   static int abl = getenv("DBFR_CONVZ_ABL") ? atoi(getenv("DBFR_CONVZ_ABL")) : 0;
-  if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 4) V(4) if (abl == 8) V(8) if (abl == 16) V(16) if (abl == 32) V(32) if (abl == 12) V(12) if (abl == 5) V(5) if (abl == 64) V(64)
+  if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 4) V(4) if (abl == 8) V(8) if (abl == 16) V(16) if (abl == 32) V(32) if (abl == 12) V(12) if (abl == 5) V(5) if (abl == 64) V(64) if (abl == 128) V(128)
 #endif
   V(0)
 #undef V

@@ -461,6 +461,27 @@ void launch_graph_chunks(const GraphArgs& A0, hipStream_t st) {
   hipLaunchKernelGGL(k_graph_chunks, dim3(N_SETS), dim3(256), 0, st, A);
 }
 
+// Largest |feature| over the node rows [ptr[g], ptr[g + 1]) of every graph: the bound k_convz scales its y operand with.  Per GRAPH, not per
+// batch: a power of two derived from it must not depend on batch mates.  One workgroup per graph.
+__global__ __launch_bounds__(256) void k_row_absmax(const float* x, int ld, int D, const int* ptr, float* out) {
+  __shared__ float sm[4];
+  const int g = blockIdx.x, r0 = ptr[g], r1 = ptr[g + 1];
+  const int d4 = D >> 2;
+  float m = 0.f;
+  for (long i = threadIdx.x; i < (long)(r1 - r0) * d4; i += 256) {
+    const int r = (int)(i / d4), c = (int)(i - (long)r * d4);
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + r) * ld + 4 * c);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[g] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+void launch_row_absmax(const float* x, int ld, int D, const int* ptr, int G, float* out, hipStream_t st) {
+  if (G > 0) hipLaunchKernelGGL(k_row_absmax, dim3(G), dim3(256), 0, st, x, ld, D, ptr, out);
+}
+
 // dbfr_model_set_edge_log: per-graph edge counts of this step, log[k * G + g] = sum over the graph's target chunks
 __global__ void k_edge_log(GraphArgs A, int* log) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
