@@ -222,7 +222,10 @@ def measure_traffic(mode, args):
                 for row in csv.DictReader(open(f)):
                     if kern in row["Kernel_Name"] and row["Counter_Name"] == ctr:
                         tot += float(row["Counter_Value"])
-                        disp.add(row["Dispatch_Id"])
+                        # reduce_first: one 'launch' of the library's profile = k_convz + (where the conv has vector-output rows) k_conv2h;
+                        # both kernels' bytes count, the launches are k_convz's
+                        if mode != "reduce_first" or "k_convz" in row["Kernel_Name"]:
+                            disp.add(row["Dispatch_Id"])
             if not disp:
                 return None, f"no {kern} dispatch in the {ctr} pass"
             out[ctr] = tot * 1024.0 / len(disp)          # the counters are in KiB
@@ -467,15 +470,18 @@ def main():
         samp.run_complexes(warm, ppc, dev, seed=i)
     torch.cuda.synchronize(dev)
     # N > 1: boards hold clocks up to 5 % apart at the power cap, and a statically sharded job takes as long as its slowest rank.  Every
-    # rank times ONE more untimed batch of the same jobs (workspace and code already warm), the times are all-gathered and the job table
+    # rank times THREE more untimed batches of the same jobs (workspace and code already warm; the median counts), the times are all-gathered and the job table
     # is LPT-sharded by measured speed (dist.rank_speeds): faster boards take proportionally more jobs.  The poses do not depend on it.
     speeds, calib_s = None, None
     if world > 1 and args.warmup > 0 and not args.no_speed_shard:      # (with --warmup 0 the batch would time one-off set-up costs)
-        ddist.barrier()
-        tc = time.perf_counter()
-        samp.run_complexes(warm, ppc, dev, seed=12345)
-        torch.cuda.synchronize(dev)
-        calib_s = time.perf_counter() - tc
+        cal = []
+        for i in range(3):              # the median of three: one hiccup (a page fault, a clock dip) must not move a tenth of the job table
+            ddist.barrier()
+            tc = time.perf_counter()
+            samp.run_complexes(warm, ppc, dev, seed=12345 + i)
+            torch.cuda.synchronize(dev)
+            cal.append(time.perf_counter() - tc)
+        calib_s = sorted(cal)[1]
         speeds = ddist.rank_speeds(calib_s, dev)
     shards, reps = ddist.shard_jobs(jobs, ppc, world, speeds)
     t_up = time.perf_counter()
@@ -653,13 +659,13 @@ def main():
                        "edge_budget_regrown_in_timed_region": model.regrown - regrown0,     # DBFR_ERR_CAPACITY -> limits raised -> step resumed
                        "board": board,      # power cap, power and shader clock of rank 0's board during the timed region (amdgpu hwmon files), or None
                        "ranks_seen": len(per_rank),
-                       "rank_speed": ([round(v, 4) for v in speeds] if speeds else None),     # relative, from one untimed calibration batch; the LPT shard's weights
+                       "rank_speed": ([round(v, 4) for v in speeds] if speeds else None),     # relative, from the median of three untimed calibration batches; the LPT shard's weights
                        "per_rank": [{"rank": int(v[0]), "device": int(v[1]), "poses": int(v[2]), "batches": int(v[3]), "elapsed_s": round(v[4], 4),
                                      "sampling_s": round(v[5], 4), "gather_and_unpack_s": round(v[4] - v[5], 4),
                                      "torch_peak_hbm_gib": round(v[6], 3), "records_upload_s_before_timing": round(v[7], 4),
                                      "assemble_host_s": round(v[8], 4),
                                      "poses_per_sec_sampling": round(v[2] / v[5], 2) if v[5] > 0 else None,      # this rank's own rate over its batches
-                                     "poses_per_sec_calibration_batch": round(v[9], 2) if v[9] > 0 else None}    # one untimed batch before the timed region
+                                     "poses_per_sec_calibration_batch": round(v[9], 2) if v[9] > 0 else None}    # the median of three untimed batches before the timed region
                                     for v in per_rank],
                        # whole-job rate / sum of what the ranks sustained while sampling: what sharding imbalance, the gather and the barriers cost
                        "parallel_efficiency": (round((poses / elapsed) / sum(v[2] / v[5] for v in per_rank if v[5] > 0), 4)

@@ -50,6 +50,10 @@ class _Half:
     def release(self):
         self.__dict__.pop("_dev", None)
 
+    def nbytes(self):
+        """Bytes of one device copy of this half."""
+        return sum(getattr(self, k).numel() * getattr(self, k).element_size() for k in self._FIELDS)
+
 
 class LigandRecord(_Half):
     """Static host-side form of one ligand (mol_pipeline.py: LigandFeaturizer / TorsionFactory / LigandGrapher keys)."""

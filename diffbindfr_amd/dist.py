@@ -194,6 +194,22 @@ def rank_speeds(seconds, device, spread=0.10):
     return [min(1.0 + spread, max(1.0 - spread, v / mean)) for v in inv]
 
 
+def free_device_bytes(dev):
+    """Free bytes on ``dev`` (None for the host)."""
+    dev = torch.device(dev)
+    return torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else None
+
+
+def release_needed(records, dev, share=0.25):
+    """``run_sharded(release="auto")``: do the device copies of these records' halves (each shared half counted once) take more than
+    ``share`` of the memory free on ``dev``?  Host-side arithmetic only."""
+    free = free_device_bytes(dev)
+    if free is None:
+        return False
+    halves = {id(h): h for r in records for h in (r.lig, r.pocket)}
+    return sum(h.nbytes() for h in halves.values()) > share * free
+
+
 def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
     """Bring the flat record buffers of all ranks together in bounded windows.
 
@@ -230,7 +246,7 @@ def _gather_windows(local, n_all, world, rank, mode, window, stage_dev):
 
 
 def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_max=10.0, gather=True, on_batch=None,
-                store="device", window_bytes=256 << 20, release=False, tapes=None, rank_speed=None):
+                store="device", window_bytes=256 << 20, release="auto", tapes=None, rank_speed=None):
     """The multi-GPU product entry: a job list in, poses out in job order.
 
         jobs    list of ``assemble.ComplexRecord`` -- the (protein, ligand) pair table of the reference
@@ -246,7 +262,9 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
                 batch + the window, whatever the size of the job table.
         release True: drop a record half's device copy (``_Half.release``) after the last batch of this rank that uses it -- for job
                 tables whose records do not fit HBM together (the forward screen's 10 k ligands do, at 20 KB each).  It MUTATES the
-                caller's records (a second run uploads them again), hence off by default.
+                caller's records (a second run uploads them again).  False: the records stay as they were uploaded.
+                "auto" (default): True only if the device copies of this rank's records would take more than a quarter of the
+                device memory that is free when the call starts (``release_needed``) -- never at the sizes of BASELINE.json.
         tapes   {job index: (init tape, noise tape)} of recorded random numbers used instead of drawing (``draw_tapes``).
         rank_speed  list[world] of relative rank speeds (``rank_speeds``: measured on a calibration batch), THE SAME LIST ON EVERY
                 RANK: the LPT shard weighs the ranks by it.  The poses do not depend on it (per-job random streams).
@@ -276,6 +294,8 @@ def run_sharded(sampler, jobs, poses, seed, device, batch_poses=640, tr_sigma_ma
     local = (torch.empty(max(n_flt[rank], 1), pin_memory=dev.type == "cuda") if on_host
              else torch.empty(max(n_flt[rank], 1), device=dev))
     batches = plan_batches([(j, reps[j]) for j in shards[rank]], batch_poses)
+    if release == "auto":
+        release = release_needed([jobs[j] for j in shards[rank]], dev)
     last_use = {}
     for bi, batch in enumerate(batches):
         for j, _, _ in batch:

@@ -30,11 +30,12 @@ def npy(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
 
-def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False, n_complex=1, poses=1, tag="traj"):
+def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False, n_complex=1, poses=1, tag="traj", robust_tol=3e-4):
     """n_complex x poses graphs (default: one complex x one pose) of the named config through all 20 steps.  `robust`: the reference algorithm's graphs have hard cutoffs, so a
     trajectory that passes within rounding distance of a cutoff event jumps by 1e-3 .. 1e-2 A under ANY rounding-sized change
     (tests/tools/example_sensitivity.py) and is useless as a 1e-3 A fixture; a seed is accepted only if a second oracle run from initial
-    ligand coordinates moved by N(0, 1e-5 A) stays within 3e-4 A of the first at every step (otherwise the next seed is tried)."""
+    ligand coordinates moved by N(0, 1e-5 A) stays within `robust_tol` (3e-4 A; 5e-4 A for the six-graph batches, whose maximum is taken over six
+    trajectories and where no seed of eight met 3e-4: half of the 1e-3 A the test allows) of the first at every step (otherwise the next seed is tried)."""
     T = synthetic.residue_tables()
     mcfg = sm.default_cfg()
     params = sm.init_params(mcfg, seed=1)
@@ -56,7 +57,7 @@ def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False, n_complex=1,
         lig2, _ = sampler.sample(params, mcfg, scfg, d2, noise, a14g, visualize=True)
         dev = (lig2 - lig).norm(dim=-1).amax(dim=1)      # (over the atoms of ALL graphs: one graph near a cutoff rejects the seed)
         print("  second run from initial coordinates moved by N(0, 1e-5 A): max deviation per step", " ".join(f"{x:.0e}" for x in dev.tolist()))
-        if float(dev.max()) < 3e-4:
+        if float(dev.max()) < robust_tol:
             break
         print("  -> passes too close to a cutoff event; next seed")
     else:
@@ -83,6 +84,6 @@ if __name__ == "__main__":
     if 2 in which:
         cfg_trajectory(out_dir, 2, 202, 22, robust=True)
     if 25 in which:
-        cfg_trajectory(out_dir, 2, 212, 23, robust=True, n_complex=3, poses=2, tag="batch_traj")
+        cfg_trajectory(out_dir, 2, 4212, 23, robust=True, n_complex=3, poses=2, tag="batch_traj", robust_tol=5e-4)      # (seeds 212 .. 3212 of the first search: 5e-4 .. 3e-3)
     if 55 in which:
-        cfg_trajectory(out_dir, 5, 515, 56, robust=True, n_complex=2, poses=2, tag="batch_traj")
+        cfg_trajectory(out_dir, 5, 515, 56, robust=True, n_complex=2, poses=2, tag="batch_traj", robust_tol=5e-4)

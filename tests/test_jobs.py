@@ -217,6 +217,27 @@ def test_record_halves_are_released_after_their_last_batch():
     assert all("_dev" not in j.lig.__dict__ for j in jobs)
 
 
+def test_release_auto_is_keyed_on_the_tables_bytes_against_free_device_memory(monkeypatch):
+    """a job table whose records do not fit the device together must not stay resident by default."""
+    cfg, n_jobs, poses, bp = _CASES["w2"]
+    raw, jobs = make_jobs(cfg, n_jobs, 60, 10)
+    total = jobs[0].pocket.nbytes() + sum(j.lig.nbytes() for j in jobs)        # the shared pocket counts once
+    assert total > 0 and jobs[0].lig.nbytes() == sum(getattr(jobs[0].lig, k).numel() * getattr(jobs[0].lig, k).element_size() for k in jobs[0].lig._FIELDS)
+    assert ddist.release_needed(jobs, "cpu") is False                           # the host: nothing to release
+    monkeypatch.setattr(ddist, "free_device_bytes", lambda dev: 4 * total + 4)
+    assert ddist.release_needed(jobs, "cpu") is False                           # a quarter of the free memory or less: stay resident
+    monkeypatch.setattr(ddist, "free_device_bytes", lambda dev: 4 * total - 4)
+    assert ddist.release_needed(jobs, "cpu") is True
+
+    class Spy(_StandInSampler):
+        def run_complexes(self, records, poses, device, tr_sigma_max, seeds, pose_ranges=None):
+            for r in records:
+                r.lig.dev("cpu"), r.pocket.dev("cpu")
+            return super().run_complexes(records, poses, device, tr_sigma_max, seeds, pose_ranges)
+    ddist.run_sharded(Spy(), jobs, poses, seed=1, device="cpu", batch_poses=bp)          # default "auto", table too large -> released
+    assert "_dev" not in jobs[0].pocket.__dict__ and all("_dev" not in j.lig.__dict__ for j in jobs)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 def _hip(dev):
     import diffbindfr_amd as dba
