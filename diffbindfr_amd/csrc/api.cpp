@@ -37,6 +37,7 @@ void dbfr_edge_form(const dbfr_batch& b, int* n_chunk, int* lanes);
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
 void launch_edge_log(const GraphArgs& A, int* log_row, hipStream_t st);
 void launch_graph_chunks(const GraphArgs& A, hipStream_t st);
+void launch_flat_chunks(const int* tgt, const int* n_edges, int max_edges, int span, int n_span, int* cnt0, int cap, int* chunk_es, int* chunk_gl, hipStream_t st);
 void launch_row_absmax(const float* x, int ld, int D, const int* ptr, int G, float* out, hipStream_t st);
 void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
                           int* tor_batch, int* sc_batch, hipStream_t st);
@@ -956,6 +957,9 @@ static void edge_set_take(Bump& b, EdgeSet& S, int cap, int n_targets, int G, in
   S.row_start = b.take<int>(n_targets, (p + ".row_start").c_str()); S.row_cnt = b.take<int>(n_targets, (p + ".row_cnt").c_str());
   S.g_cnt = b.take<int>(G, (p + ".g_cnt").c_str()); S.g_base = b.take<int>(G, (p + ".g_base").c_str());
   S.chunk0 = b.take<int>(n_graphs + 1, (p + ".chunk0").c_str()); S.gedge0 = b.take<int>(n_graphs + 1, (p + ".gedge0").c_str());
+  // k_convz's chunk table: a chunk ends after 32 edges, at the end of its graph or with the end of its CZ_MAXSEG-th target (graph.hip k_graph_chunks)
+  S.chunk_cap = cap > 0 ? cap / 32 + n_targets / CZ_MAXSEG + n_graphs + 8 : 0;
+  S.chunk_es = b.take<int>(std::max(S.chunk_cap, 1), (p + ".chunk_es").c_str()); S.chunk_gl = b.take<int>(std::max(S.chunk_cap, 1), (p + ".chunk_gl").c_str());
 }
 
 static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim, char* base, size_t cap, Ws* w,
@@ -1076,12 +1080,12 @@ static Conv2Desc conv2_desc(const ConvW2& cw, const int* n_edges, int max_edges,
   return d;
 }
 
-static ConvZDesc convz_desc(const Conv2Desc& d, const ConvZ& z, const int* tgt, int D_out, const int* chunk0 = nullptr, const int* gedge0 = nullptr, int n_graph = 0,
+static ConvZDesc convz_desc(const Conv2Desc& d, const ConvZ& z, const int* tgt, int D_out, const int* chunk_es, const int* chunk_gl, const int* n_chunks, int max_chunks,
                             const float* xmax = nullptr) {
   ConvZDesc o;
   o.n_edges = d.n_edges; o.max_edges = d.max_edges; o.tgt = tgt; o.gth = d.gth; o.emb = d.emb; o.sh = d.sh;
   o.tab1 = d.tab1; o.ld1 = d.ld1; o.idx1 = d.idx1; o.tab2 = d.tab2; o.ld2 = d.ld2; o.idx2 = d.idx2; o.x = d.x; o.ldx = d.ldx;
-  o.w = z; o.msg = d.msg; o.D_out = D_out; o.chunk0 = chunk0; o.gedge0 = gedge0; o.n_graph = n_graph; o.xmax = xmax;
+  o.w = z; o.msg = d.msg; o.D_out = D_out; o.chunk_es = chunk_es; o.chunk_gl = chunk_gl; o.n_chunks = n_chunks; o.max_chunks = max_chunks; o.xmax = xmax;
   return o;
 }
 
@@ -1210,8 +1214,8 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
         launch_row_absmax(lx, Di, Di, B->lig_ptr, G, w.xmax_l, st);
         launch_row_absmax(ax, Di, Di, B->atm_ptr, G, w.xmax_a, st);
       }
-      const ConvZDesc zs[4] = {convz_desc(ds[0], m->layerz[l][0], LL.tgt, Do, LL.chunk0, LL.gedge0, G, w.xmax_l), convz_desc(ds[1], m->layerz[l][1], AL.tgt, Do, AL.chunk0, AL.gedge0, G, w.xmax_a),
-                               convz_desc(ds[2], m->layerz[l][2], AA.tgt, Do, AA.chunk0, AA.gedge0, G, w.xmax_a), convz_desc(ds[3], m->layerz[l][3], LA.tgt, Do, LA.chunk0, LA.gedge0, G, w.xmax_l)};
+      auto zd = [&](int i, const EdgeSet& S, const float* xmax) { return convz_desc(ds[i], m->layerz[l][i], S.tgt, Do, S.chunk_es, S.chunk_gl, S.chunk0 + G, S.chunk_cap, xmax); };
+      const ConvZDesc zs[4] = {zd(0, LL, w.xmax_l), zd(1, AL, w.xmax_a), zd(2, AA, w.xmax_a), zd(3, LA, w.xmax_l)};
       conv2_call(m, ds, Ws, 4, st, (m->layer_fallback >> l) & 1u, rf ? zs : nullptr);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
@@ -1321,7 +1325,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_lig_off; a.gs_coeff = m->gs_lig_c; a.out = T.emb;
       launch_mlp(a, st);
       ds[nd] = conv2_desc(m->tor_conv2, T.n_edges, T.cap, T.gth, T.emb, T.sh, lx, D, T.gth, w.tor_attr, NS, T.tgt, lx, D, w.msg[0]);
-      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->tor_convz, T.tgt, 2 * NS, T.chunk0, T.gedge0, G, w.xmax_l); }   // (all outputs of a torsion conv are scalars)
+      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->tor_convz, T.tgt, 2 * NS, T.chunk_es, T.chunk_gl, T.chunk0 + G, T.chunk_cap, w.xmax_l); }   // (all outputs of a torsion conv are scalars)
       Ws[nd++] = m->tor_conv.W;
     }
     if (do_s) {
@@ -1331,7 +1335,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       a.gs_offset = m->gs_atom_off; a.gs_coeff = m->gs_atom_c; a.out = S.emb;
       launch_mlp(a, st);
       ds[nd] = conv2_desc(m->sc_conv2, S.n_edges, S.cap, S.gth, S.emb, S.sh, ax, D, S.gth, w.sc_attr, NS, S.tgt, ax, D, w.msg[1]);
-      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->sc_convz, S.tgt, 2 * NS, S.chunk0, S.gedge0, G, w.xmax_a); }
+      if (rf) { ds[nd].w.n_tiles = 0; zs[nd] = convz_desc(ds[nd], m->sc_convz, S.tgt, 2 * NS, S.chunk_es, S.chunk_gl, S.chunk0 + G, S.chunk_cap, w.xmax_a); }
       Ws[nd++] = m->sc_conv.W;
     }
     if (nd) conv2_call(m, ds, Ws, nd, st, (m->layer_fallback >> 31) & 1u, rf ? zs : nullptr);
@@ -1628,7 +1632,22 @@ static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t fami
     const bool rf = m->gemm_split == DBFR_GEMM_REDUCE_FIRST && !deep;   // (the message buffer then holds segment sums in the segments' first rows: include/dbfr.h)
     Conv2Desc d = conv2_desc(rf && layer >= 0 ? m->layer2v[layer][family] : *cw2, n_edges_dev, n_edges, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg);
     if (rf && layer < 0) d.w.n_tiles = 0;
-    const ConvZDesc z = convz_desc(d, layer >= 0 ? m->layerz[layer][family] : layer == -2 ? m->tor_convz : m->sc_convz, tgt, cw->D_out);
+    // k_convz's chunk table for this flat edge list, in a scratch buffer the hook keeps (test hook: one caller at a time): the list is cut every
+    // 2048 edges as if those were graphs (parallel walk)
+    static int* scratch = nullptr; static size_t scratch_ints = 0;
+    const int span = 2048, n_span = (n_edges + span - 1) / span, ccap = n_edges / 32 + n_edges / CZ_MAXSEG + n_span + 8;
+    if (rf) {
+      const size_t need = (size_t)n_span + 1 + 2 * (size_t)ccap;
+      if (need > scratch_ints) {
+        if (scratch) HIPCHECK(hipFree(scratch));
+        scratch = nullptr; scratch_ints = 0;
+        HIPCHECK(hipMalloc(&scratch, need * sizeof(int)));
+        scratch_ints = need;
+      }
+      launch_flat_chunks(tgt, n_edges_dev, n_edges, span, n_span, scratch, ccap, scratch + n_span + 1, scratch + n_span + 1 + ccap, (hipStream_t)hip_stream);
+    }
+    const ConvZDesc z = convz_desc(d, layer >= 0 ? m->layerz[layer][family] : layer == -2 ? m->tor_convz : m->sc_convz, tgt, cw->D_out,
+                                   scratch ? scratch + n_span + 1 : nullptr, scratch ? scratch + n_span + 1 + ccap : nullptr, scratch ? scratch + n_span : nullptr, ccap);
     const int W = cw->W;
     conv2_call(m, &d, &W, 1, (hipStream_t)hip_stream, deep, rf ? &z : nullptr);
   } else {

@@ -121,6 +121,7 @@ struct Conv2Args {
 // and the big GEMM runs once per TARGET (segment of <= 32 edges), not once per edge.
 #define CZ_NKT 10         // k tiles of 16: 144 hidden units + the constant 1 that carries the bias (tile 9, column 0)
 #define CZ_MAXCT 12       // c tiles of 16 over both scalar output irreps (layer convs: 8, torsion convs: 10)
+#define CZ_MAXSEG 4       // targets (segments) per chunk: k_convz keeps the masked y operand of every segment in registers
 #define CZ_TILE_BYTES 6144   // W2' of one (c tile, k tile, k-step): [3 w tiles][hi, lo][64 lanes][8 fp16]
 struct ConvZ {
   int n_io;               // scalar output irreps of this conv (1 or 2)
@@ -142,10 +143,11 @@ struct ConvZDesc {
   const float* x; int ldx;
   ConvZ w;
   float* msg; int D_out;
-  const int* chunk0;      // [n_graph + 1] first 32-edge chunk of every graph (chunks are cut per graph: batch-independent sums), or null: one graph
-  const int* gedge0;      // [n_graph + 1] first edge of every graph
-  int n_graph;
-  const float* xmax;      // [n_graph] largest |x| over the rows of every graph (k_row_absmax), or null: the kernel reads the chunk's gathered rows itself
+  const int* chunk_es;    // [n_chunks] first edge of every chunk (k_chunk_fill: <= 32 edges AND <= CZ_MAXSEG targets of ONE graph: batch-independent sums)
+  const int* chunk_gl;    // [n_chunks] graph << 6 | number of edges
+  const int* n_chunks;    // device scalar
+  int max_chunks;
+  const float* xmax;      // [graphs] largest |x| over the rows of every graph (k_row_absmax), or null: the kernel reads the chunk's gathered rows itself
 };
 struct ConvZArgs { ConvZDesc c[4]; int n_conv; float* dbg; double* executed; };   // executed (profiling only): += flops of the matrix instructions issued   // dbg (developer, DBFR_CONVZ_DEBUG=<file>): workgroup 0 / wave 0 of the first unit dumps h [32 slots][144]
 
@@ -183,8 +185,11 @@ struct EdgeSet {           // one per-step edge list, grouped (CSR) by scatter-t
   int* row_cnt;        // [n_targets]
   int* g_cnt;          // [G * n_chunk] per-(graph, target chunk) totals (count pass); n_chunk = dbfr_edge_chunks()
   int* g_base;         // [G * n_chunk] base offset of each chunk's first edge (scan)
-  int* chunk0;         // [G + 1] first 32-edge chunk of every graph (k_graph_chunks; chunks never straddle graphs: convz.hip)
+  int* chunk0;         // [G + 1] first chunk of every graph (k_chunk_count -> k_graph_chunks; chunks never straddle graphs: convz.hip)
   int* gedge0;         // [G + 1] first edge of every graph
+  int* chunk_es;       // [chunk_cap] first edge of every chunk (k_chunk_fill)
+  int* chunk_gl;       // [chunk_cap] graph << 6 | number of edges (<= 32, holding <= CZ_MAXSEG targets)
+  int chunk_cap;
 };
 
 struct ConvArgs {

@@ -49,12 +49,20 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // the stores conflict-free, the 256-byte halves / 512-byte groups (0 mod 64 banks) the loads.
 #define CZ_VSTRIDE 2064
 #define CZ_CB (8 * CZ_VSTRIDE)      // one column block
-#define CZ_NCB 3                    // column blocks of 16 per pass: the segments of the workgroup's eight chunks take consecutive columns
+#define CZ_NCB 2                    // column blocks of 16: the <= 8 x CZ_MAXSEG segments of the workgroup's eight chunks take consecutive columns
 #define CZ_TILE (CZ_NCB * CZ_CB)    // one (c, k) tile: all column blocks
 #define CZ_KPB 1                    // k tiles per barrier
 #define CZ_BUF (CZ_KPB * CZ_TILE)
 #define CZ_ZBYTES (2 * CZ_BUF)      // two buffers: step A of the next tile writes while step B of this one reads
-#define CZ_WAVE_FLOATS (32 * 12 + 32 + 32 + 32 + 32 + 32 + 32 * 16)   // harmonics [32][12] | sa | ua | gather row offsets | segment ids | first slot of segment j | masks [32 segments][4 lane groups][4 dwords]
+#define CZ_WAVE_FLOATS (32 * 12 + 32 + 32 + 32 + 32 + 32 + CZ_MAXSEG * 16 + 24 * 64)   // harmonics [32][12] | sa | ua | gather row offsets | segment ids | first slot of segment j | masks [CZ_MAXSEG segments][4 lane groups][4 dwords] | gathered x of the next c tile [8 slots x 3 components][64 lanes]
+#ifndef CZ_PRIO
+#define CZ_PRIO 1
+#endif
+#if CZ_PRIO
+#define CZ_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define CZ_SETPRIO(x)
+#endif
 #define CZ_ZSCALE (-20)             // |Z| <= 32 edges x 2^15 x 2^15 = 2^35 -> 2^15
 
 __device__ __forceinline__ void cz_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -88,10 +96,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
   int* w_row = reinterpret_cast<int*>(w_ua + 32);           // [32] gth[e] * ldx
   int* w_seg = w_row + 32;                                  // [32] segment of the slot, -1: no edge
   int* w_first = w_seg + 32;                                // [32] first slot of segment j
-  unsigned* w_mask = reinterpret_cast<unsigned*>(w_first + 32);   // [32][4][4] segment j's mask on the A-operand registers of lane group g
+  unsigned* w_mask = reinterpret_cast<unsigned*>(w_first + 32);   // [CZ_MAXSEG][4][4] segment j's mask on the A-operand registers of lane group g
+  float* w_xs = reinterpret_cast<float*>(w_mask + CZ_MAXSEG * 16);   // [24][64] the next c tile's gathered x values: row = slot t (+ 8 m: component m of a vector input), one dword per lane
   int* b_nseg = reinterpret_cast<int*>(lds + CZ_ZBYTES / 4 + NW * CZ_WAVE_FLOATS);   // [NW]
   int* b_col_edge = b_nseg + NW;                            // [48] message row of the column's segment, -1: column unused
-  float* b_col_inv = reinterpret_cast<float*>(b_col_edge + 16 * CZ_NCB);   // [48] takes the chunk's factors off
+  float* b_col_inv = reinterpret_cast<float*>(b_col_edge + 16 * CZ_NCB);   // [32] takes the chunk's factors off
+  unsigned* b_cdesc = reinterpret_cast<unsigned*>(b_col_inv + 16 * CZ_NCB);   // [CZ_MAXCT][16] the conv's c-tile descriptors (a dependent global load per use otherwise)
 
   // developer timeline (ABL & 128, DBFR_CONVZ_DEBUG=<file>): s_memtime stamps of workgroup 0's first unit, [wave][stamp] unsigned long long in a.dbg
   int tr_n = 0;
@@ -109,8 +119,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
   for (int c = 0; c < 4; ++c)
     if (c < a.n_conv) {
       const ConvZDesc& d = a.c[c];
-      const int E = min(*d.n_edges, d.max_edges);
-      nch[c] = d.chunk0 ? d.chunk0[d.n_graph] : (E + 31) >> 5;
+      nch[c] = min(*d.n_chunks, d.max_chunks);
       nu[c] = (nch[c] + NW - 1) / NW;
     }
   const int N = nu[0] + nu[1] + nu[2] + nu[3];
@@ -123,20 +132,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     // ---- my chunk: edges [es, es + len)
     const int ch = ul * NW + wave;
     int es = 0, len = 0, gidx = 0;
-    if (ch < nch[c]) {
-      if (d.chunk0) {
-        int lo = 0, hi = d.n_graph - 1;                      // the graph whose chunk range holds ch
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.chunk0[mid] <= ch) lo = mid; else hi = mid - 1; }
-        gidx = lo;
-        es = d.gedge0[lo] + 32 * (ch - d.chunk0[lo]);
-        len = min(32, d.gedge0[lo + 1] - es);
-      } else {
-        es = 32 * ch;
-        len = min(32, E - es);
-      }
-      len = max(len, 0);
+    if (ch < nch[c]) {                                       // (k_chunk_fill: <= 32 edges and <= CZ_MAXSEG targets of one graph)
+      es = d.chunk_es[ch];
+      const int gl = d.chunk_gl[ch];
+      gidx = gl >> 6;
+      len = min(min(gl & 63, 32), max(E - es, 0));
     }
     __syncthreads();   // nothing of the last unit still reads the block-level arrays
+    if (tid < CZ_MAXCT * 16) b_cdesc[tid] = tid < (W.ct0[W.n_io - 1] + W.nct[W.n_io - 1]) * 16 ? W.cdesc[tid] : 0u;
     if (unit != (int)blockIdx.x) tr_n = 1000;                // (the first unit only)
     stamp(1);
     // ---- slots: lanes 0..31 own slot L (clamped to the chunk's last edge beyond its length; a chunk without edges reads edge 0 of a non-empty conv or nothing)
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     const bool is_first = lane < 32 && sl < len && (sl == 0 || tgt_l != tgt_prev);
     const unsigned long long bal = __ballot(is_first);
     const unsigned firsts = (unsigned)bal;
-    const int nseg = __popc(firsts);
+    const int nseg = min(__popc(firsts), CZ_MAXSEG);         // (the chunk table holds no chunk with more)
     const int seg_l = (sl < len) ? __popc(firsts & (0xffffffffu >> (31 - sl))) - 1 : -1;
     if (lane < 32) {
       w_row[sl] = gth_l * d.ldx;
@@ -344,211 +347,307 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     }
     stamp(3);
     // ---- masks of my segments on the registers of the A operand (halves of a dword = two consecutive slots), for every lane group
-    for (int idx = lane; idx < nseg * 16; idx += 64) {
-      const int j = idx >> 4, gg = (idx >> 2) & 3, r = idx & 3, t0 = 2 * r;
+    {                                                        // (segments the chunk does not have: all-zero masks)
+      const int j = lane >> 4, gg = (lane >> 2) & 3, r = lane & 3, t0 = 2 * r;
       const int s0 = t0 < 4 ? 4 * gg + t0 : 16 + 4 * gg + (t0 - 4);
-      w_mask[idx] = (w_seg[s0] == j ? 0x0000ffffu : 0u) | (w_seg[s0 + 1] == j ? 0xffff0000u : 0u);
+      w_mask[lane] = (w_seg[s0] == j ? 0x0000ffffu : 0u) | (w_seg[s0 + 1] == j ? 0xffff0000u : 0u);
     }
     __builtin_amdgcn_wave_barrier();
     __syncthreads();
-    // ---- columns: the segments of the eight chunks side by side, 48 per pass
+    // ---- columns: the segments of the eight chunks side by side (<= 8 x CZ_MAXSEG = 32 = two column blocks of step B)
     int cbase = 0, total = 0;
 #pragma unroll
     for (int v = 0; v < NW; ++v) { const int c = b_nseg[v]; if (v < wave) cbase += c; total += c; }
-    cbase = __builtin_amdgcn_readfirstlane(cbase); total = __builtin_amdgcn_readfirstlane(total);   // (wave-uniform: scalar loop bounds below)
+    cbase = __builtin_amdgcn_readfirstlane(cbase); total = __builtin_amdgcn_readfirstlane(total);   // (wave-uniform: scalar branches below)
     const int nseg_u = __builtin_amdgcn_readfirstlane(nseg);
-    const int npass = (total + 16 * CZ_NCB - 1) / (16 * CZ_NCB);
+    const int ncb = (total + 15) >> 4;                       // column blocks of 16 in step B: 0 (no edges), 1 or 2
     const float col_inv = __builtin_amdgcn_ldexpf(1.f, -CZ_ZSCALE - ey - ephi);
     const float zs = __builtin_amdgcn_ldexpf(1.f, CZ_ZSCALE);
     if (ABL & 32) continue;
-    long long n_mfma = 2 * KT * 14;                          // (profiling) matrix instructions this wave issues in this unit: the hidden layer ...
-    for (int pass = 0; pass < npass; ++pass) {
-      const int c_lo = 16 * CZ_NCB * pass;
-      const int ncb = min(CZ_NCB, (total - c_lo + 15) >> 4);   // column blocks of 16 in step B
-      const int j0 = max(0, c_lo - cbase), j1 = min(nseg_u, c_lo + 16 * CZ_NCB - cbase);   // my segments of this pass: columns cbase + j - c_lo
-      __syncthreads();                                       // (the last pass's epilogue has read the column arrays)
-      for (int c = tid; c < 16 * CZ_NCB; c += 64 * NW) b_col_edge[c] = -1;
-      __syncthreads();
-      for (int j = j0 + lane; j < j1; j += 64) {
-        b_col_edge[cbase + j - c_lo] = es + w_first[j];
-        b_col_inv[cbase + j - c_lo] = col_inv;
+    for (int c = tid; c < 16 * CZ_NCB; c += 64 * NW) b_col_edge[c] = -1;
+    __syncthreads();
+    if (lane < nseg_u) {
+      b_col_edge[cbase + lane] = es + w_first[lane];
+      b_col_inv[cbase + lane] = col_inv;
+    }
+    // LDS addresses of my segments' Z columns in buffer 0 (lane part + column).  A slot without a segment computes zeros and writes them into
+    // column 31: unused whenever such a slot exists (the unit then has fewer than 32 segments), and never stored
+    char* za[CZ_MAXSEG];
+    {
+      char* zw0 = zb + (n & 7) * CZ_VSTRIDE + g * 512 + (n >> 3) * 256;
+#pragma unroll
+      for (int j = 0; j < CZ_MAXSEG; ++j) {
+        const int col = cbase + j;
+        za[j] = j < nseg_u ? zw0 + (col >> 4) * CZ_CB + (col & 15) * 16 : zw0 + CZ_CB + 15 * 16;
       }
-      for (int io = 0; io < W.n_io; ++io) {
-        // ... step A: 3 per (segment, tile), step B: 9 per (column block, tile) -- of the k tile 9 by wave 0 only
-        n_mfma += (long long)W.nct[io] * (3LL * CZ_NKT * max(j1 - j0, 0) + 9LL * ncb * (KT + (wave == 0)));
-        f32x4 acc[3][CZ_NCB];
+    }
+    long long n_mfma = 2 * KT * 14;                          // (profiling) matrix instructions this wave issues in this unit: the hidden layer ...
+    for (int io = 0; io < W.n_io; ++io) {
+      // ... step A: 3 per (segment slot, tile), step B: 9 per (column block, tile) -- of the k tile 9 by wave 0 only
+      n_mfma += (long long)W.nct[io] * (3LL * CZ_NKT * CZ_MAXSEG + 9LL * ncb * (KT + (wave == 0)));
+      f32x4 acc[3][CZ_NCB];
+#pragma unroll
+      for (int wt = 0; wt < 3; ++wt)
+#pragma unroll
+        for (int cb = 0; cb < CZ_NCB; ++cb) acc[wt][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const char* wbase = reinterpret_cast<const char*>(W.W2z) + (size_t)lane * 16;
+      int gq = W.ct0[io] * CZ_NKT;                           // running (c tile, k tile) index into W2z; CZ_NKT is even: the Z buffer of tile gq is kt & 1
+      const int gq_last = (W.ct0[io] + W.nct[io]) * CZ_NKT - 1;
+      u32x4 Wf[2][3][2];                                     // W2' fragments of my k-step: [tile parity][w tile][hi, lo], fetched one whole tile ahead
+      auto fetchW = [&](auto par_c, int q) {
+        constexpr int par = decltype(par_c)::value;
+        if ((ABL & 1) && q != W.ct0[io] * CZ_NKT) return;
+        // (no branch around these loads, not even for the k tile 9 whose fragments only wave 0 uses: behind a conditional fetch hipcc's wait-count
+        // pass assumes the loads were NOT issued and makes step B wait for vmcnt(0), i.e. for the fragments requested a moment ago)
+        const char* p = wbase + ((size_t)q * 8 + wave) * CZ_TILE_BYTES;
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt)
 #pragma unroll
-          for (int cb = 0; cb < CZ_NCB; ++cb) acc[wt][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const char* wbase = reinterpret_cast<const char*>(W.W2z) + (size_t)lane * 16;
-        int gq = W.ct0[io] * CZ_NKT;                         // running (c tile, k tile) index into W2z
-        const int gq_last = (W.ct0[io] + W.nct[io]) * CZ_NKT - 1;
-        u32x4 Wf[2][3][2];                                   // W2' fragments of my k-step: [tile parity][w tile][hi, lo], fetched one whole tile ahead
-        auto fetchW = [&](auto par_c, int q, bool bias_tile) {
-          constexpr int par = decltype(par_c)::value;
-          if ((ABL & 1) && q != W.ct0[io] * CZ_NKT) return;
-          // (no branch around these loads, not even for the k tile 9 whose fragments only wave 0 uses: behind a conditional fetch hipcc's wait-count
-          // pass assumes the loads were NOT issued and makes step B wait for vmcnt(0), i.e. for the fragments requested a moment ago)
-          (void)bias_tile;
-          const char* p = wbase + ((size_t)q * 8 + wave) * CZ_TILE_BYTES;
+          for (int pc = 0; pc < 2; ++pc) Wf[par][wt][pc] = *reinterpret_cast<const u32x4*>(p + (wt * 2 + pc) * 1024);
+      };
+      // Y of a c tile, MASKED per segment: lane (c = n, group g), my eight slots; Ym[j] = the pieces with the slots outside segment j zeroed -- the
+      // A operand of step A for all ten k tiles of the c tile (masking per (c, k) tile cost 8 vector instructions and a mask read per segment and
+      // tile).  The gathers of a scalar-input tile are requested several tiles before they are used (load_x -> finish_Y); the one vector-input
+      // tile per irrep is gathered where it is needed.
+      u32x4 Ym[CZ_MAXSEG][2];
 #pragma unroll
-          for (int wt = 0; wt < 3; ++wt)
+      for (int j = 0; j < CZ_MAXSEG; ++j) { Ym[j][0] = (u32x4){0u, 0u, 0u, 0u}; Ym[j][1] = (u32x4){0u, 0u, 0u, 0u}; }
+      // Y of a c tile (lane: c = n, group g; my eight slots): x values gathered through the slots' row offsets x the harmonics x the chunk's power of two,
+      // cut into pieces and masked per segment.  The gathers go STRAIGHT TO LDS (global_load_lds_dword: no register holds them -- under the tile loop's
+      // register pressure prefetched values were spilled one by one, a load, a wait and a scratch store each), a few tiles before the c tile starts:
+      // row t (+ 8 m for component m of a vector input) of the wave's stage, one dword per lane.
+      auto prefetch_x = [&](int ct) {
+        if (nseg_u == 0 || (ABL & 16)) return;
+        const unsigned cd_n = b_cdesc[(W.ct0[io] + ct) * 16 + n];
+        const bool vec = (__builtin_amdgcn_readfirstlane(cd_n) >> 12) & 1u;
+        const int xo = cd_n & 0xfff;
+        // (inline assembly on purpose: for the builtin hipcc's wait-count pass makes EVERY later LDS read -- the Z reads of the next tiles -- wait for
+        // vmcnt(0), i.e. for W2' fragments requested a moment before; here the one wait sits in front of the stage's readers, wait_stage)
+        const unsigned lds0 = (unsigned)(size_t)(const void __attribute__((address_space(3)))*)w_xs;
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) Wf[par][wt][pc] = *reinterpret_cast<const u32x4*>(p + (wt * 2 + pc) * 1024);
-        };
-        u32x4 Yh = {0u, 0u, 0u, 0u}, Yl = {0u, 0u, 0u, 0u};   // Y pieces of the current c tile (masked per segment where they are used)
-        // Y of a c tile: lane (c = n, group g), my eight slots.  The gathers of a scalar-input tile are requested several tiles before they are
-        // used (load_x -> finish_Y); the one vector-input tile per irrep is gathered where it is needed.
-        float xv[8];
-        unsigned cd_n = 0, cd_0 = 0;
-        auto load_x = [&](int ct) {
-          if (j1 <= j0 || (ABL & 16)) return;
-          cd_n = W.cdesc[(W.ct0[io] + ct) * 16 + n];
-          cd_0 = __builtin_amdgcn_readfirstlane(W.cdesc[(W.ct0[io] + ct) * 16]);
-          if (((cd_0 >> 12) & 1u) == 0) {
-            const int xo = cd_n & 0xfff;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) xv[t] = d.x[w_row[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)] + xo];
+        for (int t = 0; t < 8; ++t) {
+          const float* xp = d.x + w_row[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)] + xo;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + t * 256)), "v"(xp) : "m0", "memory");
+          if (vec) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + (8 + t) * 256)), "v"(xp + 1) : "m0", "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + (16 + t) * 256)), "v"(xp + 2) : "m0", "memory");
           }
-        };
-        auto finish_Y = [&]() {
-          if (j1 <= j0 || (ABL & 16)) return;
-          const int xo = cd_n & 0xfff, so = (cd_n >> 16) & 15;
-          const float yv = (cd_n >> 31) ? sY : 0.f;          // (padding columns: zero)
-          float y[8];
-          if (((cd_0 >> 12) & 1u) == 0) {                    // scalar inputs: x[u] sh0
+        }
+      };
+      // every load issued before the `younger` most recent ones has landed -- the stage's gathers among them
+      auto wait_stage = [&](auto younger_c) {
+        constexpr int y = decltype(younger_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (y == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto finish_Y = [&](int ct) {
+        if (nseg_u == 0 || (ABL & 16)) return;
+        const unsigned cd_n = b_cdesc[(W.ct0[io] + ct) * 16 + n];
+        const bool vec = (__builtin_amdgcn_readfirstlane(cd_n) >> 12) & 1u;
+        const int so = (cd_n >> 16) & 15;
+        const float yv = (cd_n >> 31) ? sY : 0.f;            // (padding columns: zero)
+        float y[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-              const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
-              y[t] = xv[t] * w_sh[slot * 12 + so] * yv;
+        for (int t = 0; t < 8; ++t) {
+          const float* sp = w_sh + (t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)) * 12 + so;
+          float v = w_xs[t * 64 + lane] * sp[0];             // x[u] sh0 | xv[u] . sh1
+          if (vec) v += w_xs[(8 + t) * 64 + lane] * sp[1] + w_xs[(16 + t) * 64 + lane] * sp[2];
+          y[t] = v * yv;
+        }
+        u32x4 Yh, Yl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { unsigned hi, lo; cz_split2(y[2 * r], y[2 * r + 1], hi, lo); Yh[r] = hi; Yl[r] = lo; }
+#pragma unroll
+        for (int j = 0; j < CZ_MAXSEG; ++j) {                // (segments the chunk does not have: all-zero masks)
+          const u32x4 mk = *reinterpret_cast<const u32x4*>(w_mask + (j * 4 + g) * 4);
+          Ym[j][0] = Yh & mk; Ym[j][1] = Yl & mk;
+        }
+      };
+#define YM(j, p) __builtin_bit_cast(f16x8, Ym[j][p])
+#define MF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define SL __builtin_amdgcn_sched_barrier(0)
+      // step A of one (c, k) tile, on its own (the first tile of an irrep, the first tile of a c tile): Z[c, k] of my four segment slots -- independent
+      // three-product chains side by side -- as fp32 to LDS (column = segment)
+      auto stepA = [&](auto kt_c, auto buf_c) {
+        constexpr int kt = decltype(kt_c)::value, boff = decltype(buf_c)::value * CZ_BUF;
+        if (ABL & 4) return;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f16x8 hh = __builtin_bit_cast(f16x8, Hh[kt][0]), hl = __builtin_bit_cast(f16x8, Hh[kt][1]);
+        f32x4 z[CZ_MAXSEG];
+#pragma unroll
+        for (int j = 0; j < CZ_MAXSEG; ++j) z[j] = MF(YM(j, 0), hl, zero);
+#pragma unroll
+        for (int j = 0; j < CZ_MAXSEG; ++j) z[j] = MF(YM(j, 1), hh, z[j]);
+#pragma unroll
+        for (int j = 0; j < CZ_MAXSEG; ++j) z[j] = MF(YM(j, 0), hh, z[j]);
+#pragma unroll
+        for (int j = 0; j < CZ_MAXSEG; ++j) *reinterpret_cast<f32x4*>(za[j] + boff) = z[j];
+      };
+      // x 2^-20 (|Z| <= 32 x 2^15 x 2^15), cut into two fp16 pieces: the B operand of my k-step (a quarter of a column block's eight values per call)
+      auto cut = [&](const f32x4 (&zf)[2], u32x4& zh, u32x4& zl, auto r_c) {
+        constexpr int r = decltype(r_c)::value;
+        unsigned hi, lo;
+        cz_split2(zf[r >> 1][2 * (r & 1)] * zs, zf[r >> 1][2 * (r & 1) + 1] * zs, hi, lo);
+        zh[r] = hi; zl[r] = lo;
+      };
+      using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+      using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+      // One tile kt < 9 as ONE instruction stream: step A of tile kt + 1 (12 MFMAs, into the other Z buffer) with the cutting of this tile's first
+      // column block in its shadow, then step B of this tile (9 MFMAs per column block) with A's four LDS writes and the cutting of the second block in
+      // its shadow.  (Round 5: as separate phases -- A as a loop over segment pairs with a mask read and eight v_and each, B block by block behind
+      // scalar branches -- a wave spent 480 + 900 cycles per tile on 30 MFMAs = 480 pipe cycles.)
+      auto tile = [&](auto kt_c, auto ncb_c) {
+        constexpr int kt = decltype(kt_c)::value, NCBV = decltype(ncb_c)::value;
+        constexpr int boffA = ((kt + 1) & 1) * CZ_BUF;
+        fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last));
+        const char* zr = zb + (kt & 1) * CZ_BUF + wave * CZ_VSTRIDE + g * 512 + n * 16;
+        f32x4 zf0[2], zf1[2];
+        zf0[0] = *reinterpret_cast<const f32x4*>(zr); zf0[1] = *reinterpret_cast<const f32x4*>(zr + 256);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f16x8 hh = __builtin_bit_cast(f16x8, Hh[kt + 1][0]), hl = __builtin_bit_cast(f16x8, Hh[kt + 1][1]);
+        u32x4 p0h, p0l, p1h, p1l;
+        f32x4 z0, z1, z2, z3;
+        if constexpr ((ABL & 4) != 0) {
+          z0 = z1 = z2 = z3 = zero;
+          cut(zf0, p0h, p0l, K0{}); cut(zf0, p0h, p0l, K1{}); cut(zf0, p0h, p0l, K2{}); cut(zf0, p0h, p0l, K3{});
+        } else {
+        CZ_SETPRIO(3);                       // (falling priority through the tile: of the two waves of a SIMD the one behind wins)
+        SL;
+        z0 = MF(YM(0, 0), hl, zero); SL;
+        z1 = MF(YM(1, 0), hl, zero); SL;
+        z2 = MF(YM(2, 0), hl, zero); SL;
+        z3 = MF(YM(3, 0), hl, zero); SL;
+        z0 = MF(YM(0, 1), hh, z0); cut(zf0, p0h, p0l, K0{}); SL;
+        z1 = MF(YM(1, 1), hh, z1); SL;
+        z2 = MF(YM(2, 1), hh, z2); cut(zf0, p0h, p0l, K1{}); SL;
+        z3 = MF(YM(3, 1), hh, z3); SL;
+        CZ_SETPRIO(2);
+        z0 = MF(YM(0, 0), hh, z0); cut(zf0, p0h, p0l, K2{}); SL;
+        z1 = MF(YM(1, 0), hh, z1); SL;
+        z2 = MF(YM(2, 0), hh, z2); cut(zf0, p0h, p0l, K3{}); SL;
+        z3 = MF(YM(3, 0), hh, z3); SL;
+        }
+#define WFR(wt, pc) __builtin_bit_cast(f16x8, Wf[kt & 1][wt][pc])
+        if constexpr ((ABL & 8) != 0) {
+          if constexpr (!(ABL & 4)) { *reinterpret_cast<f32x4*>(za[0] + boffA) = z0; *reinterpret_cast<f32x4*>(za[1] + boffA) = z1; *reinterpret_cast<f32x4*>(za[2] + boffA) = z2; *reinterpret_cast<f32x4*>(za[3] + boffA) = z3; }
+          asm volatile("" :: "v"(p0h), "v"(p0l));
+        } else {
+          const f16x8 zh = __builtin_bit_cast(f16x8, p0h), zl = __builtin_bit_cast(f16x8, p0l);
+          if constexpr (NCBV > 1) { zf1[0] = *reinterpret_cast<const f32x4*>(zr + CZ_CB); zf1[1] = *reinterpret_cast<const f32x4*>(zr + CZ_CB + 256); }
+          acc[0][0] = MF(WFR(0, 0), zl, acc[0][0]); *reinterpret_cast<f32x4*>(za[0] + boffA) = z0; SL;
+          acc[1][0] = MF(WFR(1, 0), zl, acc[1][0]); *reinterpret_cast<f32x4*>(za[1] + boffA) = z1; SL;
+          acc[2][0] = MF(WFR(2, 0), zl, acc[2][0]); *reinterpret_cast<f32x4*>(za[2] + boffA) = z2; SL;
+          acc[0][0] = MF(WFR(0, 1), zh, acc[0][0]); *reinterpret_cast<f32x4*>(za[3] + boffA) = z3; SL;
+          CZ_SETPRIO(1);
+          acc[1][0] = MF(WFR(1, 1), zh, acc[1][0]); if constexpr (NCBV > 1) cut(zf1, p1h, p1l, K0{}); SL;
+          acc[2][0] = MF(WFR(2, 1), zh, acc[2][0]); if constexpr (NCBV > 1) cut(zf1, p1h, p1l, K1{}); SL;
+          acc[0][0] = MF(WFR(0, 0), zh, acc[0][0]); if constexpr (NCBV > 1) cut(zf1, p1h, p1l, K2{}); SL;
+          acc[1][0] = MF(WFR(1, 0), zh, acc[1][0]); if constexpr (NCBV > 1) cut(zf1, p1h, p1l, K3{}); SL;
+          acc[2][0] = MF(WFR(2, 0), zh, acc[2][0]); SL;
+        }
+        if constexpr (NCBV > 1 && !(ABL & 8)) {
+          const f16x8 zh = __builtin_bit_cast(f16x8, p1h), zl = __builtin_bit_cast(f16x8, p1l);
+          acc[0][1] = MF(WFR(0, 0), zl, acc[0][1]); SL;
+          acc[1][1] = MF(WFR(1, 0), zl, acc[1][1]); SL;
+          acc[2][1] = MF(WFR(2, 0), zl, acc[2][1]); SL;
+          CZ_SETPRIO(0);
+          acc[0][1] = MF(WFR(0, 1), zh, acc[0][1]); SL;
+          acc[1][1] = MF(WFR(1, 1), zh, acc[1][1]); SL;
+          acc[2][1] = MF(WFR(2, 1), zh, acc[2][1]); SL;
+          acc[0][1] = MF(WFR(0, 0), zh, acc[0][1]); SL;
+          acc[1][1] = MF(WFR(1, 0), zh, acc[1][1]); SL;
+          acc[2][1] = MF(WFR(2, 0), zh, acc[2][1]); SL;
+        }
+      };
+      // the k tile 9 (the bias row: k-step 0 only, wave 0's) and, under it, the next c tile's Y and its first step A
+      auto tile9 = [&](int ct) {
+        constexpr int kt = KT;
+        // (the next c tile's Y first, the W2' fetch behind it: finish_Y reloads a few spilled loop invariants, and a reload waits for vmcnt(0) --
+        // with the fetch in front of it for a whole L2 round trip)
+        wait_stage(K0{});
+        if (ct + 1 < W.nct[io]) { finish_Y(ct + 1); stepA(K0{}, K0{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        fetchW(K0{}, min(gq + 1, gq_last));
+        if (wave == 0 && !(ABL & 8)) {
+          const char* zr = zb + (kt & 1) * CZ_BUF + g * 512 + n * 16;
+#pragma unroll
+          for (int cb = 0; cb < CZ_NCB; ++cb)
+            if (cb < ncb) {
+              f32x4 zf[2];
+              zf[0] = *reinterpret_cast<const f32x4*>(zr + cb * CZ_CB); zf[1] = *reinterpret_cast<const f32x4*>(zr + cb * CZ_CB + 256);
+              u32x4 ph, pl;
+              cut(zf, ph, pl, K0{}); cut(zf, ph, pl, K1{}); cut(zf, ph, pl, K2{}); cut(zf, ph, pl, K3{});
+              const f16x8 zh = __builtin_bit_cast(f16x8, ph), zl = __builtin_bit_cast(f16x8, pl);
+#pragma unroll
+              for (int wt = 0; wt < 3; ++wt) {
+                acc[wt][cb] = MF(WFR(wt, 0), zl, acc[wt][cb]);
+                acc[wt][cb] = MF(WFR(wt, 1), zh, acc[wt][cb]);
+                acc[wt][cb] = MF(WFR(wt, 0), zh, acc[wt][cb]);
+              }
             }
-          } else {                                           // vector inputs: xv[u] . sh1
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-              const int slot = t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4);
-              const float* xp = d.x + w_row[slot] + xo;
-              const float* sp = w_sh + slot * 12 + so;
-              y[t] = (xp[0] * sp[0] + xp[1] * sp[1] + xp[2] * sp[2]) * yv;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { unsigned hi, lo; cz_split2(y[2 * r], y[2 * r + 1], hi, lo); Yh[r] = hi; Yl[r] = lo; }
-        };
-        // step A of one (c, k) tile: Z[c, k] of my segments, two at a time (their three-product chains side by side), cut into pieces, to LDS
-        auto stepA = [&](auto kt_c, int buf) {
-          constexpr int kt = decltype(kt_c)::value;
-          if (ABL & 4) return;
-          char* zw0 = zb + buf * CZ_BUF + (n & 7) * CZ_VSTRIDE + g * 512 + (n >> 3) * 256;
-          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-          const f16x8 hh = __builtin_bit_cast(f16x8, Hh[kt][0]), hl = __builtin_bit_cast(f16x8, Hh[kt][1]);
-          auto zcol = [&](int col) { return zw0 + (col >> 4) * CZ_CB + (col & 15) * 16; };
-          // (tried: four segments side by side while three or more are left -- 158 spilled registers, 442 -> 422 poses/s)
-          for (int j = j0; j < j1; j += 2) {
-            const bool two = j + 1 < j1;
-            const u32x4 m0 = *reinterpret_cast<const u32x4*>(w_mask + (j * 4 + g) * 4);
-            const u32x4 m1 = two ? *reinterpret_cast<const u32x4*>(w_mask + ((j + 1) * 4 + g) * 4) : (u32x4){0u, 0u, 0u, 0u};
-            const f16x8 yh0 = __builtin_bit_cast(f16x8, Yh & m0), yl0 = __builtin_bit_cast(f16x8, Yl & m0);
-            const f16x8 yh1 = __builtin_bit_cast(f16x8, Yh & m1), yl1 = __builtin_bit_cast(f16x8, Yl & m1);
-            f32x4 z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh0, hl, zero, 0, 0, 0);
-            f32x4 z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh1, hl, zero, 0, 0, 0);
-            z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl0, hh, z0, 0, 0, 0);
-            z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl1, hh, z1, 0, 0, 0);
-            z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh0, hh, z0, 0, 0, 0);
-            z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh1, hh, z1, 0, 0, 0);
-            const int col = cbase + j - c_lo;
-            *reinterpret_cast<f32x4*>(zcol(col)) = z0;
-            if (two) *reinterpret_cast<f32x4*>(zcol(col + 1)) = z1;
-          }
-        };
-        using K0 = std::integral_constant<int, 0>;
-        // While step B reads tile i from buffer i & 1, step A of tile i + 1 is written into the other buffer; one barrier per tile.
-        fetchW(K0{}, gq, false);
-        load_x(0);
-        finish_Y();
-        stepA(K0{}, gq & 1);
-        __syncthreads();
+        }
+      };
+#undef WFR
+      // While step B reads tile i from buffer i & 1, step A of tile i + 1 is written into the other buffer; one barrier per tile.
+      prefetch_x(0);
+      wait_stage(K0{});
+      fetchW(K0{}, gq);
+      finish_Y(0);
+      stepA(K0{}, K0{});
+      __syncthreads();
+      // (the column-block count is decided once per unit, OUTSIDE the tile loops: as a branch inside a tile hipcc hoists the instructions the two
+      // forms share -- the Z reads and the first half of the cutting, with their s_waitcnt -- in front of step A's matrix instructions)
+      auto run_tiles = [&](auto ncb_c) {
         for (int ct = 0; ct < W.nct[io]; ++ct) {
           cz_static_for<0, CZ_NKT>([&](auto kt_c) {
             constexpr int kt = decltype(kt_c)::value;
-            const bool mine = kt < KT || wave == 0;          // (k tile 9 holds the bias row only: k-step 0)
-            // ---- the NEXT tile's W2' fragments set out into the other register set: a whole tile ahead of their use
-            fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last), kt + 1 == KT);
-            // ---- step B of tile (ct, kt): my k-step's Z pieces of the first column block (requested first: the step A below runs under their latency)
-            const char* zr = zb + (gq & 1) * CZ_BUF + wave * CZ_VSTRIDE + g * 512 + n * 16;
-            f32x4 zf[2][2];                                  // [block parity][half]: my k-step's eight Z values of a column block, fp32
-            if (mine) { zf[0][0] = *reinterpret_cast<const f32x4*>(zr); zf[0][1] = *reinterpret_cast<const f32x4*>(zr + 256); }
-            // ---- step A of the next tile into the other buffer, and step B of this one: the two waves of a SIMD (w, w + 4) take them in opposite
-            // order -- step A is vector-pipe work (masks, cutting Z into pieces), step B matrix-pipe work, and behind a barrier both waves would
-            // otherwise want the same pipe at the same time
-            auto nextA = [&] {
-              if constexpr (kt + 1 < CZ_NKT) stepA(std::integral_constant<int, (kt + 1) % CZ_NKT>{}, (gq + 1) & 1);
-              else if (ct + 1 < W.nct[io]) { finish_Y(); stepA(K0{}, (gq + 1) & 1); }
-              if constexpr (kt == 4) if (ct + 1 < W.nct[io]) load_x(ct + 1);   // (this c tile's last step A is issued at kt = 8; Yh / Yl are rewritten at kt = 9)
-            };
-            auto thisB = [&] {
-              if (mine && !(ABL & 8)) {
-#pragma unroll
-                for (int cb = 0; cb < CZ_NCB; ++cb)
-                  if (cb < ncb) {
-                    if (cb + 1 < ncb) {                      // the next block's values travel under this block's MFMAs
-                      zf[(cb + 1) & 1][0] = *reinterpret_cast<const f32x4*>(zr + (cb + 1) * CZ_CB);
-                      zf[(cb + 1) & 1][1] = *reinterpret_cast<const f32x4*>(zr + (cb + 1) * CZ_CB + 256);
-                    }
-                    // x 2^-20 (|Z| <= 32 x 2^15 x 2^15), cut into two fp16 pieces: the B operand of my k-step
-                    unsigned ph[4], pl[4];
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                      const f32x4 v = zf[cb & 1][hf];
-                      cz_split2(v[0] * zs, v[1] * zs, ph[2 * hf], pl[2 * hf]);
-                      cz_split2(v[2] * zs, v[3] * zs, ph[2 * hf + 1], pl[2 * hf + 1]);
-                    }
-                    const f16x8 zh = __builtin_bit_cast(f16x8, (u32x4){ph[0], ph[1], ph[2], ph[3]}), zl = __builtin_bit_cast(f16x8, (u32x4){pl[0], pl[1], pl[2], pl[3]});
-#pragma unroll
-                    for (int wt = 0; wt < 3; ++wt) {
-                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zl, acc[wt][cb], 0, 0, 0);
-                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][1]), zh, acc[wt][cb], 0, 0, 0);
-                      acc[wt][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[kt & 1][wt][0]), zh, acc[wt][cb], 0, 0, 0);
-                    }
-                  }
-              }
-            };
             stamp(10);
-            if (wave < NW / 2 && !(ABL & 64)) { nextA(); stamp(11); thisB(); stamp(12); } else { thisB(); stamp(12); nextA(); stamp(11); }
+            if constexpr (kt == 5) if (ct + 1 < W.nct[io]) prefetch_x(ct + 1);   // (used at kt = 9: four tiles for the gathers)
+            if constexpr (kt < KT)
+              tile(kt_c, ncb_c);
+            else
+              tile9(ct);
+            stamp(12);
             ++gq;
             if (!(ABL & 2)) __syncthreads();                 // the next tile's Z is complete; this tile's buffer may be written again
             stamp(13);
           });
         }
-        // ---- the output irrep is complete: add the eight waves' partial sums, take the factors off, store into the segments' first rows
-        float* red = reinterpret_cast<float*>(zb) + wave * (12 * CZ_NCB * 64);
+      };
+      if (ncb > 1) run_tiles(K2{}); else run_tiles(K1{});
+#undef YM
+#undef MF
+#undef SL
+      // ---- the output irrep is complete: add the eight waves' partial sums, take the factors off, store into the segments' first rows
+      float* red = reinterpret_cast<float*>(zb) + wave * (12 * CZ_NCB * 64);
 #pragma unroll
-        for (int wt = 0; wt < 3; ++wt)
+      for (int wt = 0; wt < 3; ++wt)
 #pragma unroll
-          for (int cb = 0; cb < CZ_NCB; ++cb)
+        for (int cb = 0; cb < CZ_NCB; ++cb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[((wt * CZ_NCB + cb) * 4 + q) * 64 + lane] = acc[wt][cb][q];
-        __syncthreads();
-        for (int idx = tid; idx < 16 * ncb * 48; idx += 64 * NW) {
-          const int col = idx / 48, w = idx - 48 * col;
-          const int e = b_col_edge[col];
-          if (e >= 0) {
-            const int r = w & 15;
-            const float* rp = reinterpret_cast<const float*>(zb) + (((w >> 4) * CZ_NCB + (col >> 4)) * 4 + (r & 3)) * 64 + 16 * (r >> 2) + (col & 15);
-            float s = 0.f;
+          for (int q = 0; q < 4; ++q) red[((wt * CZ_NCB + cb) * 4 + q) * 64 + lane] = acc[wt][cb][q];
+      __syncthreads();
+      for (int idx = tid; idx < 16 * ncb * 48; idx += 64 * NW) {
+        const int col = idx / 48, w = idx - 48 * col;
+        const int e = b_col_edge[col];
+        if (e >= 0) {
+          const int r = w & 15;
+          const float* rp = reinterpret_cast<const float*>(zb) + (((w >> 4) * CZ_NCB + (col >> 4)) * 4 + (r & 3)) * 64 + 16 * (r >> 2) + (col & 15);
+          float s = 0.f;
 #pragma unroll
-            for (int v = 0; v < NW; ++v) s += rp[v * (12 * CZ_NCB * 64)];
-            d.msg[(size_t)e * d.D_out + W.out_off[io] + w] = s * b_col_inv[col] * W.rowinv[io * 48 + w];
-          }
+          for (int v = 0; v < NW; ++v) s += rp[v * (12 * CZ_NCB * 64)];
+          d.msg[(size_t)e * d.D_out + W.out_off[io] + w] = s * b_col_inv[col] * W.rowinv[io * 48 + w];
         }
-        __syncthreads();
       }
+      __syncthreads();
     }
     if (a.executed && lane == 0) atomicAdd(a.executed, 16384.0 * (double)n_mfma);   // 16 x 16 x 32 x 2 flops per instruction
   }
 }
 
-size_t convz_lds_bytes() { return CZ_ZBYTES + 8 * CZ_WAVE_FLOATS * sizeof(float) + (8 + 2 * 16 * CZ_NCB) * sizeof(int); }
+size_t convz_lds_bytes() { return CZ_ZBYTES + 8 * CZ_WAVE_FLOATS * sizeof(float) + (8 + 2 * 16 * CZ_NCB + CZ_MAXCT * 16) * sizeof(int); }
 
 void launch_convz(const ConvZArgs& a0, hipStream_t st) {
   constexpr int NW = 8;

@@ -422,24 +422,47 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
   }
 }
 
-// Per-graph chunks of 32 edges for the reduce-first conv (convz.hip): gedge0[g] = first edge of graph g in the set, chunk0[g] = number of chunks of
-// the graphs before it (a chunk never holds edges of two graphs, so which edges are summed together does not depend on batch mates).  One block per set.
+// Chunks for the reduce-first conv (convz.hip): consecutive edges of ONE graph, at most 32 of them and at most CZ_MAXSEG scatter targets (a chunk
+// never holds edges of two graphs, and where it is cut depends on the graph's own targets only: which edges are summed together does not depend
+// on batch mates).  chunk_len: the next chunk of the edge range [es, hi), called by a whole wave; the length is wave-uniform.
+__device__ __forceinline__ int chunk_len(const int* tgt, int es, int hi) {
+  const int lane = threadIdx.x & 63;
+  const int n = min(32, hi - es);
+  int t = 0;
+  if (lane < n) t = tgt[es + lane];
+  const int tp = __shfl_up(t, 1);
+  unsigned f = (unsigned)__ballot(lane < n && (lane == 0 || t != tp));   // starts of the maximal runs of one target
+#pragma unroll
+  for (int i = 0; i < CZ_MAXSEG; ++i) f &= f - 1;
+  return f ? __ffs((int)f) - 1 : n;                      // up to the start of run CZ_MAXSEG + 1
+}
+__device__ __forceinline__ void graph_edge_range(const GraphArgs& A, const EdgeSet& S, int g, int& lo, int& hi) {
+  const int E = min(*S.n_edges, S.cap);
+  lo = min(S.g_base[g * A.n_chunk], E);
+  hi = g + 1 < A.b.G ? min(S.g_base[(g + 1) * A.n_chunk], E) : E;
+}
+// pass 1, one wave per (graph, set): the graph's first edge and its number of chunks (chunk0 holds the COUNT until k_graph_chunks scans it)
+__global__ __launch_bounds__(256) void k_chunk_count(GraphArgs A) {
+  const EdgeSet& S = A.set[blockIdx.y];
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= A.b.G) return;
+  int lo = 0, cnt = 0;
+  if (S.cap > 0) {
+    int hi;
+    graph_edge_range(A, S, g, lo, hi);
+    for (int es = lo; es < hi; ++cnt) es += chunk_len(S.tgt, es, hi);
+  }
+  if ((threadIdx.x & 63) == 0) { S.chunk0[g] = cnt; S.gedge0[g] = lo; }
+}
+// pass 2, one block per set: chunk0[g] = number of chunks of the graphs before g; chunk0[G] = their total (k_convz's unit count)
 __global__ __launch_bounds__(256) void k_graph_chunks(GraphArgs A) {
   __shared__ int sc[256];
   const EdgeSet& S = A.set[blockIdx.x];
   const int G = A.b.G;
-  if (S.cap == 0) { for (int g = threadIdx.x; g <= G; g += 256) { S.chunk0[g] = 0; S.gedge0[g] = 0; } return; }
-  const int E = min(*S.n_edges, S.cap);
   int running = 0;
   for (int g0 = 0; g0 < G; g0 += 256) {
     const int g = g0 + threadIdx.x;
-    int lo = 0, v = 0;
-    if (g < G) {
-      lo = min(S.g_base[g * A.n_chunk], E);
-      const int hi = g + 1 < G ? min(S.g_base[(g + 1) * A.n_chunk], E) : E;
-      v = (hi - lo + 31) >> 5;
-      S.gedge0[g] = lo;
-    }
+    const int v = g < G ? S.chunk0[g] : 0;
     sc[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -452,13 +475,81 @@ __global__ __launch_bounds__(256) void k_graph_chunks(GraphArgs A) {
     running += sc[255];
     __syncthreads();
   }
-  if (threadIdx.x == 0) { S.chunk0[G] = running; S.gedge0[G] = E; }
+  // (chunk_cap = cap / 32 + targets / 4 + G + 8 bounds the total: a chunk ends after 32 edges, at the end of its graph, or with the end of its
+  // fourth target -- and every target ends once)
+  if (threadIdx.x == 0) { S.chunk0[G] = min(running, S.chunk_cap); S.gedge0[G] = S.cap > 0 ? min(*S.n_edges, S.cap) : 0; }
+}
+// pass 3, one wave per (graph, set): the chunk table
+__global__ __launch_bounds__(256) void k_chunk_fill(GraphArgs A) {
+  const EdgeSet& S = A.set[blockIdx.y];
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= A.b.G || S.cap == 0) return;
+  int lo, hi;
+  graph_edge_range(A, S, g, lo, hi);
+  int ch = S.chunk0[g];
+  for (int es = lo; es < hi && ch < S.chunk_cap; ++ch) {
+    const int len = chunk_len(S.tgt, es, hi);
+    if ((threadIdx.x & 63) == 0) { S.chunk_es[ch] = es; S.chunk_gl[ch] = (g << 6) | len; }
+    es += len;
+  }
 }
 
 void launch_graph_chunks(const GraphArgs& A0, hipStream_t st) {
   GraphArgs A = A0;
   if (A.n_chunk <= 0) dbfr_edge_form(A.b, &A.n_chunk, &A.lanes);
+  hipLaunchKernelGGL(k_chunk_count, dim3((A.b.G + 3) / 4, N_SETS), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_graph_chunks, dim3(N_SETS), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_chunk_fill, dim3((A.b.G + 3) / 4, N_SETS), dim3(256), 0, st, A);
+}
+
+// The same table for ONE flat edge list (the single-conv test hooks, api.cpp test_conv_impl): the list is cut every `span` edges as if those were
+// graphs, so that the walk runs in parallel.  cnt0 [n_span + 1] scratch -> first chunk of every span, total in cnt0[n_span].
+__global__ __launch_bounds__(256) void k_flat_chunk_count(const int* tgt, const int* n_edges, int max_edges, int span, int n_span, int* cnt0) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_span) return;
+  const int E = min(*n_edges, max_edges);
+  const int lo = min(g * span, E), hi = min(lo + span, E);
+  int cnt = 0;
+  for (int es = lo; es < hi; ++cnt) es += chunk_len(tgt, es, hi);
+  if ((threadIdx.x & 63) == 0) cnt0[g] = cnt;
+}
+__global__ __launch_bounds__(256) void k_flat_chunk_scan(int n_span, int* cnt0, int cap) {
+  __shared__ int sc[256];
+  int running = 0;
+  for (int g0 = 0; g0 < n_span; g0 += 256) {
+    const int g = g0 + threadIdx.x;
+    const int v = g < n_span ? cnt0[g] : 0;
+    sc[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int w = threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+      __syncthreads();
+      sc[threadIdx.x] += w;
+      __syncthreads();
+    }
+    if (g < n_span) cnt0[g] = running + sc[threadIdx.x] - v;
+    running += sc[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt0[n_span] = min(running, cap);
+}
+__global__ __launch_bounds__(256) void k_flat_chunk_fill(const int* tgt, const int* n_edges, int max_edges, int span, int n_span, const int* cnt0, int cap,
+                                                         int* chunk_es, int* chunk_gl) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_span) return;
+  const int E = min(*n_edges, max_edges);
+  const int lo = min(g * span, E), hi = min(lo + span, E);
+  int ch = cnt0[g];
+  for (int es = lo; es < hi && ch < cap; ++ch) {
+    const int len = chunk_len(tgt, es, hi);
+    if ((threadIdx.x & 63) == 0) { chunk_es[ch] = es; chunk_gl[ch] = len; }   // (graph 0: the hooks pass no per-graph bounds)
+    es += len;
+  }
+}
+void launch_flat_chunks(const int* tgt, const int* n_edges, int max_edges, int span, int n_span, int* cnt0, int cap, int* chunk_es, int* chunk_gl, hipStream_t st) {
+  hipLaunchKernelGGL(k_flat_chunk_count, dim3((n_span + 3) / 4), dim3(256), 0, st, tgt, n_edges, max_edges, span, n_span, cnt0);
+  hipLaunchKernelGGL(k_flat_chunk_scan, dim3(1), dim3(256), 0, st, n_span, cnt0, cap);
+  hipLaunchKernelGGL(k_flat_chunk_fill, dim3((n_span + 3) / 4), dim3(256), 0, st, tgt, n_edges, max_edges, span, n_span, cnt0, cap, chunk_es, chunk_gl);
 }
 
 // Largest |feature| over the node rows [ptr[g], ptr[g + 1]) of every graph: the bound k_convz scales its y operand with.  Per GRAPH, not per

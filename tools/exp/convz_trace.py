@@ -10,11 +10,14 @@ for w in range(8):
     print(f"wave {w}: {len(ts)} stamps; prologue: slots {ts[1]-ts[0] if len(ts)>1 else 0}  hidden+scan {ts[2]-ts[1] if len(ts)>2 else 0}")
     # tile loop
     i = 3; rows = []
-    while i + 3 < len(ts) and len(rows) < 400:
+    while i + 2 < len(ts) and len(rows) < 400:
         if tags[i] == 10:
-            seq = {int(tags[i+k]): int(ts[i+k]) for k in range(1, 4)}
-            rows.append((seq.get(11, 0) - ts[i], seq.get(12, 0) - ts[i], seq.get(13, 0) - ts[i]))
-            i += 4
+            seq = {}
+            k = 1
+            while i + k < len(ts) and tags[i + k] != 10:
+                seq[int(tags[i + k])] = int(ts[i + k]); k += 1
+            rows.append((seq.get(11, ts[i]) - ts[i], seq.get(12, ts[i]) - ts[i], seq.get(13, ts[i]) - ts[i]))
+            i += k
         else:
             i += 1
     r = np.array(rows)
