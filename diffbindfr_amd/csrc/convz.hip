@@ -86,7 +86,7 @@ template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no W2' fet
 __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
   constexpr int KT = 9;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave: a scalar register)
   const int n = lane & 15, g = lane >> 4;
   char* zb = reinterpret_cast<char*>(lds);
   float* wl = lds + CZ_ZBYTES / 4 + wave * CZ_WAVE_FLOATS;
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     xmx = cz_wave_max(xmx); smx = cz_wave_max(smx);
     int ey = 0;                                              // y is multiplied by 2^ey: |y| <= 3 |x| |sh| < 2^(ex + es + 2) -> below 2^15
     if (xmx > 0.f && smx > 0.f) ey = max(-100, min(100, 13 - __builtin_amdgcn_frexp_expf(xmx) - __builtin_amdgcn_frexp_expf(smx)));
+    ey = __builtin_amdgcn_readfirstlane(ey);
     const float sY = __builtin_amdgcn_ldexpf(1.f, ey);
 
     stamp(2);
@@ -416,8 +417,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       // cut into pieces and masked per segment.  The gathers go STRAIGHT TO LDS (global_load_lds_dword: no register holds them -- under the tile loop's
       // register pressure prefetched values were spilled one by one, a load, a wait and a scratch store each), a few tiles before the c tile starts:
       // row t (+ 8 m for component m of a vector input) of the wave's stage, one dword per lane.
+      // (prefetch_x / finish_Y run once per c tile: they take the lane id from v_mbcnt instead of the kernel's `lane`, so that nothing of theirs is kept
+      // in registers -- or spilled and reloaded, a memory round trip each -- across the ten tiles between two uses)
       auto prefetch_x = [&](int ct) {
         if (nseg_u == 0 || (ABL & 16)) return;
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), n = lane & 15, g = lane >> 4;
         const unsigned cd_n = b_cdesc[(W.ct0[io] + ct) * 16 + n];
         const bool vec = (__builtin_amdgcn_readfirstlane(cd_n) >> 12) & 1u;
         const int xo = cd_n & 0xfff;
@@ -444,17 +448,26 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       };
       auto finish_Y = [&](int ct) {
         if (nseg_u == 0 || (ABL & 16)) return;
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), n = lane & 15, g = lane >> 4;
         const unsigned cd_n = b_cdesc[(W.ct0[io] + ct) * 16 + n];
         const bool vec = (__builtin_amdgcn_readfirstlane(cd_n) >> 12) & 1u;
         const int so = (cd_n >> 16) & 15;
         const float yv = (cd_n >> 31) ? sY : 0.f;            // (padding columns: zero)
         float y[8];
+        if (!vec) {                                          // x[u] sh0
+          float xs[8], s0[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float* sp = w_sh + (t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)) * 12 + so;
-          float v = w_xs[t * 64 + lane] * sp[0];             // x[u] sh0 | xv[u] . sh1
-          if (vec) v += w_xs[(8 + t) * 64 + lane] * sp[1] + w_xs[(16 + t) * 64 + lane] * sp[2];
-          y[t] = v * yv;
+          for (int t = 0; t < 8; ++t) { xs[t] = w_xs[t * 64 + lane]; s0[t] = w_sh[(t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)) * 12 + so]; }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) y[t] = xs[t] * s0[t] * yv;
+        } else {                                             // xv[u] . sh1
+          float xs[8][3], s1[8][3];
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { xs[t][m] = w_xs[(8 * m + t) * 64 + lane]; s1[t][m] = w_sh[(t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)) * 12 + so + m]; }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) y[t] = (xs[t][0] * s1[t][0] + xs[t][1] * s1[t][1] + xs[t][2] * s1[t][2]) * yv;
         }
         u32x4 Yh, Yl;
 #pragma unroll
@@ -564,13 +577,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       // the k tile 9 (the bias row: k-step 0 only, wave 0's) and, under it, the next c tile's Y and its first step A
       auto tile9 = [&](int ct) {
         constexpr int kt = KT;
-        // (the next c tile's Y first, the W2' fetch behind it: finish_Y reloads a few spilled loop invariants, and a reload waits for vmcnt(0) --
-        // with the fetch in front of it for a whole L2 round trip)
+        // Order: wave 0's step B, the next c tile's Y and first step A, and only then the W2' fetch of the next tile.  Both parts reload a few spilled
+        // loop invariants, and a reload waits for vmcnt(0): behind the fetch that is a whole L2 round trip (7 800 cycles for this tile when the
+        // fetch came first).
         wait_stage(K0{});
-        if (ct + 1 < W.nct[io]) { finish_Y(ct + 1); stepA(K0{}, K0{}); }
-        __builtin_amdgcn_sched_barrier(0);
-        fetchW(K0{}, min(gq + 1, gq_last));
         if (wave == 0 && !(ABL & 8)) {
+          const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), n = lane & 15, g = lane >> 4;
           const char* zr = zb + (kt & 1) * CZ_BUF + g * 512 + n * 16;
 #pragma unroll
           for (int cb = 0; cb < CZ_NCB; ++cb)
@@ -588,6 +600,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
               }
             }
         }
+        if (ct + 1 < W.nct[io]) { finish_Y(ct + 1); stepA(K0{}, K0{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        fetchW(K0{}, min(gq + 1, gq_last));
       };
 #undef WFR
       // While step B reads tile i from buffer i & 1, step A of tile i + 1 is written into the other buffer; one barrier per tile.
@@ -604,10 +619,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
           cz_static_for<0, CZ_NKT>([&](auto kt_c) {
             constexpr int kt = decltype(kt_c)::value;
             stamp(10);
-            if constexpr (kt == 5) if (ct + 1 < W.nct[io]) prefetch_x(ct + 1);   // (used at kt = 9: four tiles for the gathers)
-            if constexpr (kt < KT)
+            if constexpr (kt < KT) {
               tile(kt_c, ncb_c);
-            else
+              // (behind the tile's matrix instructions, where the wave would wait at the barrier; used at kt = 9: four tiles for the gathers)
+              if constexpr (kt == 5) if (ct + 1 < W.nct[io]) prefetch_x(ct + 1);
+            } else
               tile9(ct);
             stamp(12);
             ++gq;

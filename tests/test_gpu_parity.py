@@ -400,7 +400,7 @@ def _fused_conv_and_reduce(setup, dev, layer, fam, name, kernel):
     L.check(rc)
     torch.cuda.synchronize()
     if kernel == "k_convz":
-        # DBFR_GEMM_REDUCE_FIRST: the scalar columns of a target's FIRST message row inside a 32-edge chunk hold the sum over that segment, its
+        # DBFR_GEMM_REDUCE_FIRST: the scalar columns of a target's FIRST message row inside a chunk hold the sum over that segment, its
         # other rows zeros (include/dbfr.h); vector columns are per edge.  What the reference defines is the per-node sum: compare that, and the layout.
         mh = msg.cpu()
         seg = lambda m: torch.zeros(Nt, Dout).index_add_(0, tgt, m)
@@ -408,7 +408,8 @@ def _fused_conv_and_reduce(setup, dev, layer, fam, name, kernel):
         assert rel_err(seg(mh), seg(m_ref)) < 1e-5
         sl = o3.Irreps(o).slices()
         first = torch.ones(E, dtype=torch.bool)
-        first[1:] = (tgt[1:] != tgt[:-1]) | (torch.arange(1, E) % 32 == 0)      # (the hook's edges are one graph: chunks of 32 from edge 0)
+        first[1:] = tgt[1:] != tgt[:-1]
+        first[torch.tensor(_hook_chunk_starts(tgt))] = True          # (the hook's chunks: <= 32 edges and <= 4 targets each)
         for k, mir in enumerate(o3.Irreps(o)):
             if mir.ir.l == 0:
                 assert float(mh[~first][:, sl[k]].abs().max()) == 0.0
@@ -645,6 +646,26 @@ def test_split_kernels_match_k_conv_and_are_unit_independent(setup, dev, layer, 
     assert torch.equal(part, a[:E3])
 
 
+def _hook_chunk_starts(tgt, span=2048, max_edges=32, max_targets=4):
+    """First edge of every chunk the single-conv hooks cut a flat, target-sorted edge list into for DBFR_GEMM_REDUCE_FIRST (graph.hip chunk_len,
+    api.cpp test_conv_impl): the list is cut every `span` edges as if those were graphs; inside a span a chunk takes consecutive edges until it
+    holds 32 of them or the 5th target would begin (CZ_MAXSEG = 4)."""
+    t = tgt.tolist()
+    E, starts, es = len(t), [], 0
+    while es < E:
+        hi = min((es // span + 1) * span, E)
+        starts.append(es)
+        n, runs = 1, 1
+        while es + n < hi and n < max_edges:
+            if t[es + n] != t[es + n - 1]:
+                if runs == max_targets:
+                    break
+                runs += 1
+            n += 1
+        es += n
+    return starts
+
+
 def _node_sums(m, tgt, n):
     return torch.zeros(n, m.shape[1], dtype=torch.float64).index_add_(0, tgt.cpu().long(), m.cpu().double())
 
@@ -663,7 +684,7 @@ def test_reduce_first_matches_k_conv_and_is_unit_independent(setup, dev, layer, 
     with gemm(model, "reduce_first"):
         a = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E, dev)
         b = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E, dev)
-        E3 = (E // 3) // 32 * 32          # (a multiple of the chunk length: the chunks of the first third are the same 32-edge chunks)
+        E3 = max(e for e in _hook_chunk_starts(c["tgt"].cpu()) if e <= E // 3)   # (a chunk boundary of the full run: the chunks in front of it are the same)
         part = _run_conv_hook(lib.dbfr_test_conv2, h, layer, fam, c, E3, dev)
     assert torch.isfinite(a).all()
     n = int(c["tgt"].max()) + 1
