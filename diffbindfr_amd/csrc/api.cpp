@@ -143,6 +143,7 @@ struct dbfr_model {
   int conv2_layers;    // big batches: interaction layers [0, conv2_layers) still go through k_conv2 (their short W2 favours it)
   int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
   std::string fallback_convs;   // ';'-separated names of the convs whose weights two fp16 pieces cannot hold (dbfr_model_fallback_convs)
+  std::string rowscaled_convs;  // 'name:depth;' of the convs packed with per-row factors (dbfr_model_rowscaled_convs)
   uint32_t layer_fallback;      // bit l: interaction layer l goes through k_conv2r in DBFR_GEMM_SPLIT_F16 mode; bit 31: the torsion heads
   int* edge_log; int edge_log_steps, edge_log_graphs;   // dbfr_model_set_edge_log: caller-owned device buffer [steps][6][graphs], or null
   Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
@@ -413,7 +414,10 @@ static int pack_conv(dbfr_model* m, const TMap& tm, const std::string& name, int
 // (relative error 2^(d - 40) of the row's own dot product) -- the model routes such a conv to the three-bf16-piece kernel (bf16 has
 // fp32's exponent range), see fallback_convs.
 #define F16_ROW_DEPTH_OK 17
-static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int nt, uint16_t* out, int* depth = nullptr) {
+// rinv (may be null): per-ROW factors on top of 2^k -- every row of these tiles is multiplied by the power of two 2^d that puts ITS largest
+// magnitude into [2^14, 2^15) (as far as its bias allows), rinv[16 t + row] = 2^-d is what the kernel takes off the accumulator row
+// (k_conv2h<.., ROWF>; the hidden layers of k_conv2h / k_convz for W1h).  No row is deep any more: *depth reports what is left (bias-bound rows).
+static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int nt, uint16_t* out, int* depth = nullptr, float* rinv = nullptr) {
   constexpr int KT = 9;
   const size_t tile_h = CH_TILE_BYTES_HOST / 2, tail_off = 8192 / 2, bias_off = 9216 / 2;
   auto h16 = [](float v) { const _Float16 h = (_Float16)v; uint16_t u; memcpy(&u, &h, 2); return u; };
@@ -430,26 +434,39 @@ static int pack_f16_tiles(const float* frag, const float* bias16, int tile0, int
   for (int i = 16 * tile0; i < 16 * (tile0 + nt); ++i) bmx = std::max(bmx, fabsf(bias16[i]));
   if (bmx > 0.f) { int eb = 0; (void)frexpf(bmx, &eb); k = std::min(k, 48 - eb); }
   const float sc = ldexpf(1.f, k);
-  if (depth) {
-    int dmax = 0;
-    for (int t = tile0; t < tile0 + nt; ++t)
-      for (int row = 0; row < 16; ++row) {
-        float rm = 0.f;
-        for (int s4 = 0; s4 < KT; ++s4)
-          for (int gq = 0; gq < 4; ++gq)
-            for (int q = 0; q < 4; ++q) rm = std::max(rm, fabsf(frag[(((size_t)t * KT + s4) * 64 + 16 * gq + row) * 4 + q]));
-        if (rm > 0.f) { int er = 0; (void)frexpf(rm, &er); dmax = std::max(dmax, 15 - (er + k)); }   // (all-zero rows: padded channels)
+  std::vector<int> rowd((size_t)nt * 16, 0);        // extra exponent of every row (0 without per-row factors)
+  int dmax = 0;
+  for (int t = tile0; t < tile0 + nt; ++t)
+    for (int row = 0; row < 16; ++row) {
+      float rm = 0.f;
+      for (int s4 = 0; s4 < KT; ++s4)
+        for (int gq = 0; gq < 4; ++gq)
+          for (int q = 0; q < 4; ++q) rm = std::max(rm, fabsf(frag[(((size_t)t * KT + s4) * 64 + 16 * gq + row) * 4 + q]));
+      if (rm <= 0.f) continue;                     // (all-zero rows: padded channels)
+      int er = 0;
+      (void)frexpf(rm, &er);
+      int d = 15 - (er + k);
+      if (rinv) {
+        int up = std::max(d, 0);
+        const float br = fabsf(bias16[16 * t + row]);
+        if (br > 0.f) { int eb = 0; (void)frexpf(br, &eb); up = std::max(0, std::min(up, 48 - eb - k)); }   // (|bias| 2^(k + d) stays below 2^48, as for k)
+        up = std::min(up, 100);
+        rowd[(size_t)(t - tile0) * 16 + row] = up;
+        d -= up;
       }
-    *depth = dmax;
-  }
+      dmax = std::max(dmax, d);
+    }
+  if (depth) *depth = dmax;
+  if (rinv)
+    for (int i = 0; i < nt * 16; ++i) rinv[(size_t)tile0 * 16 + i] = ldexpf(1.f, -rowd[i]);
   for (int t = tile0; t < tile0 + nt; ++t) {
     float b[16];
-    for (int i = 0; i < 16; ++i) b[i] = bias16[16 * t + i] * sc;
+    for (int i = 0; i < 16; ++i) b[i] = bias16[16 * t + i] * ldexpf(sc, rowd[(size_t)(t - tile0) * 16 + i]);
     memcpy(&out[t * tile_h + bias_off], b, 64);
     for (int s4 = 0; s4 < KT; ++s4)
       for (int lane = 0; lane < 64; ++lane)
         for (int q = 0; q < 4; ++q) {
-          const float v = frag[(((size_t)t * KT + s4) * 64 + lane) * 4 + q] * sc;
+          const float v = frag[(((size_t)t * KT + s4) * 64 + lane) * 4 + q] * ldexpf(sc, rowd[(size_t)(t - tile0) * 16 + (lane & 15)]);
           const _Float16 hi = (_Float16)v;
           const uint16_t pc[2] = {h16(v), h16(v - (float)hi)};
           for (int i = 0; i < 2; ++i) {
@@ -604,14 +621,28 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   }
   {   // ... and into TWO fp16 pieces (conv2h.hip), run by run (a run = the tiles of one tensor-product path of one channel group):
       // pack_f16_tiles below.  k travels in RunDesc.meta bits 24..31; the kernel folds 2^-k into the run's harmonics.
+    // A conv with a run whose rows lie further apart than two fp16 pieces hold behind ONE factor (depth > F16_ROW_DEPTH_OK) is packed again with
+    // per-ROW factors (W2rinv) and served by k_conv2h<.., ROWF>, which takes them off the accumulator rows: four more vector instructions per edge
+    // block and tile instead of the six-product kernel (round 4's fall-back).  DBFR_F16_ROWSCALE=0 (developer) keeps the old routing, =2 packs
+    // every conv this way.
+    static const int rowscale = getenv("DBFR_F16_ROWSCALE") ? atoi(getenv("DBFR_F16_ROWSCALE")) : 1;
     std::vector<uint16_t> w2h((size_t)n_tiles * (CH_TILE_BYTES_HOST / 2) + 512, 0);
-    int depth_max = 0;
-    for (RunDesc& rd : runs) {
-      const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
-      int depth = 0;
-      const int k = pack_f16_tiles(w2q.data(), b2q.data(), tile0, nt, w2h.data(), &depth);
-      depth_max = std::max(depth_max, depth);
-      rd.meta = (rd.meta & 0x00ffffffu) | ((uint32_t)(k & 0xff) << 24);
+    std::vector<float> w2rinv((size_t)std::max(n_tiles, 1) * 16, 1.f);
+    int depth_max = 0, depth_run = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool rowf = pass == 1;
+      if (rowf && !(rowscale == 2 || (rowscale == 1 && depth_max > F16_ROW_DEPTH_OK))) break;
+      if (rowf) depth_run = depth_max;
+      depth_max = 0;
+      for (RunDesc& rd : runs) {
+        const int tile0 = rd.tile0_n & 0xfffff, nt = rd.tile0_n >> 20;
+        int depth = 0;
+        const int k = pack_f16_tiles(w2q.data(), b2q.data(), tile0, nt, w2h.data(), &depth, rowf ? w2rinv.data() : nullptr);
+        depth_max = std::max(depth_max, depth);
+        rd.meta = (rd.meta & 0x00ffffffu) | ((uint32_t)(k & 0xff) << 24);
+      }
+      if (!rowf) depth_run = depth_max;
+      else o->W2rinv = upload(m, w2rinv, &rc);
     }
     o->W2h = upload(m, w2h, &rc);
     // the hidden layer W1 (144 x 144) the same way: nine 16-row tiles with ONE factor 2^k1
@@ -627,8 +658,15 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
     std::vector<uint16_t> w1h((size_t)KT * (CH_TILE_BYTES_HOST / 2) + 512, 0);
     int depth1 = 0;
     o->k1 = pack_f16_tiles(w1q.data(), B1, 0, KT, w1h.data(), &depth1);
+    depth_run = std::max(depth_run, depth1);
+    if (rowscale == 2 || (rowscale == 1 && depth1 > F16_ROW_DEPTH_OK)) {
+      std::vector<float> w1rinv((size_t)KT * 16, 1.f);
+      o->k1 = pack_f16_tiles(w1q.data(), B1, 0, KT, w1h.data(), &depth1, w1rinv.data());
+      o->W1rinv = upload(m, w1rinv, &rc);
+    }
     o->W1h = upload(m, w1h, &rc);
     o->f16_depth = std::max(depth_max, depth1);
+    o->f16_depth_run = depth_run;
   }
   o->runs = upload(m, runs, &rc);
   // contiguous group ranges of near-equal tile count for S = 1, 2, 4, 8
@@ -735,13 +773,21 @@ static int pack_convz(dbfr_model* m, const TMap& tm, const std::string& name, in
   o->cdesc = upload(m, cdesc, &rc);
   o->rowinv = upload(m, rowinv, &rc);
   o->W2z = upload(m, w2z, &rc);
-  o->W1h = base.W1h; o->k1 = base.k1;
+  o->W1h = base.W1h; o->k1 = base.k1; o->W1rinv = base.W1rinv;
   return rc;
 }
 
 extern "C" int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out) {
   if (!frag || !bias || !out || !k_out || n_tiles <= 0) return fail(DBFR_ERR_ARG, "dbfr_test_pack_f16_tiles: bad argument");
   *k_out = pack_f16_tiles(frag, bias, 0, n_tiles, (uint16_t*)out);
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_test_pack_f16_rows(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out, float* rinv_out, int32_t* depth_out) {
+  if (!frag || !bias || !out || !k_out || !rinv_out || n_tiles <= 0) return fail(DBFR_ERR_ARG, "dbfr_test_pack_f16_rows: bad argument");
+  int depth = 0;
+  *k_out = pack_f16_tiles(frag, bias, 0, n_tiles, (uint16_t*)out, &depth, rinv_out);
+  if (depth_out) *depth_out = depth;
   return DBFR_OK;
 }
 
@@ -753,6 +799,18 @@ extern "C" int dbfr_test_pack_f16_depth(const float* frag, const float* bias, in
   *depth_out = depth;
   if (depth_ok_out) *depth_ok_out = F16_ROW_DEPTH_OK;
   return DBFR_OK;
+}
+
+extern "C" int dbfr_model_rowscaled_convs(const dbfr_model* m, char* names, size_t names_cap) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  int n = 0;
+  for (char c : m->rowscaled_convs) n += c == ';';
+  if (names && names_cap) {
+    const size_t len = std::min(names_cap - 1, m->rowscaled_convs.size());
+    memcpy(names, m->rowscaled_convs.data(), len);
+    names[len] = 0;
+  }
+  return n;
 }
 
 extern "C" int dbfr_model_fallback_convs(const dbfr_model* m, char* names, size_t names_cap) {
@@ -853,6 +911,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
       rc = pack_conv(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), &m->layer[l][f]);
       if (!rc) rc = pack_conv2(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer[l][f], &m->layer2[l][f]);
       if (!rc && m->layer2[l][f].f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << l; m->fallback_convs += std::string(fam[f]) + "." + std::to_string(l) + ";"; }
+      if (!rc && (m->layer2[l][f].W2rinv || m->layer2[l][f].W1rinv)) m->rowscaled_convs += std::string(fam[f]) + "." + std::to_string(l) + ":" + std::to_string(m->layer2[l][f].f16_depth_run) + ";";
       if (!rc) rc = pack_conv2(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer[l][f], &m->layer2v[l][f], true);
       if (!rc) rc = pack_convz(m, tm, std::string(fam[f]) + "." + std::to_string(l), std::min(l, 3), m->layer2[l][f], &m->layerz[l][f]);
     }
@@ -860,10 +919,12 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   if (!rc) rc = pack_conv(m, tm, "tor_bond_conv", 5, &m->tor_conv);
   if (!rc) rc = pack_conv2(m, tm, "tor_bond_conv", 5, m->tor_conv, &m->tor_conv2);
   if (!rc && m->tor_conv2.f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << 31; m->fallback_convs += "tor_bond_conv;"; }
+  if (!rc && (m->tor_conv2.W2rinv || m->tor_conv2.W1rinv)) m->rowscaled_convs += "tor_bond_conv:" + std::to_string(m->tor_conv2.f16_depth_run) + ";";
   if (!rc) rc = pack_convz(m, tm, "tor_bond_conv", 5, m->tor_conv2, &m->tor_convz);
   if (!rc && !cfg->no_sc_torsion) rc = pack_conv(m, tm, "sc_tor_bond_conv", 5, &m->sc_conv);
   if (!rc && !cfg->no_sc_torsion) rc = pack_conv2(m, tm, "sc_tor_bond_conv", 5, m->sc_conv, &m->sc_conv2);
   if (!rc && !cfg->no_sc_torsion && m->sc_conv2.f16_depth > f16_depth_ok()) { m->layer_fallback |= 1u << 31; m->fallback_convs += "sc_tor_bond_conv;"; }
+  if (!rc && !cfg->no_sc_torsion && (m->sc_conv2.W2rinv || m->sc_conv2.W1rinv)) m->rowscaled_convs += "sc_tor_bond_conv:" + std::to_string(m->sc_conv2.f16_depth_run) + ";";
   if (!rc && !cfg->no_sc_torsion) rc = pack_convz(m, tm, "sc_tor_bond_conv", 5, m->sc_conv2, &m->sc_convz);
   if (!rc) rc = pack_mlp(m, tm, "lig_node_embedding", cfg->lig_node_features + EMB, NS, NS, true, &m->lig_node_emb);
   if (!rc) rc = pack_mlp(m, tm, "lig_edge_embedding", cfg->lig_edge_features + 2 * EMB, NS, NS, true, &m->lig_edge_emb);

@@ -86,7 +86,10 @@ struct ConvW2 {
   const void* W2s;    // [n_tiles] x 13824 B: W2q cut into three bf16 pieces for k_conv2r (conv2r.hip; layout: api.cpp pack_conv2)
   const void* W1h;    // [9] x 9280 B: lin.0 (W1p's tiles, bias rows) in the W2h tile format with the one factor 2^k1, for k_conv2h's hidden layer
   int k1;
-  int f16_depth;      // largest row depth of the fp16 packing (api.cpp pack_f16_tiles): above F16_ROW_DEPTH_OK the conv is served by k_conv2r
+  int f16_depth;      // largest row depth LEFT in the fp16 packing (api.cpp pack_f16_tiles): above F16_ROW_DEPTH_OK the conv would be served by k_conv2r
+  int f16_depth_run;  // ... before the per-row factors: above F16_ROW_DEPTH_OK the rows of W2h / W1h carry their own powers of two (W2rinv / W1rinv)
+  const float* W2rinv;   // [n_tiles][16] 2^-d(row) of the rows of W2h packed with per-row factors, or null (every factor 1): k_conv2h<.., ROWF> takes them off the accumulator rows
+  const float* W1rinv;   // [144] the same for W1h's rows (hidden units), or null
   const void* W2h;    // [n_tiles] x 9280 B: W2q x 2^k(run) cut into two fp16 pieces + the tile's 16 bias values x 2^k, for k_conv2h (conv2h.hip; k in RunDesc.meta bits 24..31)
   const RunDesc* runs;    // meta bit 20: run reads the second x layout; x offsets already mapped to the LDS row
   int part_run[4][9];     // part_run[si][p] = first run of part p when the conv is cut into 1 << si parts
@@ -132,6 +135,7 @@ struct ConvZ {
   const void* W2z;        // [c tile][k tile][8 k-steps][3 w tiles][hi, lo][64 lanes][8 fp16] x 2^s(w), s per output row
   const float* rowinv;    // [n_io][48]: 2^-s(w)
   const void* W1h; int k1;   // lin.0 as in ConvW2
+  const float* W1rinv;    // [144] per-row factors of W1h to take off the hidden units, or null (ConvW2)
 };
 struct ConvZDesc {
   const int* n_edges; int max_edges;

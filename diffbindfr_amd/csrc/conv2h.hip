@@ -70,9 +70,12 @@ __device__ __forceinline__ void sum4(f32x4& o, const f32x4& a, const f32x4& b) {
 #define C2_XLD 124                                   // LDS x row: 120 floats + 4 (odd multiple of 4: 16 rows -> 16 distinct 16-B slots)
 #define C2_WAVE_FLOATS (32 * C2_XLD + 32 * 10 + 32 * 8 + 32)   // x rows | harmonics | l=2 matrix | gather indices
 
+// ABL & 1024 (a PRODUCT variant, right results): the rows of W2h carry their own powers of two (ConvW2::W2rinv: convs whose rows lie further apart
+// than two fp16 pieces hold behind one factor per run); their inverses come off the accumulator rows where the tile's two chains are added.
 template <int NW, int ABL = 0>   // ABL (developer, wrong results): 1 no contraction, 2 no ring barriers, 4 no ring filling (8: loads only, 16: LDS writes only), 32 no per-tile fetch (the unit's first shares are written again and again: real data, no loads), 512 every fetch from tiles 0..7 (always L2 hits), 64 unit prologue only; 256 (right results): ring writes right behind the barriers (slots 0 / 12 instead of 9 / 21)
 __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
   constexpr int K = 144, KT = 9;
+  constexpr bool ROWF = (ABL & 1024) != 0;
   constexpr int EPB = 32 * NW;                       // edges per block (unit)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -280,10 +283,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
           __builtin_amdgcn_sched_barrier(0);
           if (m + 1 < KT) ld_tail(m + 1);
         }
+        f32x4 rv = {1.f, 1.f, 1.f, 1.f};                  // ROWF: W1h's per-row factors (a conv with hidden-layer rows far apart) come off the units here
+        if constexpr (ROWF) if (d.w.W1rinv) rv = *reinterpret_cast<const f32x4*>(d.w.W1rinv + 16 * m + 4 * g);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { H[b][m][r] = fmaxf(aS[b][r] + aB[b][r], 0.f); mx[b] = fmaxf(mx[b], H[b][m][r]); }
+          for (int r = 0; r < 4; ++r) { H[b][m][r] = fmaxf(aS[b][r] + aB[b][r], 0.f); if constexpr (ROWF) H[b][m][r] *= rv[r]; mx[b] = fmaxf(mx[b], H[b][m][r]); }
       }
 #undef AHB
 #undef FW
@@ -349,6 +354,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
     f32x4 accN[2];                                     // bias x the edge's factor: where the next tile's small-product chain starts
     f32x4 accS[2], accB[2];                            // this tile's accumulators: small products (+ bias) | large products
     f32x4 accp[2];                                     // the previous tile's result (accS + accB), being contracted
+    f32x4 rinv_c = {1.f, 1.f, 1.f, 1.f}, rinv_n = {1.f, 1.f, 1.f, 1.f};   // ROWF: 2^-d of this lane's four rows, of this tile | of the next one
+    const float* rinv_base = ROWF && d.w.W2rinv ? d.w.W2rinv + 4 * g : nullptr;
+    auto sumr4 = [&](f32x4& o, const f32x4& x, const f32x4& y) {   // the tile's result: small-product chain + large-product chain (x the rows' factors)
+      if constexpr (ROWF) { o[0] = (x[0] + y[0]) * rinv_c[0]; o[1] = (x[1] + y[1]) * rinv_c[1]; o[2] = (x[2] + y[2]) * rinv_c[2]; o[3] = (x[3] + y[3]) * rinv_c[3]; }
+      else sum4(o, x, y);
+    };
     auto rd_step = [&](auto jc, f16x8 (&F)[2]) {
       constexpr int j = decltype(jc)::value;
 #pragma unroll
@@ -398,7 +409,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       // k-step 3 (FB): the A shares of the tile after next set out
       accS[0] = M32(accS[0], 0, 0, 1, FB, 3); SLOT(18);
       accS[1] = M32(accS[1], 0, 1, 1, FB, 3); SLOT(19);
-      accS[0] = M32(accS[0], 1, 0, 0, FB, 3); FT = *reinterpret_cast<const f16x8*>(ring + CH_TAIL_OFF + vW); SLOT(20);
+      accS[0] = M32(accS[0], 1, 0, 0, FB, 3); FT = *reinterpret_cast<const f16x8*>(ring + CH_TAIL_OFF + vW);
+      if constexpr (ROWF) if (rinv_base) rinv_n = *reinterpret_cast<const f32x4*>(rinv_base + 16 * min(t + 1, t_last));   // (a tile ahead, straight from L2: 64 bytes per tile)
+      SLOT(20);
       accS[1] = M32(accS[1], 1, 1, 0, FB, 3); if (!(ABL & 256)) putA(); SLOT(21);
       accB[0] = M32(accB[0], 0, 0, 0, FB, 3); if (!(ABL & (256 | 32))) fetchA(min(t + 2, t_last)); SLOT(22);
       accB[1] = M32(accB[1], 0, 1, 0, FB, 3); SLOT(23);
@@ -410,7 +423,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       accB[0] = MT16(accB[0], 0); rd_step(I0{}, FA); SLOT(25);
       accS[1] = MT32(accS[1], 1); SLOT(26);
       accB[1] = MT16(accB[1], 1); SLOT(27);
-      sum4(accp[1], accS[1], accB[1]);
+      sumr4(accp[1], accS[1], accB[1]);
+      if constexpr (ROWF) rinv_c = rinv_n;
       __builtin_amdgcn_sched_barrier(0);
     };
 #undef SLOT
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
       rd_step(I0{}, FA);
       bias_n = *reinterpret_cast<const f32x4*>(ring + CH_BIAS_OFF + vB);
       scale4(accN[0], bias_n, se[0]); scale4(accN[1], bias_n, se[1]);
+      if constexpr (ROWF) if (rinv_base) rinv_c = *reinterpret_cast<const f32x4*>(rinv_base + 16 * t_first);
     }
     for (int r = r_begin; r < r_end; ++r) {
       const RunDesc rd = d.w.runs[r];
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv2h(Conv2Args a) {
           if constexpr (m == 12) cop(B1{}, std::integral_constant<int, 0>{}, xp);
           if constexpr (m >= 15 && m <= 26) cop(B1{}, std::integral_constant<int, m - 14>{}, xp);
           if constexpr (m == 26) scale4(accN[0], bias_n, se[0]);
-          if constexpr (m == 27) { scale4(accN[1], bias_n, se[1]); sum4(accp[0], accS[0], accB[0]); }
+          if constexpr (m == 27) { scale4(accN[1], bias_n, se[1]); sumr4(accp[0], accS[0], accB[0]); }
         };
         // tile i carries the contraction of tile i - 1; the run's first tile carries one of zeros (same code, no second copy
         // of the loop body for the register allocator to fit)
@@ -601,6 +616,8 @@ void launch_conv2h(const Conv2Args& a, hipStream_t st) {
   if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 3) V(3) if (abl == 4) V(4) if (abl == 7) V(7) if (abl == 8) V(8) if (abl == 16) V(16)
   if (abl == 32) V(32) if (abl == 64) V(64) if (abl == 256) V(256) if (abl == 512) V(512)
 #endif
+  for (int i = 0; i < a.n_conv; ++i)
+    if (a.c[i].w.W2rinv || a.c[i].w.W1rinv) V(1024)            // a conv of this launch carries per-row factors
   V(0)
 #undef V
 }

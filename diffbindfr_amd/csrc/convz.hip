@@ -291,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
           const f16x8 wf = __builtin_bit_cast(f16x8, wt);
           const f16x8 wh = __builtin_bit_cast(f16x8, (u32x4){wt[0], wt[1], 0u, 0u});
           const float bias = __builtin_bit_cast(float, F[i % 3][1][0]);
+          const float w1r = W.W1rinv ? W.W1rinv[16 * m + n] : 1.f;
 #pragma unroll
           for (int et = 0; et < 2; ++et) {
             acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Atc[et]), wf, acc[et], 0, 0, 0);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
           for (int et = 0; et < 2; ++et)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float v = fmaxf(acc[et][q] + bias * sar[et][q], 0.f) * uar[et][q];   // = 2^k1 h
+              const float v = fmaxf(acc[et][q] + bias * sar[et][q], 0.f) * (uar[et][q] * w1r);   // = 2^k1 h (w1r: my unit's row factor of W1h off)
               Hf[m][et][q] = v;
               hmx = fmaxf(hmx, v);
             }

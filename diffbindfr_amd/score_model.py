@@ -240,10 +240,20 @@ class TensorProductModelHIP(nn.Module):
         self._handles[idx] = (fp, h)
         return h
 
+    def rowscaled_convs(self, device=None):
+        """{state_dict prefix: depth} of the convs that hold a run whose rows lie more than 2^17 apart (depth = log2 of the spread found) and
+        are therefore packed with one power-of-two factor per ROW, taken off the accumulator rows by the kernel
+        (``dbfr_model_rowscaled_convs``).  Empty for seeded weights; a trained checkpoint may name some."""
+        buf = C.create_string_buffer(8192)
+        n = L.load().dbfr_model_rowscaled_convs(self.handle(device), buf, 8192)
+        if n < 0:
+            L.check(n)
+        return {x.split(":")[0]: int(x.split(":")[1]) for x in buf.value.decode().split(";") if x}
+
     def fallback_convs(self, device=None):
-        """Names (state_dict prefixes) of the convs whose weights two fp16 pieces cannot hold -- a run whose rows lie more than 2^17
-        apart -- and which the library therefore serves through the three-bf16-piece kernel whatever ``gemm`` says
-        (``dbfr_model_fallback_convs``).  Empty for seeded weights; a trained checkpoint may name some."""
+        """Names (state_dict prefixes) of the convs that even per-row factors cannot fit into two fp16 pieces and which the library
+        therefore serves through the three-bf16-piece kernel whatever ``gemm`` says (``dbfr_model_fallback_convs``).  None since
+        ABI 5, unless a bias dwarfs its weight row by more than 2^48."""
         buf = C.create_string_buffer(4096)
         n = L.load().dbfr_model_fallback_convs(self.handle(device), buf, 4096)
         if n < 0:

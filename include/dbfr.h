@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-#define DBFR_ABI_VERSION 4   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
+#define DBFR_ABI_VERSION 5   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
                                 3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only);
-                                4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_model_set_edge_log takes the graph capacity; DBFR_GEMM_SPLIT_BF16_L1 (k_conv2s) retired; dbfr_test_conv2's message rows in that mode hold segment sums */
+                                4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_model_set_edge_log takes the graph capacity; DBFR_GEMM_SPLIT_BF16_L1 (k_conv2s) retired; dbfr_test_conv2's message rows in that mode hold segment sums;
+                                5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back); the reduce-first chunks hold <= 4 targets */
 
 typedef enum {
   DBFR_OK = 0,
@@ -434,12 +435,15 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 #define DBFR_GEMM_REDUCE_FIRST 4
 #define DBFR_GEMM_DEFAULT DBFR_GEMM_REDUCE_FIRST
 int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
-/* DBFR_GEMM_SPLIT_F16 holds a weight row to 22 significant bits while the row's largest |w| is within 2^17 of the largest |w| of its
- * tensor-product run (one power-of-two factor per run; lin.0: per matrix).  dbfr_model_create measures every run of every conv; a conv
- * with a deeper row (a trained checkpoint may hold one; seeded weights do not) is served by the DBFR_GEMM_SPLIT_BF16 kernel -- bf16 has
- * fp32's exponent range -- together with the other convs of its launch (an interaction layer / the two torsion heads), whatever the
- * mode says.  Returns the number of such convs; names (may be NULL) receives their state_dict prefixes, ';'-terminated each
- * ("atom_conv_layers.3;").                                                                                                       */
+/* DBFR_GEMM_SPLIT_F16 holds a weight row to 22 significant bits while the row's largest |w| is within 2^17 of the largest |w| that shares its
+ * power-of-two factor -- one per tensor-product run; lin.0: one per matrix.  dbfr_model_create measures every run of every conv; a conv with
+ * a deeper row (a trained checkpoint may hold one; seeded weights do not) is packed with one factor per ROW instead, which the kernel takes
+ * off the accumulator rows (ABI 5; four more vector instructions per edge block and tile): dbfr_model_rowscaled_convs counts those convs and
+ * writes "name:depth;" for each (depth = log2 of the spread that was found).  dbfr_model_fallback_convs counts the convs that even so cannot
+ * be held by two fp16 pieces and are served by the DBFR_GEMM_SPLIT_BF16 kernel together with the other convs of their launch (an interaction
+ * layer / the two torsion heads): none since ABI 5, unless a bias dwarfs its row by more than 2^48.  names (may be NULL) receives the
+ * state_dict prefixes, ';'-terminated each ("atom_conv_layers.3;").                                                                  */
+int dbfr_model_rowscaled_convs(const dbfr_model* model, char* names, size_t names_cap);
 int dbfr_model_fallback_convs(const dbfr_model* model, char* names, size_t names_cap);
 int dbfr_model_get_gemm(const dbfr_model* model);
 
@@ -461,6 +465,9 @@ int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* 
  * [64 lanes][hi 4 | lo 4 fp16] for the last 16 k, then the 16 bias values (fp32) -- everything multiplied by 2^k, the power of two that
  * puts the largest |value| of these tiles into [2^14, 2^15).  Returns k in *k_out.                                                     */
 int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out);
+/* The same packer with one power of two per ROW on top of 2^k (ABI 5; what a conv with rows further apart than 2^17 is packed with):
+ * rinv_out [n_tiles x 16] receives 2^-d(row), the factor the kernel takes off the accumulator row; *depth_out the row depth that is left. */
+int dbfr_test_pack_f16_rows(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out, float* rinv_out, int32_t* depth_out);
 /* The range guard of the same packer (host code, no GPU): the largest ROW DEPTH d of these tiles taken as one run -- the row's largest
  * |value| is 2^(15 - d) after the run's factor -- and the limit up to which two fp16 pieces hold a row to 22 significant bits (17): a conv
  * with a deeper row in one of its runs is what dbfr_model_fallback_convs reports.                                                     */

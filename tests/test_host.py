@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(L.SYMBOLS) == declared
-    assert lib.dbfr_abi_version() == 4
+    assert lib.dbfr_abi_version() == 5
 
 
 def test_gemm_mode_entry_points_reject_bad_arguments():
@@ -414,6 +414,53 @@ def test_f16_tile_packer_scales_and_splits_exactly(scale):
     assert np.isfinite(main).all() and np.abs(main[:, 0]).max() < 2 ** 15
     with pytest.raises(Exception):
         L.check(lib.dbfr_test_pack_f16_tiles(None, None, 0, None, None))
+
+
+def test_f16_tile_packer_with_per_row_factors():
+    """ABI 5: rows that lie further apart than two fp16 pieces hold behind one factor (here: every row its own size, log-uniform over TEN decades,
+    a tile of all-zero rows, a row whose bias dwarfs it) are packed with one power of two per row: every row's largest magnitude lands in
+    [2^14, 2^15), the pieces hold every value to 2^-22 of its ROW's maximum, rinv is the exact inverse power of two of the row's extra factor,
+    the bias rows carry the row's factor too, and no depth is left -- except where the bias bound stops the factor."""
+    import ctypes as C
+    lib = L.load()
+    rng = np.random.default_rng(9)
+    nt = 4
+    rowmag = 10.0 ** rng.uniform(-10, 0, (nt, 16))                     # [tile][row]
+    frag = rng.standard_normal((nt, 9, 64, 4)).astype(np.float64)
+    lane_row = np.arange(64) & 15
+    frag *= rowmag[:, None, lane_row, None]
+    frag[3] = 0.0                                                      # padded channels
+    frag = frag.astype(np.float32)
+    bias = (rng.standard_normal((nt, 16)) * rowmag).astype(np.float32)
+    out = np.zeros(nt * 9280, np.uint8)
+    k, depth = C.c_int32(), C.c_int32()
+    rinv = np.zeros(nt * 16, np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.check(lib.dbfr_test_pack_f16_rows(vp(frag), vp(bias), nt, vp(out), C.byref(k), vp(rinv), C.byref(depth)))
+    assert depth.value <= 0
+    rinv = rinv.reshape(nt, 16).astype(np.float64)
+    assert np.array_equal(np.log2(rinv), np.round(np.log2(rinv))) and (rinv <= 1).all() and (rinv[3] == 1).all()
+    tiles = out.reshape(nt, 9280)
+    main = tiles[:, :8192].copy().view(np.float16).reshape(nt, 2, 4, 64, 8).astype(np.float64)
+    tail = tiles[:, 8192:9216].copy().view(np.float16).reshape(nt, 64, 2, 4).astype(np.float64)
+    b = tiles[:, 9216:9280].copy().view(np.float32).reshape(nt, 16).astype(np.float64)
+    got = np.empty((nt, 9, 64, 4))
+    for s4 in range(8):
+        got[:, s4] = main[:, 0, s4 >> 1, :, 4 * (s4 & 1):4 * (s4 & 1) + 4] + main[:, 1, s4 >> 1, :, 4 * (s4 & 1):4 * (s4 & 1) + 4]
+    got[:, 8] = tail[:, :, 0] + tail[:, :, 1]
+    rowmax = np.abs(got).reshape(nt, 9, 4, 16, 4).max(axis=(1, 2, 4))                                 # per (tile, row) after scaling
+    assert ((rowmax[:3] >= 2 ** 14) & (rowmax[:3] < 2 ** 15)).all()
+    s = 2.0 ** -k.value
+    back = got * s * rinv[:, None, lane_row, None]                                                      # what the kernel's arithmetic sees
+    want = frag.astype(np.float64)
+    rm = np.abs(want).reshape(nt, 9, 4, 16, 4).max(axis=(1, 2, 4))[:, None, lane_row, None]
+    assert (np.abs(back - want) <= np.maximum(np.abs(want) * 2.0 ** -22, rm * 2.0 ** -39)).all()
+    assert np.allclose(b * s * rinv, bias.astype(np.float64), rtol=1e-7, atol=0)
+    # a bias that dwarfs its row stops the row's factor (|bias| 2^(k + d) < 2^48): depth is left and reported
+    bias2 = bias.copy(); bias2[0, 0] = 1e30
+    L.check(lib.dbfr_test_pack_f16_rows(vp(frag), vp(bias2), nt, vp(out), C.byref(k), vp(rinv.astype(np.float32).ravel().copy()), C.byref(depth)))
+    b2 = out.reshape(nt, 9280)[:, 9216:9280].copy().view(np.float32)
+    assert np.isfinite(b2).all() and np.abs(b2).max() < 2.0 ** 48
 
 
 def test_f16_tile_packer_keeps_the_bias_finite_next_to_tiny_weights():

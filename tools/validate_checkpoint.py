@@ -7,9 +7,9 @@ available offline: `DiffBindFR/weights/diffbindfr_paper.pth` comes from Zenodo (
   1. load the checkpoint through the drop-in's loader contract (strict=True, the way DiffBindFR/app/predict.py:118-125 ->
      druglib/core/runner/checkpoint.py loads it): every key must find its parameter; the e3nn buffer keys land in the key sinks;
   2. pack it for the device (dbfr_model_create) and report the DYNAMIC RANGE of the radial-MLP weights -- per conv the spread of its
-     lin.3 row maxima in bits -- and which convs the library routes off the two-fp16-piece kernel (dbfr_model_fallback_convs: a
-     tensor-product run whose rows lie more than 2^17 apart); on seeded weights the list is empty, what a trained checkpoint holds
-     nobody has seen here;
+     lin.3 row maxima in bits -- and which convs the library packs with per-row factors (dbfr_model_rowscaled_convs: a
+     tensor-product run whose rows lie more than 2^17 apart), with the row depth found per conv; on seeded weights the list is
+     empty, what a trained checkpoint holds nobody has seen here;
   3. with the reference importable (RDKit etc.): `examples/forward` (3DBS x its 15 SDF ligands), 40 poses each, seed 888, through the
      reference's own dataset pipeline with `model.type=DiffBindFRHIP`, and the rate of poses with ligand RMSD < 2 A against the crystal
      pose next to the notebook's 37.5 % (15 of 40, /root/reference/notebooks/AF2_model_docking.ipynb).
@@ -76,9 +76,14 @@ def main():
         stop("step 2: no ROCm device: the per-run verdict needs dbfr_model_create (there is no CPU path)")
     dev = torch.device(args.device)
     model = model.to(dev)
-    fb = model.fallback_convs(dev)
-    print(f"step 2: convs served by the three-bf16-piece kernel instead of the two-fp16-piece one: {fb or 'none'} "
-          f"(a run's rows more than 2^17 apart; include/dbfr.h: dbfr_model_fallback_convs)")
+    rs, fb = model.rowscaled_convs(dev), model.fallback_convs(dev)
+    print("step 2: convs packed with one power of two per ROW (a tensor-product run's rows more than 2^17 apart behind one factor: "
+          "k_conv2h<.., ROWF>, ~7 % slower on those launches; include/dbfr.h: dbfr_model_rowscaled_convs), with the row depth found:")
+    for name, depth in sorted(rs.items()):
+        print(f"  {name:28s} deepest row 2^-{depth} of its run's largest")
+    if not rs:
+        print("  none")
+    print(f"step 2: convs that leave the fp16 kernels for the three-bf16-piece one (a bias 2^48 above its row): {fb or 'none'}")
 
     # ---- 3. the notebook's experiment through the reference's own pipeline
     if not os.path.isdir(os.path.join(args.reference, "DiffBindFR")):
