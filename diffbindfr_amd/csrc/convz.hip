@@ -11,19 +11,22 @@
 // times as large and the saving is nil.
 //
 // Both products run on v_mfma_f32_16x16x32_f16 with fp32 operands cut into two fp16 pieces / three partial products, as in conv2h.hip:
-//   * a wave owns a CHUNK of 32 consecutive edges of one graph (chunks are cut per graph, so what is summed with what never depends on
-//     batch mates); the maximal runs of one target inside the chunk are its SEGMENTS.  Hidden layer transposed, D[edge, unit] = A W1^T:
-//     the radial-MLP inputs are the A operand straight from memory, the W1h tiles of conv2h serve unchanged as B operand, and the result
-//     registers -- unit on the lane, eight edges in registers -- ARE the B operand of step A (contraction over the edges);
-//   * step A, per segment and 16 x 16 tile (c, k): Y masked to the segment's edges (A operand, built per c tile from gathered x rows and the
-//     harmonics) x H; the 16 x 16 block of Z goes, cut into pieces, to LDS in the layout step B reads (column = segment);
-//   * step B, per 256 Z values of every column: the eight waves take one k-step of 32 each, W2' fragments straight from L2 into registers
-//     (every wave another k-step: no LDS ring), columns = the up to 32 segments of the workgroup's eight chunks; partial sums over the
-//     k-steps are added across the waves once per output irrep.
-// Scaling (exact powers of two): inputs per edge, W1 per matrix (conv2h), h per chunk, y per chunk (bound from max |x| max |sh|), Z by the
+//   * a wave owns a CHUNK: consecutive edges of one graph, at most 32 of them and at most CZ_MAXSEG = 4 targets (the chunk table of graph.hip
+//     k_chunk_count / k_graph_chunks / k_chunk_fill; chunks are cut per graph by the graph's own targets, so what is summed with what never depends
+//     on batch mates); the maximal runs of one target inside the chunk are its SEGMENTS.  Hidden layer transposed, D[edge, unit] = A W1^T: the
+//     radial-MLP inputs are the A operand straight from memory, the W1h tiles of conv2h serve unchanged as B operand, and the result registers --
+//     unit on the lane, eight edges in registers -- ARE the B operand of step A (contraction over the edges);
+//   * Y of a c tile (gathered x rows x harmonics, cut into pieces) is masked per segment ONCE per c tile and kept in registers (Ym[4][hi, lo]);
+//   * a tile (c, k) is one instruction stream per wave: step A of the NEXT tile -- four independent three-product chains Ym[j] x H[k + 1], the
+//     16 x 16 blocks of Z as fp32 into the other LDS buffer, column = segment -- with the cutting of this tile's Z in its shadow, then step B of this
+//     tile: the eight waves take one k-step of 32 each of the 256 (c, k) values of every column, W2' fragments straight from L2 into registers a
+//     whole tile ahead (every wave another k-step: no LDS ring), columns = the up to 32 segments of the workgroup's eight chunks; partial sums over
+//     the k-steps are added across the waves once per output irrep.
+// Scaling (exact powers of two): inputs per edge, W1 per matrix or per row (conv2h), h per chunk, y per chunk (bound from max |x| max |sh|), Z by the
 // constant 2^-20 (|Z| <= 32 x 2^15 x 2^15), W2' per output ROW (undone on the accumulator rows at the end: no row-depth limit).
 // The message interface is kept: the sum of a segment lands in the message row of the segment's FIRST edge, the scalar columns of its
 // other rows are zero -- k_reduce_ln[_layer] adds the rows of a node and divides by their number as before.
+// Design, cost model and what bounds the kernel: docs/kernels/conv_reduce_first.md; what was tried: profiles/TUNING_r5.md.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
