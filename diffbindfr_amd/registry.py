@@ -93,4 +93,12 @@ def register_into_druglib():
         for n, cls in reg.module_dict.items():
             if ref.get(n) is not cls:
                 ref.register_module(name=n, overwrite=ref.get(n) is not None, module=cls)
+    # ``isinstance(model, BaseMLDocker)`` gates in a user's fork: the drop-in is registered as a VIRTUAL subclass (the reference's base is an
+    # ABCMeta class, druglib/models/Docking/base.py:13) -- it has the inference surface, not the training runner's
+    try:
+        from druglib.models.Docking.base import BaseMLDocker
+        for n, cls in MLDOCK_BUILDER.module_dict.items():
+            BaseMLDocker.register(cls)
+    except Exception:
+        pass
     return True

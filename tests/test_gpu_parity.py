@@ -562,6 +562,39 @@ def test_pocket_larger_than_the_old_2048_atom_limit(setup, dev):
     assert max(errs) < SCORE_RTOL, errs
 
 
+def test_the_documented_size_limits(setup, dev):
+    """DESIGN.md section 4, invariant 6: a ligand of exactly 256 heavy atoms and a pocket of just under 8 192 atoms are SERVED
+    -- finite scores, and the default arithmetic (k_convz + k_conv2h) agrees with the fp32-instruction kernels (k_conv: other code, other
+    unit structure) at the score tolerance; one atom more is REFUSED with DBFR_ERR_ARG and a message that names the limit.  (The oracle
+    needs [E, W] weights for ~200 k edges at this size: the cross-check between the two kernel families stands in for it.)"""
+    mcfg, params, model = setup
+    sc = osched.step_scalars(osched.default_sample_cfg(), 7)
+    rng = np.random.default_rng(41)
+
+    def batch(n_atoms, n_lig):
+        pk, lg = synthetic.make_pocket(rng, n_atoms), synthetic.make_ligand(rng, n_lig)
+        d = synthetic.collate([(pk, lg) + synthetic.init_pose(rng, pk, lg, tr_sigma=2.0)])
+        return osampler.set_time(d, sc, d.num_graphs)
+
+    for n_atoms, n_lig in ((300, 256), (8060, 20)):
+        d = batch(n_atoms, n_lig)
+        if n_lig == 256:
+            assert int(d.lig_pos.shape[0]) == 256
+        else:
+            assert 7900 < int(d.rec_atm_pos.shape[0]) <= 8192
+        with gemm(model, "f32"):
+            ref = hip_scores(model, copy.deepcopy(d), dev)
+        out = hip_scores(model, copy.deepcopy(d), dev)
+        for a, b in zip(out, ref):
+            assert torch.isfinite(a).all()
+            if b.numel():
+                assert rel_err(a, b) < SCORE_RTOL
+    for n_atoms, n_lig, word in ((300, 257, "256"), (8400, 20, "8192")):
+        d = batch(n_atoms, n_lig)
+        with pytest.raises(L.DbfrError, match=word):
+            hip_scores(model, d, dev)
+
+
 def _random_conv_inputs(dev, layer, E):
     Din = [48, 84, 120, 168][min(layer, 3)] if layer >= 0 else 168
     Dout = [84, 120, 168, 168][min(layer, 3)] if layer >= 0 else 96

@@ -481,3 +481,30 @@ def test_f16_tile_packer_keeps_the_bias_finite_next_to_tiny_weights():
     frag[:] = 0
     L.check(lib.dbfr_test_pack_f16_tiles(frag.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), nt, out.ctypes.data_as(C.c_void_p), C.byref(k)))
     assert k.value == 0
+
+
+def test_register_into_druglib_with_a_stand_in_package(monkeypatch):
+    """`register_into_druglib` against a stand-in `druglib` (the real one needs its whole environment): our classes land in ITS registries under
+    their names, an existing entry of the same name is overwritten, and `DiffBindFRHIP` becomes a virtual subclass of the reference's ABCMeta base
+    `BaseMLDocker` (druglib/models/Docking/base.py:13), so `isinstance` gates in a user's fork hold."""
+    import sys, types
+    from abc import ABCMeta
+    from diffbindfr_amd import registry as R
+    mods = {n: types.ModuleType(n) for n in ("druglib", "druglib.models", "druglib.models.builder", "druglib.models.Docking", "druglib.models.Docking.base")}
+    b = mods["druglib.models.builder"]
+    b.INTERACTION, b.MLDOCK_BUILDER, b.ENERGY = R.Registry("interaction"), R.Registry("mldock"), R.Registry("energy")
+
+    class Old:                                                  # something a fork registered under our name before
+        pass
+    b.MLDOCK_BUILDER.register_module(name="DiffBindFRHIP", module=Old)
+
+    class BaseMLDocker(metaclass=ABCMeta):
+        pass
+    mods["druglib.models.Docking.base"].BaseMLDocker = BaseMLDocker
+    for n, m in mods.items():
+        monkeypatch.setitem(sys.modules, n, m)
+    assert not issubclass(dba.DiffBindFRHIP, BaseMLDocker)
+    assert R.register_into_druglib() is True
+    assert b.MLDOCK_BUILDER.get("DiffBindFRHIP") is dba.DiffBindFRHIP
+    assert b.INTERACTION.get("TensorProductModelHIP") is dba.TensorProductModelHIP
+    assert issubclass(dba.DiffBindFRHIP, BaseMLDocker) and isinstance(dba.DiffBindFRHIP(), BaseMLDocker)
