@@ -48,8 +48,8 @@ PIPE_RF = dict(kernel="k_convz + k_conv2h (one launch pair per interaction layer
                instruction="v_mfma_f32_16x16x32_f16", products=3, peak=2500.0, hidden_on_pipe=True, sustained=1937.0,
                arithmetic="three fp16 x fp16 partial products per fp32 product (two fp16 pieces per operand, exact power-of-two scalings), fp32 accumulation")
 PMC_FILE = {"f32": "profiles/r2_pmc_k_conv.json", "split": "profiles/r2_pmc_k_conv2r.json",
-            "split_f16": "profiles/r4_pmc_k_conv2h.json"}
-PMC_FILE_CFG5 = {"split_f16": "profiles/r4_cfg5_pmc_k_conv2h.json"}
+            "split_f16": "profiles/r4_pmc_k_conv2h.json", "reduce_first": "profiles/r5_pmc_conv_pair.json"}
+PMC_FILE_CFG5 = {"split_f16": "profiles/r4_cfg5_pmc_k_conv2h.json", "reduce_first": "profiles/r5_cfg5_pmc_conv_pair.json"}
 HALF_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 W2_SHARE = 34992.0 / (34992.0 + 6 * 144.0)   # share of the conv flops 2*144*(144+W) that is the 144 x W GEMM (W = 2880, 3888, 4896, 7776 x3)
 # what the matrix pipe executes per algorithmic fp32 product of the 144 x W GEMM, and on which instruction (include/dbfr.h: DBFR_GEMM_*)

@@ -16,12 +16,19 @@ void launch_conv2r(const Conv2Args& a, hipStream_t st);
 void launch_conv2h(const Conv2Args& a, hipStream_t st);
 void launch_convz(const ConvZArgs& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
-                      const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st);
+                      const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st, const uint8_t* first = nullptr, unsigned long long sc_lanes = 0);
 struct ReduceLayerArgs {
   const float* msg[4]; const int* row_start[4]; const int* row_cnt[4]; LNDesc ln[4];
   int NL, NA, D, D_old;
   const float* old_l; const float* old_a; float* out_l; float* out_a;
+  const uint8_t* first[4]; unsigned long long sc_lanes[4];   // (conv.hip: DBFR_GEMM_REDUCE_FIRST reads the scalar-output columns of a segment's first row only)
 };
+// the lanes (one float4 of message columns each) that hold the scalar-output columns k_convz writes: 12 per irrep from out_off / 4
+static unsigned long long convz_sc_lanes(const ConvZ& z) {
+  unsigned long long m = 0;
+  for (int i = 0; i < z.n_io; ++i) m |= 0xfffull << (z.out_off[i] / 4);
+  return m;
+}
 void launch_reduce_ln_layer(const ReduceLayerArgs& a, hipStream_t st);
 enum SetKind { SET_LL = 0, SET_AA = 1, SET_AL = 2, SET_LA = 3, SET_TOR = 4, SET_SC = 5, N_SETS = 6 };
 struct GraphArgs {
@@ -1021,6 +1028,7 @@ static void edge_set_take(Bump& b, EdgeSet& S, int cap, int n_targets, int G, in
   // k_convz's chunk table: a chunk ends after 32 edges, at the end of its graph or with the end of its CZ_MAXSEG-th target (graph.hip k_graph_chunks)
   S.chunk_cap = cap > 0 ? cap / 32 + n_targets / CZ_MAXSEG + n_graphs + 8 : 0;
   S.chunk_es = b.take<int>(std::max(S.chunk_cap, 1), (p + ".chunk_es").c_str()); S.chunk_gl = b.take<int>(std::max(S.chunk_cap, 1), (p + ".chunk_gl").c_str());
+  S.seg_first = b.take<uint8_t>(std::max(cap, 1), (p + ".seg_first").c_str());
 }
 
 static int plan(const dbfr_model* m, const dbfr_batch* B, const dbfr_limits* lim, char* base, size_t cap, Ws* w,
@@ -1280,7 +1288,10 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
       conv2_call(m, ds, Ws, 4, st, (m->layer_fallback >> l) & 1u, rf ? zs : nullptr);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
-      for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
+      for (int i = 0; i < 4; ++i) {
+        ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln;
+        ra.first[i] = rf ? es[i]->seg_first : nullptr; ra.sc_lanes[i] = rf ? convz_sc_lanes(m->layerz[l][i]) : 0;
+      }
       ra.NL = NL; ra.NA = NA; ra.D = Do; ra.D_old = Di; ra.old_l = lx; ra.old_a = ax; ra.out_l = lnew; ra.out_a = anew;
       launch_reduce_ln_layer(ra, st);
     } else if (m->conv_fuse && !w.multi) {   // bench-sized batches: the layer's four convs as ONE k_conv grid, one reduction launch
@@ -1304,7 +1315,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
           launch_acc_flops(c4[i].n_edges, 2.0 * 144 * (144.0 + m->layer[l][i].W), 4.0 * (m->layer[l][i].W + Di + 9) + 16.0, fused_bytes(Di, Do), m->flops_dev, st);
       ReduceLayerArgs ra;
       const EdgeSet* es[4] = {&LL, &AL, &AA, &LA};
-      for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; }
+      for (int i = 0; i < 4; ++i) { ra.msg[i] = w.msg[i]; ra.row_start[i] = es[i]->row_start; ra.row_cnt[i] = es[i]->row_cnt; ra.ln[i] = m->layer[l][i].ln; ra.first[i] = nullptr; ra.sc_lanes[i] = 0; }
       ra.NL = NL; ra.NA = NA; ra.D = Do; ra.D_old = Di; ra.old_l = lx; ra.old_a = ax; ra.out_l = lnew; ra.out_a = anew;
       launch_reduce_ln_layer(ra, st);
     } else if (!w.multi || m->profile == 1) {   // profiling times each conv alone on the main stream
@@ -1401,11 +1412,11 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     }
     if (nd) conv2_call(m, ds, Ws, nd, st, (m->layer_fallback >> 31) & 1u, rf ? zs : nullptr);
     if (do_t) {
-      launch_reduce_ln(w.msg[0], T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st);
+      launch_reduce_ln(w.msg[0], T.row_start, T.row_cnt, B->NTOR, 2 * NS, m->tor_conv.ln, nullptr, 0, w.tor_feat, 2 * NS, 2, st, rf ? T.seg_first : nullptr, rf ? convz_sc_lanes(m->tor_convz) : 0);
       launch_tor_final(w.tor_feat, m->tor_final, c->tor_score_norm2, cfg.scale_by_sigma, B->NTOR, out->tor, st);
     }
     if (do_s) {
-      launch_reduce_ln(w.msg[1], S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, st);
+      launch_reduce_ln(w.msg[1], S.row_start, S.row_cnt, B->NSC, 2 * NS, m->sc_conv.ln, nullptr, 0, w.sc_feat, 2 * NS, 2, st, rf ? S.seg_first : nullptr, rf ? convz_sc_lanes(m->sc_convz) : 0);
       launch_tor_final(w.sc_feat, m->sc_final, c->sc_tor_score_norm2, cfg.scale_by_sigma, B->NSC, out->sc_tor, st);
     }
     return DBFR_OK;
@@ -1710,6 +1721,8 @@ static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t fami
     const ConvZDesc z = convz_desc(d, layer >= 0 ? m->layerz[layer][family] : layer == -2 ? m->tor_convz : m->sc_convz, tgt, cw->D_out,
                                    scratch ? scratch + n_span + 1 : nullptr, scratch ? scratch + n_span + 1 + ccap : nullptr, scratch ? scratch + n_span : nullptr, ccap);
     const int W = cw->W;
+    // (k_convz writes the scalar-output columns of a segment's first row only; the hook's documented layout has zeros in the other rows)
+    if (rf) HIPCHECK(hipMemsetAsync(msg, 0, (size_t)n_edges * cw->D_out * sizeof(float), (hipStream_t)hip_stream));
     conv2_call(m, &d, &W, 1, (hipStream_t)hip_stream, deep, rf ? &z : nullptr);
   } else {
     conv_call(m, *cw, n_edges_dev, n_edges, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx, msg, (hipStream_t)hip_stream);

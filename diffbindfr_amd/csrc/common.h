@@ -194,6 +194,8 @@ struct EdgeSet {           // one per-step edge list, grouped (CSR) by scatter-t
   int* chunk_es;       // [chunk_cap] first edge of every chunk (k_chunk_fill)
   int* chunk_gl;       // [chunk_cap] graph << 6 | number of edges (<= 32, holding <= CZ_MAXSEG targets)
   int chunk_cap;
+  uint8_t* seg_first;  // [cap] 1: the edge starts a segment (first edge of its target inside its chunk) -- k_convz stores a segment's scalar-output sum in that
+                       // message row and writes nothing into the scalar columns of the other rows; the reductions read those columns of flagged rows only
 };
 
 struct ConvArgs {

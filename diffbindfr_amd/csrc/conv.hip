@@ -480,10 +480,54 @@ void launch_conv(const ConvArgs& a, hipStream_t st) {
 // Segmented mean + equivariant LayerNorm + residual (tpscore.py:190,196-197,513-516; :53-104).
 // One wavefront per target node; the node's messages are contiguous rows [row_start, +row_cnt).
 //   mode 0: out[n] = pad(old[n], D) + LN(mean)      mode 1: out[n] += LN(mean)     mode 2: out[n] = LN(mean)
+// Sum of a node's message rows [rs, rs + rc), one float4 of columns per lane (lane < D / 4), in CSR order.  first != null (DBFR_GEMM_REDUCE_FIRST): the lanes
+// of `sc_lanes` hold scalar-output columns, which k_convz writes in the FIRST row of every segment only (the other rows of these columns hold stale
+// data): those lanes add flagged rows only.  The flags of up to 64 rows are fetched by one load and kept as a wave mask in scalar registers.
+__device__ __forceinline__ f32x4 row_sum(const float* __restrict__ msg, int rs, int rc, int D, int lane, const uint8_t* __restrict__ first, unsigned long long sc_lanes) {
+  const int d4 = D >> 2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4* r = reinterpret_cast<const f32x4*>(msg + (size_t)rs * D) + min(lane, d4 - 1);
+  if (!first) {
+    if (lane < d4) {
+      int e = 0;
+      // eight rows requested before the first add (the adds keep the CSR order: same bits as any other unrolling)
+      for (; e + 8 <= rc; e += 8) {
+        const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
+        const f32x4 v4 = r[(size_t)(e + 4) * d4], v5 = r[(size_t)(e + 5) * d4], v6 = r[(size_t)(e + 6) * d4], v7 = r[(size_t)(e + 7) * d4];
+        acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+      }
+      for (; e + 4 <= rc; e += 4) {
+        const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
+        acc += v0; acc += v1; acc += v2; acc += v3;
+      }
+      for (; e < rc; ++e) acc += r[(size_t)e * d4];
+    }
+    return acc;
+  }
+  const bool sc = (sc_lanes >> lane) & 1ull;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int e0 = 0; e0 < rc; e0 += 64) {
+    const int nb = min(64, rc - e0);
+    const unsigned long long fl = __ballot(lane < nb && first[rs + e0 + lane] != 0);     // (all 64 lanes take part)
+    if (lane < d4) {
+      int e = 0;
+      for (; e + 4 <= nb; e += 4) {            // four rows requested before the first add; a row these columns were not written in contributes nothing
+        const bool t0 = !sc || ((fl >> e) & 1ull), t1 = !sc || ((fl >> (e + 1)) & 1ull), t2 = !sc || ((fl >> (e + 2)) & 1ull), t3 = !sc || ((fl >> (e + 3)) & 1ull);
+        const f32x4 v0 = t0 ? r[(size_t)(e0 + e) * d4] : zero, v1 = t1 ? r[(size_t)(e0 + e + 1) * d4] : zero;
+        const f32x4 v2 = t2 ? r[(size_t)(e0 + e + 2) * d4] : zero, v3 = t3 ? r[(size_t)(e0 + e + 3) * d4] : zero;
+        acc += v0; acc += v1; acc += v2; acc += v3;
+      }
+      for (; e < nb; ++e)
+        if (!sc || ((fl >> e) & 1ull)) acc += r[(size_t)(e0 + e) * d4];
+    }
+  }
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ msg, const int* __restrict__ row_start,
                                                    const int* __restrict__ row_cnt, int N, int D, LNDesc ln,
                                                    const float* __restrict__ old, int D_old, float* __restrict__ out,
-                                                   int ldo, int mode) {
+                                                   int ldo, int mode, const uint8_t* first, unsigned long long sc_lanes) {
   __shared__ float buf[4][MAXD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int node_raw = blockIdx.x * 4 + wave;
@@ -493,15 +537,8 @@ __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ msg
   // rows are 16-B aligned (D is a multiple of 4): one float4 per lane covers a row, four rows are requested before the
   // first add so that one L2 round trip serves four edges; the adds keep the edge order (reproducible, order = CSR order)
   const int d4 = D >> 2;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 acc = row_sum(msg, rs, rc, D, lane, first, sc_lanes);
   if (lane < d4) {
-    const f32x4* r = reinterpret_cast<const f32x4*>(msg + (size_t)rs * D) + lane;
-    int e = 0;
-    for (; e + 4 <= rc; e += 4) {
-      const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
-      acc += v0; acc += v1; acc += v2; acc += v3;
-    }
-    for (; e < rc; ++e) acc += r[(size_t)e * d4];
     const float cntf = (float)max(rc, 1);
     float* bw = buf[wave] + 4 * lane;
     bw[0] = acc[0] / cntf; bw[1] = acc[1] / cntf; bw[2] = acc[2] / cntf; bw[3] = acc[3] / cntf;
@@ -557,10 +594,10 @@ __global__ __launch_bounds__(256) void k_reduce_ln(const float* __restrict__ msg
 }
 
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
-                      const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st) {
+                      const float* old, int D_old, float* out, int ldo, int mode, hipStream_t st, const uint8_t* first, unsigned long long sc_lanes) {
   if (N <= 0) return;
   hipLaunchKernelGGL(k_reduce_ln, dim3((N + 3) / 4), dim3(256), 0, st, msg, row_start, row_cnt, N, D, ln, old, D_old,
-                     out, ldo, mode);
+                     out, ldo, mode, first, sc_lanes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,25 +608,13 @@ struct ReduceLayerArgs {
   const float* msg[4]; const int* row_start[4]; const int* row_cnt[4]; LNDesc ln[4];   // ll, al, aa, la
   int NL, NA, D, D_old;
   const float* old_l; const float* old_a; float* out_l; float* out_a;
+  const uint8_t* first[4]; unsigned long long sc_lanes[4];   // DBFR_GEMM_REDUCE_FIRST: the segment-start flags of the four edge sets and the lanes of scalar-output columns (row_sum), else null / 0
 };
 
-__device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, int rc, int D, const LNDesc& ln, float* bw, int lane) {
+__device__ __forceinline__ void mean_ln(const float* __restrict__ msg, int rs, int rc, int D, const LNDesc& ln, float* bw, int lane, const uint8_t* first, unsigned long long sc_lanes) {
   const int d4 = D >> 2;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 acc = row_sum(msg, rs, rc, D, lane, first, sc_lanes);
   if (lane < d4) {
-    const f32x4* r = reinterpret_cast<const f32x4*>(msg + (size_t)rs * D) + lane;
-    int e = 0;
-    // eight rows requested before the first add (the adds keep the CSR order: same bits as any other unrolling)
-    for (; e + 8 <= rc; e += 8) {
-      const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
-      const f32x4 v4 = r[(size_t)(e + 4) * d4], v5 = r[(size_t)(e + 5) * d4], v6 = r[(size_t)(e + 6) * d4], v7 = r[(size_t)(e + 7) * d4];
-      acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
-    }
-    for (; e + 4 <= rc; e += 4) {
-      const f32x4 v0 = r[(size_t)e * d4], v1 = r[(size_t)(e + 1) * d4], v2 = r[(size_t)(e + 2) * d4], v3 = r[(size_t)(e + 3) * d4];
-      acc += v0; acc += v1; acc += v2; acc += v3;
-    }
-    for (; e < rc; ++e) acc += r[(size_t)e * d4];
     const float cntf = (float)max(rc, 1);
     bw[4 * lane] = acc[0] / cntf; bw[4 * lane + 1] = acc[1] / cntf; bw[4 * lane + 2] = acc[2] / cntf; bw[4 * lane + 3] = acc[3] / cntf;
   }
@@ -645,8 +670,8 @@ __global__ __launch_bounds__(256) void k_reduce_ln_layer(ReduceLayerArgs a) {
   const int N = lig ? a.NL : a.NA;
   if (node >= N) return;                         // waves are independent here (wave-level barriers only)
   const int s0 = lig ? 0 : 2;
-  mean_ln(a.msg[s0], a.row_start[s0][node], a.row_cnt[s0][node], a.D, a.ln[s0], buf[wave][0], lane);
-  mean_ln(a.msg[s0 + 1], a.row_start[s0 + 1][node], a.row_cnt[s0 + 1][node], a.D, a.ln[s0 + 1], buf[wave][1], lane);
+  mean_ln(a.msg[s0], a.row_start[s0][node], a.row_cnt[s0][node], a.D, a.ln[s0], buf[wave][0], lane, a.first[s0], a.sc_lanes[s0]);
+  mean_ln(a.msg[s0 + 1], a.row_start[s0 + 1][node], a.row_cnt[s0 + 1][node], a.D, a.ln[s0 + 1], buf[wave][1], lane, a.first[s0 + 1], a.sc_lanes[s0 + 1]);
   const float* old = (lig ? a.old_l : a.old_a) + (size_t)node * a.D_old;
   float* out = (lig ? a.out_l : a.out_a) + (size_t)node * a.D;
 #pragma unroll

@@ -24,8 +24,9 @@
 //     the k-steps are added across the waves once per output irrep.
 // Scaling (exact powers of two): inputs per edge, W1 per matrix or per row (conv2h), h per chunk, y per chunk (bound from max |x| max |sh|), Z by the
 // constant 2^-20 (|Z| <= 32 x 2^15 x 2^15), W2' per output ROW (undone on the accumulator rows at the end: no row-depth limit).
-// The message interface is kept: the sum of a segment lands in the message row of the segment's FIRST edge, the scalar columns of its
-// other rows are zero -- k_reduce_ln[_layer] adds the rows of a node and divides by their number as before.
+// Message interface: the sum of a segment lands in the message row of the segment's FIRST edge; the scalar columns of its other rows are not
+// written -- k_reduce_ln[_layer] add a node's flagged rows for these columns (EdgeSet::seg_first, written with the chunk table) and all rows
+// for the vector columns, and divide by the number of edges as before.
 // Design, cost model and what bounds the kernel: docs/kernels/conv_reduce_first.md; what was tried: profiles/TUNING_r5.md.
 #include <cstdio>
 #include <cstdlib>
@@ -167,18 +168,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       w_sh[sl * 12 + 9] = w_sh[sl * 12 + 10] = w_sh[sl * 12 + 11] = 0.f;
     }
     if (lane == 0) b_nseg[wave] = nseg;
-    // ---- zero the scalar columns of the message rows that are not the first of their segment
-    if (have) {
-      const unsigned rest = (len >= 32 ? 0xffffffffu : ((1u << len) - 1u)) & ~firsts;
-      const int per_row = 12 * W.n_io;                       // float4 stores per row
-      for (int s0 = 0; s0 < 32; s0 += 2) {
-        const int s = s0 + (lane >> 5), j = lane & 31;
-        if (((rest >> s) & 1u) && j < per_row) {
-          const int io = j / 12;
-          *reinterpret_cast<f32x4*>(d.msg + (size_t)(es + s) * d.D_out + W.out_off[io] + 4 * (j - 12 * io)) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
+    // (the scalar columns of the message rows that are not the first of their segment are NOT written: the reductions read those columns of flagged rows
+    // only -- EdgeSet::seg_first, conv.hip row_sum; round 5's first kernel zeroed them, 1.5 GB of stores per layer launch, and the reduction read them back)
     // ---- bounds for the y scale: largest |x| over the gathered rows, largest |harmonic|
     float xmx = 0.f, smx = 0.f;
     if (have) {

@@ -425,13 +425,14 @@ void launch_edges(const GraphArgs& A0, bool with_heads_only, hipStream_t st) {
 // Chunks for the reduce-first conv (convz.hip): consecutive edges of ONE graph, at most 32 of them and at most CZ_MAXSEG scatter targets (a chunk
 // never holds edges of two graphs, and where it is cut depends on the graph's own targets only: which edges are summed together does not depend
 // on batch mates).  chunk_len: the next chunk of the edge range [es, hi), called by a whole wave; the length is wave-uniform.
-__device__ __forceinline__ int chunk_len(const int* tgt, int es, int hi) {
+__device__ __forceinline__ int chunk_len(const int* tgt, int es, int hi, unsigned* starts = nullptr) {
   const int lane = threadIdx.x & 63;
   const int n = min(32, hi - es);
   int t = 0;
   if (lane < n) t = tgt[es + lane];
   const int tp = __shfl_up(t, 1);
   unsigned f = (unsigned)__ballot(lane < n && (lane == 0 || t != tp));   // starts of the maximal runs of one target
+  if (starts) *starts = f;
 #pragma unroll
   for (int i = 0; i < CZ_MAXSEG; ++i) f &= f - 1;
   return f ? __ffs((int)f) - 1 : n;                      // up to the start of run CZ_MAXSEG + 1
@@ -488,8 +489,11 @@ __global__ __launch_bounds__(256) void k_chunk_fill(GraphArgs A) {
   graph_edge_range(A, S, g, lo, hi);
   int ch = S.chunk0[g];
   for (int es = lo; es < hi && ch < S.chunk_cap; ++ch) {
-    const int len = chunk_len(S.tgt, es, hi);
-    if ((threadIdx.x & 63) == 0) { S.chunk_es[ch] = es; S.chunk_gl[ch] = (g << 6) | len; }
+    unsigned starts = 0;
+    const int len = chunk_len(S.tgt, es, hi, &starts);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) { S.chunk_es[ch] = es; S.chunk_gl[ch] = (g << 6) | len; }
+    if (lane < len) S.seg_first[es + lane] = (starts >> lane) & 1u;      // (every edge lies in exactly one chunk: no clearing pass)
     es += len;
   }
 }
