@@ -1731,6 +1731,18 @@ static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t fami
   return take_launch_error();
 }
 
+// Test hook: the chunk table of DBFR_GEMM_REDUCE_FIRST for one flat, target-sorted edge list, cut every `span` edges as if those were graphs
+// (graph.hip k_flat_chunk_*; the same chunk_len as the per-graph kernels of the sampler).  Device pointers; scratch = n_span + 1 ints.
+extern "C" int dbfr_test_chunk_table(const int32_t* tgt, const int32_t* n_edges_dev, int32_t max_edges, int32_t span, int32_t* scratch, int32_t cap,
+                                     int32_t* chunk_es, int32_t* chunk_gl, void* hip_stream) {
+  if (!tgt || !n_edges_dev || !scratch || !chunk_es || !chunk_gl || span <= 0 || max_edges < 0 || cap <= 0) return fail(DBFR_ERR_ARG, "dbfr_test_chunk_table: bad argument");
+  g_launch_err = false;
+  const int n_span = std::max((max_edges + span - 1) / span, 1);
+  launch_flat_chunks(tgt, n_edges_dev, max_edges, span, n_span, scratch, cap, chunk_es, chunk_gl, (hipStream_t)hip_stream);
+  HIPCHECK(hipGetLastError());
+  return take_launch_error();
+}
+
 extern "C" int dbfr_test_conv(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edges, const int32_t* n_edges_dev,
                               const int32_t* tgt, const int32_t* gth, const float* emb, const float* sh,
                               const float* tab1, int32_t ld1, const int32_t* idx1, const float* tab2, int32_t ld2,

@@ -33,7 +33,7 @@ extern "C" {
 #define DBFR_ABI_VERSION 5   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
                                 3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only);
                                 4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_model_set_edge_log takes the graph capacity; DBFR_GEMM_SPLIT_BF16_L1 (k_conv2s) retired; dbfr_test_conv2's message rows in that mode hold segment sums;
-                                5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back); the reduce-first chunks hold <= 4 targets */
+                                5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back), dbfr_test_pack_f16_rows, dbfr_test_chunk_table; the reduce-first chunks hold <= 4 targets */
 
 typedef enum {
   DBFR_OK = 0,
@@ -464,6 +464,11 @@ int dbfr_conv_paths(int32_t kind, int32_t* table10, int32_t max_paths, int32_t* 
  * fragments (K = 144), bias = n_tiles x 16; out = n_tiles x 9280 bytes: [hi, lo][4 k-steps of 32][64 lanes][8 fp16], then
  * [64 lanes][hi 4 | lo 4 fp16] for the last 16 k, then the 16 bias values (fp32) -- everything multiplied by 2^k, the power of two that
  * puts the largest |value| of these tiles into [2^14, 2^15).  Returns k in *k_out.                                                     */
+/* Test hook (GPU): the chunk table k_convz walks, for one flat target-sorted edge list cut every `span` edges as if those were graphs: a chunk =
+ * consecutive edges, at most 32 of them and at most four targets.  All pointers are device pointers; scratch holds (max_edges + span - 1) / span + 1
+ * ints and receives the first chunk of every span, the total behind them; chunk_es[ch] = first edge, chunk_gl[ch] = number of edges (graph 0). */
+int dbfr_test_chunk_table(const int32_t* tgt, const int32_t* n_edges_dev, int32_t max_edges, int32_t span, int32_t* scratch, int32_t cap,
+                          int32_t* chunk_es, int32_t* chunk_gl, void* hip_stream);
 int dbfr_test_pack_f16_tiles(const float* frag, const float* bias, int32_t n_tiles, void* out, int32_t* k_out);
 /* The same packer with one power of two per ROW on top of 2^k (ABI 5; what a conv with rows further apart than 2^17 is packed with):
  * rinv_out [n_tiles x 16] receives 2^-d(row), the factor the kernel takes off the accumulator row; *depth_out the row depth that is left. */

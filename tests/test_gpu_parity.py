@@ -699,6 +699,49 @@ def _hook_chunk_starts(tgt, span=2048, max_edges=32, max_targets=4):
     return starts
 
 
+@pytest.mark.parametrize("case", ["random", "one_target", "all_distinct", "runs_of_9", "empty", "span_edge"])
+def test_chunk_table_follows_the_rule(dev, case):
+    """The chunk table k_convz walks (graph.hip chunk_len / k_flat_chunk_*, the same walk as the sampler's per-graph kernels) against the rule stated in
+    docs/kernels/conv_reduce_first.md, restated in Python (`_hook_chunk_starts`): consecutive edges, at most 32 and at most four targets per chunk,
+    a new chunk at every span boundary; every edge lies in exactly one chunk."""
+    g = torch.Generator().manual_seed(3)
+    span = 2048
+    E = {"random": 9000, "one_target": 300, "all_distinct": 500, "runs_of_9": 4097, "empty": 0, "span_edge": 2 * span}[case]
+    if case == "random":
+        tgt = torch.sort(torch.randint(0, 700, (E,), generator=g)).values
+    elif case == "one_target":
+        tgt = torch.zeros(E, dtype=torch.int64)
+    elif case == "all_distinct":
+        tgt = torch.arange(E)
+    elif case == "runs_of_9":
+        tgt = torch.arange(E) // 9
+    elif case == "span_edge":
+        tgt = torch.arange(E) // 40                       # a target straddles the span boundary
+    else:
+        tgt = torch.zeros(0, dtype=torch.int64)
+    lib = L.load()
+    cap = E // 32 + E // 4 + E // span + 16
+    n_span = max((E + span - 1) // span, 1)
+    tgtd = tgt.to(dev, torch.int32) if E else torch.zeros(1, dtype=torch.int32, device=dev)
+    ned = torch.tensor([E], dtype=torch.int32, device=dev)
+    scratch = torch.zeros(n_span + 1, dtype=torch.int32, device=dev)
+    ces, cgl = torch.full((cap,), -1, dtype=torch.int32, device=dev), torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    L.check(lib.dbfr_test_chunk_table(ptr(tgtd), ptr(ned), E, span, ptr(scratch), cap, ptr(ces), ptr(cgl), None))
+    torch.cuda.synchronize()
+    n = int(scratch[n_span])
+    want = _hook_chunk_starts(tgt, span=span)
+    assert n == len(want)
+    if n == 0:
+        assert E == 0
+        return
+    es, ln = ces[:n].cpu().tolist(), cgl[:n].cpu().tolist()
+    assert es == want
+    assert all(1 <= x <= 32 for x in ln) and [a + b for a, b in zip(es, ln)] == want[1:] + [E]
+    for a, b in zip(es, ln):
+        assert len(torch.unique(tgt[a:a + b])) <= 4
+
+
 def _node_sums(m, tgt, n):
     return torch.zeros(n, m.shape[1], dtype=torch.float64).index_add_(0, tgt.cpu().long(), m.cpu().double())
 
