@@ -511,10 +511,14 @@ __device__ __forceinline__ f32x4 row_sum(const float* __restrict__ msg, int rs, 
     const unsigned long long fl = __ballot(lane < nb && first[rs + e0 + lane] != 0);     // (all 64 lanes take part)
     if (lane < d4) {
       int e = 0;
-      for (; e + 4 <= nb; e += 4) {            // four rows requested before the first add; a row these columns were not written in contributes nothing
-        const bool t0 = !sc || ((fl >> e) & 1ull), t1 = !sc || ((fl >> (e + 1)) & 1ull), t2 = !sc || ((fl >> (e + 2)) & 1ull), t3 = !sc || ((fl >> (e + 3)) & 1ull);
-        const f32x4 v0 = t0 ? r[(size_t)(e0 + e) * d4] : zero, v1 = t1 ? r[(size_t)(e0 + e + 1) * d4] : zero;
-        const f32x4 v2 = t2 ? r[(size_t)(e0 + e + 2) * d4] : zero, v3 = t3 ? r[(size_t)(e0 + e + 3) * d4] : zero;
+      // eight (then four) rows requested before the first add; a row these columns were not written in contributes nothing
+      auto row = [&](int i) { return (!sc || ((fl >> i) & 1ull)) ? r[(size_t)(e0 + i) * d4] : zero; };
+      for (; e + 8 <= nb; e += 8) {
+        const f32x4 v0 = row(e), v1 = row(e + 1), v2 = row(e + 2), v3 = row(e + 3), v4 = row(e + 4), v5 = row(e + 5), v6 = row(e + 6), v7 = row(e + 7);
+        acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+      }
+      for (; e + 4 <= nb; e += 4) {
+        const f32x4 v0 = row(e), v1 = row(e + 1), v2 = row(e + 2), v3 = row(e + 3);
         acc += v0; acc += v1; acc += v2; acc += v3;
       }
       for (; e < nb; ++e)
