@@ -632,7 +632,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
     // per-ROW factors (W2rinv) and served by k_conv2h<.., ROWF>, which takes them off the accumulator rows: four more vector instructions per edge
     // block and tile instead of the six-product kernel (round 4's fall-back).  DBFR_F16_ROWSCALE=0 (developer) keeps the old routing, =2 packs
     // every conv this way.
-    static const int rowscale = getenv("DBFR_F16_ROWSCALE") ? atoi(getenv("DBFR_F16_ROWSCALE")) : 1;
+    const int rowscale = getenv("DBFR_F16_ROWSCALE") ? atoi(getenv("DBFR_F16_ROWSCALE")) : 1;   // (read at every model creation: a test packs one model this way)
     std::vector<uint16_t> w2h((size_t)n_tiles * (CH_TILE_BYTES_HOST / 2) + 512, 0);
     std::vector<float> w2rinv((size_t)std::max(n_tiles, 1) * 16, 1.f);
     int depth_max = 0, depth_run = 0;

@@ -106,6 +106,27 @@ def test_trajectory_matches_reference_fixture(setup, dev, both_gemms):
     assert (a14.cpu() - torch.from_numpy(z["traj_atom14"])).norm(dim=-1).max() < POSE_ATOL
 
 
+@pytest.mark.parametrize("mode", ["reduce_first", "split_f16"])
+def test_reference_trajectory_with_per_row_factors_on_every_conv(dev, monkeypatch, mode):
+    """The ROWF instantiation of k_conv2h (and the per-row factors of lin.0 in both hidden layers) on weights that do not need it: a model packed with
+    DBFR_F16_ROWSCALE=2 carries one power of two per row on EVERY conv (26 listed) and must follow the reference-generated 20-step trajectory like the
+    default packing does -- the factors are exact powers of two taken off again, so nothing but the rounding of the pieces changes."""
+    monkeypatch.setenv("DBFR_F16_ROWSCALE", "2")
+    mcfg = sm.default_cfg()
+    model = dba.TensorProductModelHIP({}).to(dev)
+    model.load_state_dict(sm.init_params(mcfg, seed=1), strict=True)
+    assert len(model.rowscaled_convs(dev)) == 26 and model.fallback_convs(dev) == []
+    d, z = load_golden_batch()
+    with gemm(model, mode):
+        samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
+        pb = PackedBatch(namespace_to(d, dev), dev)
+        noise = {k: torch.from_numpy(z[f"noise_{k}"]).to(dev).contiguous() for k in ("tr", "rot", "tor", "sc")}
+        lig, a14 = samp.sample_packed(pb, noise, visualize=True)
+    assert (lig.cpu() - torch.from_numpy(z["traj_lig"])).norm(dim=-1).max() < POSE_ATOL
+    assert (a14.cpu() - torch.from_numpy(z["traj_atom14"])).norm(dim=-1).max() < POSE_ATOL
+    model.release()
+
+
 def test_level1_model_inside_the_reference_style_sampler_loop(setup, dev):
     """The level-1 drop-in (`--cfg-options model.diffusion_model.type=TensorProductModelHIP`): only the score
     network is replaced, the sampler loop stays the reference's.  Here the loop is the oracle's restatement of scFlex.py:124-250 (deepcopy,
