@@ -1706,12 +1706,16 @@ static int test_conv_impl(dbfr_model* m, bool conv2, int32_t layer, int32_t fami
     if (rf && layer < 0) d.w.n_tiles = 0;
     // k_convz's chunk table for this flat edge list, in a scratch buffer the hook keeps (test hook: one caller at a time): the list is cut every
     // 2048 edges as if those were graphs (parallel walk)
-    static int* scratch = nullptr; static size_t scratch_ints = 0;
-    const int span = 2048, n_span = (n_edges + span - 1) / span, ccap = n_edges / 32 + n_edges / CZ_MAXSEG + n_span + 8;
+    static int* scratch_dev[16] = {nullptr}; static size_t scratch_dev_ints[16] = {0};   // (per device: the hook may be driven on several)
+    int dev_id = 0;
+    HIPCHECK(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 16) return fail(DBFR_ERR_ARG, "test hook: device index beyond 15");
+    int*& scratch = scratch_dev[dev_id]; size_t& scratch_ints = scratch_dev_ints[dev_id];
+    const int span = 2048, n_span = std::max((n_edges + span - 1) / span, 1), ccap = n_edges / 32 + n_edges / CZ_MAXSEG + n_span + 8;
     if (rf) {
       const size_t need = (size_t)n_span + 1 + 2 * (size_t)ccap;
       if (need > scratch_ints) {
-        if (scratch) HIPCHECK(hipFree(scratch));
+        if (scratch) HIPCHECK(hipFree(scratch));           // (hipFree waits for the device: nothing in flight still reads the old buffer)
         scratch = nullptr; scratch_ints = 0;
         HIPCHECK(hipMalloc(&scratch, need * sizeof(int)));
         scratch_ints = need;
