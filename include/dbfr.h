@@ -420,12 +420,13 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
  *                            output irrep (74 % of the rows at depth 3, all rows of the torsion convs): a scalar message element is linear in
  *                            y (x) h (y = the tensor-product input coupled with the harmonics, h = the hidden layer), and so is the scatter over
  *                            the edges of a target node, so Z[t,c,k] = sum_{e -> t} y[e,c] h[e,k] is formed first and the 144 x W GEMM runs
- *                            once per TARGET SEGMENT (<= 32 consecutive edges of one target inside a 32-edge chunk of one graph), not once per
+ *                            once per TARGET SEGMENT (the edges of one target inside a chunk = <= 32 consecutive edges and <= 4 targets of one graph), not once per
  *                            edge: 8-10 x fewer matrix instructions for those rows.  Kernel k_convz (csrc/convz.hip); the l = 1 outputs stay
  *                            per edge on k_conv2h.  Every lin.3 output row carries its own power-of-two factor there (no row-depth limit).
- *                            MESSAGE BUFFER in this mode: the scalar columns of a segment's FIRST message row hold the segment's SUM, those of
- *                            its other rows are zero (vector columns: per edge as before) -- the per-node reduction (sum of a node's rows /
- *                            their number) is unchanged.  Chunks are cut per graph: what is summed with what never depends on batch mates.
+ *                            MESSAGE BUFFER in this mode: the scalar columns of a segment's FIRST message row hold the segment's SUM; those of
+ *                            its other rows are zero in the buffer dbfr_test_conv2 fills (the hook clears it first) and NOT WRITTEN inside the
+ *                            sampler, whose reductions read them of segment-first rows only (vector columns: per edge as before).  Chunks
+ *                            are cut per graph, by the graph's own targets: what is summed with what never depends on batch mates.
  * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_f16 | reduce_first) says otherwise.
  * A workspace is laid out for the mode it was sized in: set the mode before dbfr_workspace_bytes.                       */
 #define DBFR_GEMM_F32 0
