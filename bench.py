@@ -47,7 +47,7 @@ PIPE_RF = dict(kernel="k_convz + k_conv2h (one launch pair per interaction layer
                       "irrep reduce-first (Z = sum over a target's edges of y (x) h, then the 144 x W GEMM once per target segment), the vector-output rows per edge",
                instruction="v_mfma_f32_16x16x32_f16", products=3, peak=2500.0, hidden_on_pipe=True, sustained=1937.0,
                arithmetic="three fp16 x fp16 partial products per fp32 product (two fp16 pieces per operand, exact power-of-two scalings), fp32 accumulation")
-PMC_FILE = {"f32": "profiles/r2_pmc_k_conv.json", "split": "profiles/r2_pmc_k_conv2r.json",
+PMC_FILE = {"f32": "profiles/r2_pmc_k_conv.json",
             "split_f16": "profiles/r4_pmc_k_conv2h.json", "reduce_first": "profiles/r5_pmc_conv_pair.json"}
 PMC_FILE_CFG5 = {"split_f16": "profiles/r4_cfg5_pmc_k_conv2h.json", "reduce_first": "profiles/r5_cfg5_pmc_conv_pair.json"}
 HALF_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
@@ -58,11 +58,6 @@ PIPE = {
                        "two k_conv<144> torsion-head convs; one 'launch' = one such grid",
                 instruction="v_mfma_f32_16x16x4_f32", products=1, peak=FP32_MATRIX_PEAK_TFLOPS,
                 arithmetic="v_mfma_f32_16x16x4_f32 (fp32 operands, bit-exact an fmaf chain)"),
-    "split": dict(kernel="k_conv2r (persistent; all four convs of an interaction layer, or the two torsion-head convs, per launch): fused radial MLP + "
-                         "tensor product; W2 pieces through an LDS ring, one copy per tile per CU",
-                  instruction="v_mfma_f32_16x16x32_bf16 (+ _16x16x16_bf16 for the last 16 k)", products=6, peak=HALF_MATRIX_PEAK_TFLOPS,
-                  arithmetic="six bf16 x bf16 partial products per fp32 product (operands cut into three bf16 pieces, exact), fp32 accumulation -- "
-                             "error vs fp64 <= the fp32 MFMA's"),
     "split_f16": dict(kernel="k_conv2h (persistent; all four convs of an interaction layer, or the two torsion-head convs, per launch): fused radial MLP "
                              "+ tensor product; W2 pieces through an LDS ring, one copy per tile per CU, two barriers per tile",
                       instruction="v_mfma_f32_16x16x32_f16 (+ _16x16x16_f16 for the last 16 k)", products=3, peak=HALF_MATRIX_PEAK_TFLOPS,
@@ -187,7 +182,7 @@ def cpu_baseline(cfg_id, samp, dev, n_poses=1, batched=(2, 2), batched_steps=5):
     return out
 
 
-PMC_KERNEL = {"split_f16": "k_conv2h", "split": "k_conv2r", "reduce_first": "k_conv"}
+PMC_KERNEL = {"split_f16": "k_conv2h", "reduce_first": "k_conv"}
 
 
 def measure_traffic(mode, args):
@@ -552,7 +547,7 @@ def main():
         alg = fl.value / (ms.value * 1e-3) / 1e12            # algorithmic fp32 flops 2*144*(144+W) per edge / kernel time
         P = PIPE_RF if mode == "reduce_first" else PIPE[mode]
         # what the named matrix instruction executes: `products` MFMA-flops per algorithmic flop of the 144 x W GEMM (97.6 % of the
-        # conv's flops); in k_conv2r the 144 x 144 hidden layer stays on the fp32 instruction inside the same kernel and is
+        # conv's flops); in the retired k_conv2r the 144 x 144 hidden layer stayed on the fp32 instruction inside the same kernel and was
         # not counted, k_conv2h runs it on the same three-product form (W1h tiles)
         ex = alg if mode == "f32" else P["products"] * (1.0 if P.get("hidden_on_pipe") else W2_SHARE) * alg
         exe = C.c_double()

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdbfr.so")
-SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "conv2.hip", "conv2r.hip", "conv2h.hip", "convz.hip", "graph.hip", "heads.hip", "export.hip", "mdn.hip", "probe.hip"]
+SOURCES = ["api.cpp", "so3_host.cpp", "conv.hip", "conv2.hip", "conv2h.hip", "convz.hip", "graph.hip", "heads.hip", "export.hip", "mdn.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("DBFR_BUILD_DEV") == "1":      # developer build: the timing-only kernel variants behind DBFR_CONV*_ABL / _VAR (wrong results)
     FLAGS.append("-DDBFR_DEV_VARIANTS")
@@ -27,9 +27,8 @@ FILE_FLAGS = {"conv.hip": ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-arr
               + ([f"-DCONV_XPF={os.environ['DBFR_BUILD_XPF']}"] if "DBFR_BUILD_XPF" in os.environ else [])}
 FILE_FLAGS["mdn.hip"] = ["-ffp-contract=off"]
 FILE_FLAGS["conv2.hip"] = ["-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-array-bounds"]
-FILE_FLAGS["conv2r.hip"] = FILE_FLAGS["conv2.hip"] + ["-Rpass-analysis=kernel-resource-usage"]
-FILE_FLAGS["conv2h.hip"] = FILE_FLAGS["conv2r.hip"]
-FILE_FLAGS["convz.hip"] = FILE_FLAGS["conv2r.hip"]
+FILE_FLAGS["conv2h.hip"] = FILE_FLAGS["conv2.hip"] + ["-Rpass-analysis=kernel-resource-usage"]
+FILE_FLAGS["convz.hip"] = FILE_FLAGS["conv2h.hip"]
 DEFAULT_FP = ["-ffp-contract=off"]
 
 

@@ -12,7 +12,6 @@
 void launch_conv(const ConvArgs& a, hipStream_t st);
 void launch_conv_layer(const ConvArgs* c4, hipStream_t st);
 void launch_conv2(const Conv2Args& a, hipStream_t st);
-void launch_conv2r(const Conv2Args& a, hipStream_t st);
 void launch_conv2h(const Conv2Args& a, hipStream_t st);
 void launch_convz(const ConvZArgs& a, hipStream_t st);
 void launch_reduce_ln(const float* msg, const int* row_start, const int* row_cnt, int N, int D, const LNDesc& ln,
@@ -126,11 +125,10 @@ int dbfr_current_cu_count() {
   return n;
 }
 
-// DBFR_GEMM = f32 | split: which matrix instruction carries the 144 x W GEMM of the K=144 convs (dbfr_model_set_gemm overrides)
+// DBFR_GEMM = f32 | split_f16 | reduce_first: which matrix instruction carries the 144 x W GEMM of the K=144 convs (dbfr_model_set_gemm overrides)
 static int gemm_from_env() {
   const char* e = getenv("DBFR_GEMM");
   if (!e || !*e) return DBFR_GEMM_DEFAULT;
-  if (!strcmp(e, "split") || !strcmp(e, "1")) return DBFR_GEMM_SPLIT_BF16;
   if (!strcmp(e, "split_f16") || !strcmp(e, "3")) return DBFR_GEMM_SPLIT_F16;
   if (!strcmp(e, "reduce_first") || !strcmp(e, "4")) return DBFR_GEMM_REDUCE_FIRST;
   return DBFR_GEMM_F32;
@@ -151,7 +149,7 @@ struct dbfr_model {
   int* queue;          // [2] unit queue of k_conv2 (re-armed by the kernel itself)
   std::string fallback_convs;   // ';'-separated names of the convs whose weights two fp16 pieces cannot hold (dbfr_model_fallback_convs)
   std::string rowscaled_convs;  // 'name:depth;' of the convs packed with per-row factors (dbfr_model_rowscaled_convs)
-  uint32_t layer_fallback;      // bit l: interaction layer l goes through k_conv2r in DBFR_GEMM_SPLIT_F16 mode; bit 31: the torsion heads
+  uint32_t layer_fallback;      // bit l: interaction layer l goes through the fp32-instruction kernel k_conv2 whatever the mode (a bias 2^48 above its row); bit 31: the torsion heads
   int* edge_log; int edge_log_steps, edge_log_graphs;   // dbfr_model_set_edge_log: caller-owned device buffer [steps][6][graphs], or null
   Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
   Mlp2 tr_final, rot_final, tor_final, sc_final;
@@ -605,28 +603,7 @@ static int pack_conv2(dbfr_model* m, const TMap& tm, const std::string& name, in
   o->W2q = upload(m, w2q, &rc);
   o->b2q = upload(m, b2q, &rc);
   }
-  if (!vector_only) {   // the same fragments cut into three bf16 pieces (conv2r.hip).  Per tile: [3 pieces][4 k-steps of 32][64][8] -- step s = fp32
-      // k-steps 2s and 2s+1 of the same lane -- then [3 pieces][64][4] for the last 16 k (fp32 k-step 8)
-    const size_t tile_h = 13824 / 2, tail_off = 12288 / 2;
-    std::vector<uint16_t> w2s((size_t)n_tiles * tile_h + 512, 0);   // (+ 1 KiB of slack behind the last tile)
-    for (int t = 0; t < n_tiles; ++t)
-      for (int s4 = 0; s4 < KT; ++s4)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int q = 0; q < 4; ++q) {
-            const float v = w2q[(((size_t)t * KT + s4) * 64 + lane) * 4 + q];
-            const uint16_t p0 = dbfr_bf16_rne(v);
-            const float r1 = v - dbfr_bf16_to_f32(p0);
-            const uint16_t p1 = dbfr_bf16_rne(r1);
-            const uint16_t p2 = dbfr_bf16_rne(r1 - dbfr_bf16_to_f32(p1));
-            const uint16_t pc[3] = {p0, p1, p2};
-            for (int i = 0; i < 3; ++i) {
-              if (s4 < 8) w2s[t * tile_h + ((size_t)(i * 4 + (s4 >> 1)) * 64 + lane) * 8 + 4 * (s4 & 1) + q] = pc[i];
-              else w2s[t * tile_h + tail_off + ((size_t)i * 64 + lane) * 4 + q] = pc[i];
-            }
-          }
-    o->W2s = upload(m, w2s, &rc);
-  }
-  {   // ... and into TWO fp16 pieces (conv2h.hip), run by run (a run = the tiles of one tensor-product path of one channel group):
+  {   // the same fragments cut into TWO fp16 pieces (conv2h.hip), run by run (a run = the tiles of one tensor-product path of one channel group):
       // pack_f16_tiles below.  k travels in RunDesc.meta bits 24..31; the kernel folds 2^-k into the run's harmonics.
     // A conv with a run whose rows lie further apart than two fp16 pieces hold behind ONE factor (depth > F16_ROW_DEPTH_OK) is packed again with
     // per-ROW factors (W2rinv) and served by k_conv2h<.., ROWF>, which takes them off the accumulator rows: four more vector instructions per edge
@@ -839,7 +816,7 @@ extern "C" int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t 
 }
 
 extern "C" int dbfr_model_set_gemm(dbfr_model* m, int32_t mode) {
-  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_REDUCE_FIRST || mode == 2) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument (mode 2, the L1 variant of the bf16 split, was retired with ABI 4)");
+  if (!m || mode < DBFR_GEMM_F32 || mode > DBFR_GEMM_REDUCE_FIRST || mode == 1 || mode == 2) return fail(DBFR_ERR_ARG, "dbfr_model_set_gemm: bad argument (modes 1 and 2, the three-bf16-piece kernels, were retired with ABI 5 / 4)");
   m->gemm_split = mode;
   return DBFR_OK;
 }
@@ -1171,7 +1148,7 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     prof_events(m, &e0, &e1);
     (void)hipEventRecord(e0, st);
   }
-  // developer timeline of k_conv2r: DBFR_CONV2_TRACE=<file> (+ DBFR_CONV2R_ABL=128): the stamps of the LAST traced launch are written at exit
+  // developer clock read-out of k_conv2h: DBFR_CONV2_TRACE=<file>: the stamps of the LAST traced launch are written at exit
   static unsigned long long* trace_dev = nullptr;
   static const char* trace_file = getenv("DBFR_CONV2_TRACE");
   if (trace_file && !trace_dev) {
@@ -1199,8 +1176,7 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
     launch_convz(za, st);
   }
   else if (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) launch_conv2h(a, st);
-  else if (m->gemm_split == DBFR_GEMM_SPLIT_BF16 || m->gemm_split >= DBFR_GEMM_SPLIT_F16) launch_conv2r(a, st);   // (a launch holding a conv whose weights span more than two fp16 pieces hold: three bf16 pieces)
-  else launch_conv2(a, st);
+  else launch_conv2(a, st);   // DBFR_GEMM_F32, and a launch holding a conv that even per-row factors cannot fit into two fp16 pieces: the fp32 instruction
   if (m->profile == 1) (void)hipEventRecord(e1, st);
   if (m->profile)
     for (int i = 0; i < n; ++i) {
@@ -1209,7 +1185,7 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
       // (reduce-first: the vector-output rows only; the split kernels of round 2 keep the hidden layer on the fp32 instruction)
       const double rows = 16.0 * descs[i].w.n_tiles;
       const bool f16 = (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) || z;
-      const double ex = m->gemm_split == DBFR_GEMM_F32 ? 2.0 * 144 * (144.0 + rows) : f16 ? 3.0 * 2.0 * 144 * (144.0 + rows) : 2.0 * 144 * 144.0 + 6.0 * 2.0 * 144 * rows;
+      const double ex = f16 ? 3.0 * 2.0 * 144 * (144.0 + rows) : 2.0 * 144 * (144.0 + rows);
       if (!z || descs[i].w.n_tiles > 0) launch_acc_executed(descs[i].n_edges, ex, m->flops_dev + 3, st);
     }
 }

@@ -83,10 +83,9 @@ struct ConvW2 {
   const float* b1;
   const float* W2q;   // [n_tiles][K/16][64][4]
   const float* b2q;   // [n_tiles*16]
-  const void* W2s;    // [n_tiles] x 13824 B: W2q cut into three bf16 pieces for k_conv2r (conv2r.hip; layout: api.cpp pack_conv2)
   const void* W1h;    // [9] x 9280 B: lin.0 (W1p's tiles, bias rows) in the W2h tile format with the one factor 2^k1, for k_conv2h's hidden layer
   int k1;
-  int f16_depth;      // largest row depth LEFT in the fp16 packing (api.cpp pack_f16_tiles): above F16_ROW_DEPTH_OK the conv would be served by k_conv2r
+  int f16_depth;      // largest row depth LEFT in the fp16 packing (api.cpp pack_f16_tiles): above F16_ROW_DEPTH_OK the conv is served by the fp32-instruction kernel k_conv2
   int f16_depth_run;  // ... before the per-row factors: above F16_ROW_DEPTH_OK the rows of W2h / W1h carry their own powers of two (W2rinv / W1rinv)
   const float* W2rinv;   // [n_tiles][16] 2^-d(row) of the rows of W2h packed with per-row factors, or null (every factor 1): k_conv2h<.., ROWF> takes them off the accumulator rows
   const float* W1rinv;   // [144] the same for W1h's rows (hidden units), or null
@@ -113,7 +112,7 @@ struct Conv2Args {
   int* queue;             // [2] device ints, zero at launch: next unit, workgroups done (re-armed by the last one)
   int run_barrier, no_split;   // developer knobs (launch_conv2)
   int skew;                    // start delay of the second half of the waves, in 512-cycle sleeps
-  unsigned long long* trace;   // developer timeline of k_conv2r (DBFR_CONV2_TRACE=<file>): [8 waves][C2_TRACE_CAP] shader-clock stamps of workgroup 0, or null
+  unsigned long long* trace;   // developer read-out of k_conv2h (DBFR_CONV2_TRACE=<file>): [8 waves][C2_TRACE_CAP] shader-clock stamps of workgroup 0, or null
 };
 #define C2_TRACE_CAP 4096
 

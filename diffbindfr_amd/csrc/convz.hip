@@ -422,14 +422,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
         const int xo = cd_n & 0xfff;
         // (inline assembly on purpose: for the builtin hipcc's wait-count pass makes EVERY later LDS read -- the Z reads of the next tiles -- wait for
         // vmcnt(0), i.e. for W2' fragments requested a moment before; here the one wait sits in front of the stage's readers, wait_stage)
+        // (m0 is written without being declared clobbered: hipcc treats it as a reserved register and rejects the clobber; nothing the compiler emits for
+        // this kernel uses m0 -- no movrel indexing, no LDS-DMA builtin, no GWS -- which `grep m0` on the generated assembly shows)
         const unsigned lds0 = (unsigned)(size_t)(const void __attribute__((address_space(3)))*)w_xs;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const float* xp = d.x + w_row[t < 4 ? 4 * g + t : 16 + 4 * g + (t - 4)] + xo;
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + t * 256)), "v"(xp) : "m0", "memory");
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + t * 256)), "v"(xp) : "memory");
           if (vec) {
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + (8 + t) * 256)), "v"(xp + 1) : "m0", "memory");
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + (16 + t) * 256)), "v"(xp + 2) : "m0", "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + (8 + t) * 256)), "v"(xp + 1) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(__builtin_amdgcn_readfirstlane(lds0 + (16 + t) * 256)), "v"(xp + 2) : "memory");
           }
         }
       };

@@ -102,7 +102,7 @@ def conv_paths(kind):
     return wn.value, [list(tab[10 * i:10 * i + 10]) for i in range(n)]
 
 
-GEMM_MODES = {"f32": 0, "split": 1, "split_f16": 3, "reduce_first": 4}     # include/dbfr.h: DBFR_GEMM_*
+GEMM_MODES = {"f32": 0, "split_f16": 3, "reduce_first": 4}     # include/dbfr.h: DBFR_GEMM_*
 
 
 @INTERACTION.register_module(name=["TensorProductModelHIP"])
@@ -115,7 +115,7 @@ class TensorProductModelHIP(nn.Module):
         assert not g("use_second_order_repr", False), "use_second_order_repr=True is not supported"
         self.no_sc_torsion = bool(g("no_sc_torsion", False))
         # which matrix instruction carries the radial MLP's big GEMM: None = the library's default (or $DBFR_GEMM),
-        # "f32" = v_mfma_f32_16x16x4_f32, "split" = three bf16 pieces per fp32 operand on v_mfma_f32_16x16x32_bf16,
+        # "f32" = v_mfma_f32_16x16x4_f32,
         # "split_f16" = two fp16 pieces / three products on v_mfma_f32_16x16x32_f16, "reduce_first" (the default) = the same arithmetic with the
         # scalar-output rows reduced over a target's edges before the big GEMM (include/dbfr.h)
         self.gemm = g("gemm", None)
@@ -278,7 +278,7 @@ class TensorProductModelHIP(nn.Module):
         return log
 
     def set_gemm(self, mode):
-        """Switch the GEMM mode ("f32" | "split" | None = library default at the next re-pack) of this model on every device."""
+        """Switch the GEMM mode ("f32" | "split_f16" | "reduce_first" | None = library default at the next re-pack) of this model on every device."""
         assert mode in (None,) + tuple(GEMM_MODES)
         self.gemm = mode
         if mode is not None:

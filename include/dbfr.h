@@ -33,7 +33,7 @@ extern "C" {
 #define DBFR_ABI_VERSION 5   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
                                 3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only);
                                 4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_model_set_edge_log takes the graph capacity; DBFR_GEMM_SPLIT_BF16_L1 (k_conv2s) retired; dbfr_test_conv2's message rows in that mode hold segment sums;
-                                5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back), dbfr_test_pack_f16_rows, dbfr_test_chunk_table; the reduce-first chunks hold <= 4 targets */
+                                5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back), dbfr_test_pack_f16_rows, dbfr_test_chunk_table; the reduce-first chunks hold <= 4 targets; DBFR_GEMM_SPLIT_BF16 (k_conv2r) retired */
 
 typedef enum {
   DBFR_OK = 0,
@@ -405,16 +405,13 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
 /* Which matrix instruction carries the 144 x W GEMM of the radial MLP (97-99 % of the arithmetic) in the K=144 convs.
  * All modes produce fp32 results from fp32 weights and fp32 activations:
  *   DBFR_GEMM_F32            v_mfma_f32_16x16x4_f32 (fp32 operands): k_conv / k_conv2;
- *   DBFR_GEMM_SPLIT_BF16     every operand cut into three bf16 pieces (a = a1 + a2 + a3 exactly), the six partial products
- *                            with i + j <= 4 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: measured error vs fp64 one
- *                            third of the fp32 instruction's (tools/exp/split_bf16.hip; the tests hold all modes to the same
- *                            tolerances), 2.4x less matrix-pipe time; serves every batch size.  Kernel k_conv2r
- *                            (csrc/conv2r.hip): the W2 pieces reach the waves through an LDS ring, one copy per tile per CU;
+ *   (1, DBFR_GEMM_SPLIT_BF16 -- three bf16 pieces per operand, six products on v_mfma_f32_16x16x32_bf16, kernel k_conv2r: round 2's default,
+ *                            retired with ABI 5 once no conv needed it as a fall-back; the number stays unused)
  *   DBFR_GEMM_SPLIT_F16      every operand cut into TWO fp16 pieces (hi = fp16(x), lo = fp16(x - hi): 23 of fp32's 24 significand
  *                            bits) after an exact power-of-two scaling that keeps the pieces inside fp16's exponent range (W2: per
  *                            tensor-product run, at model creation; activations: per edge, in the kernel), three partial products
  *                            hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x32_f16, the two small ones and the large one in separate
- *                            fp32 accumulators: half the matrix instructions of SPLIT_BF16.  Kernel k_conv2h (csrc/conv2h.hip);
+ *                            fp32 accumulators.  Kernel k_conv2h (csrc/conv2h.hip);
  *                            accuracy table: profiles/r3_split_experiments.txt.
  *   DBFR_GEMM_REDUCE_FIRST   the arithmetic of SPLIT_F16 with the ORDER of the work changed for the rows of lin.3 that feed a scalar (l = 0)
  *                            output irrep (74 % of the rows at depth 3, all rows of the torsion convs): a scalar message element is linear in
@@ -430,8 +427,7 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
  * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_f16 | reduce_first) says otherwise.
  * A workspace is laid out for the mode it was sized in: set the mode before dbfr_workspace_bytes.                       */
 #define DBFR_GEMM_F32 0
-#define DBFR_GEMM_SPLIT_BF16 1
-/* (2 was DBFR_GEMM_SPLIT_BF16_L1, k_conv2s: retired with ABI 4, the number stays unused) */
+/* (1 was DBFR_GEMM_SPLIT_BF16, k_conv2r: retired with ABI 5; 2 was DBFR_GEMM_SPLIT_BF16_L1, k_conv2s: retired with ABI 4; the numbers stay unused) */
 #define DBFR_GEMM_SPLIT_F16 3
 #define DBFR_GEMM_REDUCE_FIRST 4
 #define DBFR_GEMM_DEFAULT DBFR_GEMM_REDUCE_FIRST
@@ -441,7 +437,7 @@ int dbfr_model_set_gemm(dbfr_model* model, int32_t mode);
  * a deeper row (a trained checkpoint may hold one; seeded weights do not) is packed with one factor per ROW instead, which the kernel takes
  * off the accumulator rows (ABI 5; four more vector instructions per edge block and tile): dbfr_model_rowscaled_convs counts those convs and
  * writes "name:depth;" for each (depth = log2 of the spread that was found).  dbfr_model_fallback_convs counts the convs that even so cannot
- * be held by two fp16 pieces and are served by the DBFR_GEMM_SPLIT_BF16 kernel together with the other convs of their launch (an interaction
+ * be held by two fp16 pieces and are served by the fp32-instruction kernel (k_conv2) together with the other convs of their launch (an interaction
  * layer / the two torsion heads): none since ABI 5, unless a bias dwarfs its row by more than 2^48.  names (may be NULL) receives the
  * state_dict prefixes, ';'-terminated each ("atom_conv_layers.3;").                                                                  */
 int dbfr_model_rowscaled_convs(const dbfr_model* model, char* names, size_t names_cap);

@@ -59,7 +59,7 @@ def hip_scores(model, d, dev):
 @contextlib.contextmanager
 def gemm(model, mode):
     """Run a block with the radial MLP's big GEMM on the fp32 matrix instruction ("f32": k_conv / k_conv2) or on the bf16 one
-    with three-piece operands ("split": k_conv2r), or on the fp16 one with two-piece operands ("split_f16":
+    (round 2's three-bf16-piece kernel, "split", was retired in round 5), or on the fp16 one with two-piece operands ("split_f16":
     k_conv2h; "reduce_first": k_convz for the scalar-output rows, reduced over a target's edges BEFORE the big GEMM, + k_conv2h for the
     vector-output rows); include/dbfr.h: dbfr_model_set_gemm."""
     before = model.gemm
@@ -70,7 +70,7 @@ def gemm(model, mode):
         model.set_gemm(before if before is not None else DEFAULT_GEMM)
 
 
-@pytest.fixture(params=["split", "split_f16", "f32", "reduce_first"])
+@pytest.fixture(params=["split_f16", "f32", "reduce_first"])
 def both_gemms(request, setup):
     with gemm(setup[2], request.param):
         yield request.param
@@ -377,13 +377,13 @@ def test_graph_permutation_invariance(setup, dev):
 @pytest.mark.parametrize("layer,fam,name", [(0, 0, "lig_conv_layers.0"), (1, 2, "atom_conv_layers.1"),
                                             (2, 1, "cross_al_conv_layers.2"), (5, 3, "cross_la_conv_layers.5"),
                                             (-1, 0, "final_conv"), (-2, 0, "tor_bond_conv"), (-3, 0, "sc_tor_bond_conv")])
-@pytest.mark.parametrize("kernel", ["k_conv", "k_conv2", "k_conv2r", "k_conv2h", "k_convz"])
+@pytest.mark.parametrize("kernel", ["k_conv", "k_conv2", "k_conv2h", "k_convz"])
 def test_fused_conv_and_reduce_kernels(setup, dev, layer, fam, name, kernel):
     """Every conv shape of the network alone against the oracle's tensor product (oracle._tp over e3nn_lite), through every fused-conv
     kernel -- the default one (k_conv2h, DBFR_GEMM_SPLIT_F16) included."""
     if kernel != "k_conv" and layer == -1:
         pytest.skip("final_conv (K=96) runs on k_conv only")
-    with gemm(setup[2], {"k_conv2r": "split", "k_conv2h": "split_f16", "k_convz": "reduce_first"}.get(kernel, "f32")):
+    with gemm(setup[2], {"k_conv2h": "split_f16", "k_convz": "reduce_first"}.get(kernel, "f32")):
         _fused_conv_and_reduce(setup, dev, layer, fam, name, kernel)
 
 
@@ -678,10 +678,10 @@ def test_k_conv2_equals_k_conv_bitwise(setup, dev, layer, fam, E):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("mode", ["split", "split_f16"])
+@pytest.mark.parametrize("mode", ["split_f16"])
 @pytest.mark.parametrize("layer,fam,E", CONV_CASES)
 def test_split_kernels_match_k_conv_and_are_unit_independent(setup, dev, layer, fam, E, mode):
-    """k_conv2r (operands cut into three bf16 pieces, bf16 matrix instruction, fp32 accumulation) against k_conv (fp32 matrix
+    """k_conv2h (operands cut into two fp16 pieces, fp16 matrix instruction, fp32 accumulation) against k_conv (fp32 matrix
     instruction) on the same random edges: equal to fp32 rounding noise; bit-identical from run to run; and the message of an
     edge does not depend on which workgroup / which tail split processed it (the first third of the edges alone -- other
     unit boundaries, another split of the last round -- gives the very same bits for those edges)."""
@@ -826,8 +826,7 @@ def test_reduce_first_accuracy_against_float64(setup, dev):
 
 def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, dev):
     """The claim that makes the split path the default: against a float64 evaluation of the same conv (the oracle run in
-    double), the messages of k_conv2r are at least as close as those of k_conv.  (Measured on the bare GEMM: 1.05e-7 vs
-    3.1e-7 of sum|w h|, tools/exp/split_bf16.hip -- 30 roundings per dot product instead of 144.)"""
+    double), the messages of k_conv2h are at least as close as those of k_conv (tools/exp/split_f16.hip: 0.6 x on the bare GEMM)."""
     mcfg, p, model = setup
     lib, h = L.load(), model.handle(dev)
     name, layer, fam, E = "atom_conv_layers.3", 3, 2, 600
@@ -841,7 +840,7 @@ def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, 
     m64 = sm._tp(i, shirr, o)(x[gth], sh, sm.simple_linear(p64, f"{name}.fc", a64))
     assert m64.dtype == torch.float64
     err, rms = {}, {}
-    for mode, fn in (("f32", lib.dbfr_test_conv), ("split", lib.dbfr_test_conv2), ("split_f16", lib.dbfr_test_conv2)):
+    for mode, fn in (("f32", lib.dbfr_test_conv), ("split_f16", lib.dbfr_test_conv2)):
         with gemm(model, mode):
             m = _run_conv_hook(fn, h, layer, fam, c, E, dev)
         dm = m.cpu().double() - m64
@@ -849,7 +848,6 @@ def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, 
         rms[mode] = float(dm.pow(2).mean().sqrt() / m64.pow(2).mean().sqrt())
     print("conv message error vs float64: max", err, "rms", rms)
     assert max(err.values()) < 2e-6, err
-    assert err["split"] <= 1.25 * err["f32"] + 5e-8, err
     # the two-piece fp16 form (k_conv2h): separate accumulators for the small and the large products => closer to float64 than the
     # fp32 instruction both in the largest and in the rms deviation (tools/exp/split_f16.hip: 0.6 x on the bare GEMM)
     assert err["split_f16"] <= err["f32"] and rms["split_f16"] <= rms["f32"], (err, rms)
@@ -877,7 +875,7 @@ def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms,
     samp = dba.DiffBindFRHIP(diffusion_model=model, test_cfg={})
     noise = {k: torch.from_numpy(z[f"noise_{k}"]).to(dev).contiguous() for k in ("tr", "rot", "tor", "sc")}
     noise = {k: (v if v.shape[1] else torch.zeros(v.shape[0], 1, device=dev)) for k, v in noise.items()}
-    for mode in (("reduce_first", "split_f16", "split", "f32") if tag == "traj" else ("reduce_first", "f32")):
+    for mode in (("reduce_first", "split_f16", "f32") if tag == "traj" else ("reduce_first", "f32")):
         model.set_gemm(mode)
         pb = PackedBatch(namespace_to(d, dev), dev)
         lig, a14 = samp.sample_packed(pb, noise, visualize=True)

@@ -32,11 +32,12 @@ def test_gemm_mode_entry_points_reject_bad_arguments():
     assert lib.dbfr_model_get_gemm(None) == -1
     hdr = open(os.path.join(ROOT, "include", "dbfr.h")).read()
     modes = dict(re.findall(r"#define (DBFR_GEMM_[A-Z0-9_]+) (\w+)", hdr))
-    assert modes["DBFR_GEMM_F32"] == "0" and modes["DBFR_GEMM_SPLIT_BF16"] == "1" and "DBFR_GEMM_SPLIT_BF16_L1" not in modes
+    # (modes 1 and 2, the three-bf16-piece kernels of round 2, are retired: their numbers stay unused)
+    assert modes["DBFR_GEMM_F32"] == "0" and "DBFR_GEMM_SPLIT_BF16" not in modes and "DBFR_GEMM_SPLIT_BF16_L1" not in modes
     assert modes["DBFR_GEMM_SPLIT_F16"] == "3" and modes["DBFR_GEMM_REDUCE_FIRST"] == "4"
-    assert modes["DBFR_GEMM_DEFAULT"] in ("DBFR_GEMM_SPLIT_BF16", "DBFR_GEMM_SPLIT_F16", "DBFR_GEMM_REDUCE_FIRST")
+    assert modes["DBFR_GEMM_DEFAULT"] in ("DBFR_GEMM_SPLIT_F16", "DBFR_GEMM_REDUCE_FIRST")
     from diffbindfr_amd.score_model import GEMM_MODES
-    assert sorted(GEMM_MODES.values()) == [0, 1, 3, 4]
+    assert sorted(GEMM_MODES.values()) == [0, 3, 4]
 
 
 def test_product_schedule_matches_reference_fixture():

@@ -12,7 +12,7 @@ sc = osched.step_scalars(osched.default_sample_cfg(), 4)
 dd = osampler.set_time(copy.deepcopy(d), sc, d.num_graphs)
 ref = sm.forward(params, mcfg, copy.deepcopy(dd))
 def rel(a, b): return float((a.cpu() - b).abs().max() / b.abs().max())
-for mode in ("f32", "split", "split_f16", "reduce_first"):
+for mode in ("f32", "split_f16", "reduce_first"):
     model.set_gemm(mode)
     out = model(namespace_to(copy.deepcopy(dd), dev))
     print(mode, model.gemm_mode(), [f"{rel(o, r):.2e}" for o, r in zip(out, ref) if o is not None], flush=True)

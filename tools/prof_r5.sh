@@ -42,7 +42,7 @@ if [ $WHAT = all ] || [ $WHAT = lines ]; then
     bench.py --gpus 2 --steps 1 --warmup 0 --batch-poses 320 --no-profile > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err
   # the same WITHOUT a launcher: bench.py starts its own two ranks
   DBFR_DIST_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 1 --warmup 0 --batch-poses 320 --no-profile > $OUT/bench_2rank_selfspawn_gloo.json 2> $OUT/bench_2rank_selfspawn_gloo.err
-  for m in split_f16 split f32; do DBFR_GEMM=$m timeout 400 python bench.py --steps 2 $Q > $OUT/bench_gemm_$m.json 2>/dev/null; done
+  for m in split_f16 f32; do DBFR_GEMM=$m timeout 400 python bench.py --steps 2 $Q > $OUT/bench_gemm_$m.json 2>/dev/null; done
   for f in $OUT/bench_*.json; do echo $f; python -c "
 import json,sys
 try:
