@@ -67,6 +67,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #else
 #define CZ_SETPRIO(x)
 #endif
+#ifndef CZ_PF_KT
+#define CZ_PF_KT 7                  // the k tile behind which the next c tile's x gathers set out (used at k tile 9, behind an explicit wait); 3 / 5 / 6 / 8: 2.5-3.5 % slower (same-box A/B, profiles/TUNING_r5.md)
+#endif
 #define CZ_ZSCALE (-20)             // |Z| <= 32 edges x 2^15 x 2^15 = 2^35 -> 2^15
 
 __device__ __forceinline__ void cz_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -618,8 +621,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
             stamp(10);
             if constexpr (kt < KT) {
               tile(kt_c, ncb_c);
-              // (behind the tile's matrix instructions, where the wave would wait at the barrier; used at kt = 9: four tiles for the gathers)
-              if constexpr (kt == 5) if (ct + 1 < W.nct[io]) prefetch_x(ct + 1);
+              // (behind the tile's matrix instructions, where the wave would wait at the barrier; used at kt = 9)
+              if constexpr (kt == CZ_PF_KT) if (ct + 1 < W.nct[io]) prefetch_x(ct + 1);
             } else
               tile9(ct);
             stamp(12);
