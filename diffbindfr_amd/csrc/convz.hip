@@ -67,6 +67,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #else
 #define CZ_SETPRIO(x)
 #endif
+#ifndef CZ_FETCH_AT
+#define CZ_FETCH_AT 4                // step A's matrix instructions in front of the next tile's W2' fetch (0 | 4 | 8 | 12)
+#endif
 #ifndef CZ_PF_KT
 #define CZ_PF_KT 7                  // the k tile behind which the next c tile's x gathers set out (used at k tile 9, behind an explicit wait); 3 / 5 / 6 / 8: 2.5-3.5 % slower (same-box A/B, profiles/TUNING_r5.md)
 #endif
@@ -514,7 +517,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       auto tile = [&](auto kt_c, auto ncb_c) {
         constexpr int kt = decltype(kt_c)::value, NCBV = decltype(ncb_c)::value;
         constexpr int boffA = ((kt + 1) & 1) * CZ_BUF;
-        fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last));
+        // (the next tile's fragments are requested behind step A's first CZ_FETCH_AT matrix instructions, not at the top of the tile: same-box A/B, TUNING_r5.md)
+        if constexpr (CZ_FETCH_AT == 0) fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last));
         const char* zr = zb + (kt & 1) * CZ_BUF + wave * CZ_VSTRIDE + g * 512 + n * 16;
         f32x4 zf0[2], zf1[2];
         zf0[0] = *reinterpret_cast<const f32x4*>(zr); zf0[1] = *reinterpret_cast<const f32x4*>(zr + 256);
@@ -532,16 +536,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
         z1 = MF(YM(1, 0), hl, zero); SL;
         z2 = MF(YM(2, 0), hl, zero); SL;
         z3 = MF(YM(3, 0), hl, zero); SL;
+        if constexpr (CZ_FETCH_AT == 4) { fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last)); SL; }
         z0 = MF(YM(0, 1), hh, z0); cut(zf0, p0h, p0l, K0{}); SL;
         z1 = MF(YM(1, 1), hh, z1); SL;
         z2 = MF(YM(2, 1), hh, z2); cut(zf0, p0h, p0l, K1{}); SL;
         z3 = MF(YM(3, 1), hh, z3); SL;
+        if constexpr (CZ_FETCH_AT == 8) { fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last)); SL; }
         CZ_SETPRIO(2);
         z0 = MF(YM(0, 0), hh, z0); cut(zf0, p0h, p0l, K2{}); SL;
         z1 = MF(YM(1, 0), hh, z1); SL;
         z2 = MF(YM(2, 0), hh, z2); cut(zf0, p0h, p0l, K3{}); SL;
         z3 = MF(YM(3, 0), hh, z3); SL;
+        if constexpr (CZ_FETCH_AT == 12) { fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last)); SL; }
         }
+        if constexpr ((ABL & 4) != 0 && CZ_FETCH_AT != 0) fetchW(std::integral_constant<int, (kt + 1) & 1>{}, min(gq + 1, gq_last));
 #define WFR(wt, pc) __builtin_bit_cast(f16x8, Wf[kt & 1][wt][pc])
         if constexpr ((ABL & 8) != 0) {
           if constexpr (!(ABL & 4)) { *reinterpret_cast<f32x4*>(za[0] + boffA) = z0; *reinterpret_cast<f32x4*>(za[1] + boffA) = z1; *reinterpret_cast<f32x4*>(za[2] + boffA) = z2; *reinterpret_cast<f32x4*>(za[3] + boffA) = z3; }
