@@ -164,6 +164,8 @@ struct dbfr_model {
   double* flops_dev;
   double fused_bytes_last;   // third counter as of the last dbfr_profile_read (before its reset)
   double executed_last;      // fourth counter (flops the matrix pipe executed in the K=144 conv launches), likewise
+  double useful_last;        // fifth: the executed flops that are not padding
+  double form_bytes_last;    // sixth: HBM bytes the form that runs has to move (DBFR_GEMM_REDUCE_FIRST: scalar-output message columns once per segment, inputs read by both kernels)
   double conv_ms_acc; int64_t conv_launches_acc;
   // side streams for small batches: the four convs of an interaction layer (and the three heads) are independent
   hipStream_t side[3];
@@ -709,6 +711,7 @@ static int pack_convz(dbfr_model* m, const TMap& tm, const std::string& name, in
   int nct_total = 0;
   for (int i = 0; i < o->n_io; ++i) {
     o->nct[i] = (int)cols[i].size() / 16;
+    for (auto& q : cols[i]) o->nc_valid[i] += q.p != nullptr;
     o->ct0[i] = nct_total;
     nct_total += o->nct[i];
     int off = 0;
@@ -878,7 +881,7 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   for (int i = 0; i < n_tensors; ++i) tm[tensors[i].name] = &tensors[i];
   dbfr_model* m = new dbfr_model();
   m->cfg = *cfg;
-  m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->executed_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
+  m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->executed_last = 0; m->useful_last = 0; m->form_bytes_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
   m->streams_ready = false;
   m->edge_log = nullptr; m->edge_log_steps = 0; m->edge_log_graphs = 0; m->layer_fallback = 0;
   // which fused-conv kernel the K=144 convs use: k_conv2 (persistent, one launch per layer, tail split) wins while a layer
@@ -945,7 +948,8 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
     if (!rc) { *gs[i].off = upload(m, std::vector<float>(off, off + EMB), &rc); *gs[i].c = upload(m, std::vector<float>(c, c + 1), &rc); }
   }
   if (!rc) m->a14_group = upload(m, std::vector<int>(kAtom14ToGroup, kAtom14ToGroup + 21 * 14), &rc);
-  if (!rc) { m->flops_dev = upload(m, std::vector<double>(4, 0.0), &rc); }
+  // profiling counters: flops of the reference algorithm | reference-form bytes | fused-form bytes | executed flops | executed flops that are not padding | bytes of the form that runs
+  if (!rc) { m->flops_dev = upload(m, std::vector<double>(6, 0.0), &rc); }
   if (!rc) { m->queue = upload(m, std::vector<int>(4, 0), &rc); }
   if (rc) { dbfr_model_destroy(m); return rc; }
   *out = m;
@@ -1187,6 +1191,16 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
       const bool f16 = (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) || z;
       const double ex = f16 ? 3.0 * 2.0 * 144 * (144.0 + rows) : 2.0 * 144 * (144.0 + rows);
       if (!z || descs[i].w.n_tiles > 0) launch_acc_executed(descs[i].n_edges, ex, m->flops_dev + 3, st);
+      // ... of which are not padding: everything in the per-edge kernels, except that the pair of DBFR_GEMM_REDUCE_FIRST computes the hidden layer twice
+      // (k_convz counts its own instructions and the useful ones among them itself, the hidden layer included)
+      if (!z) launch_acc_executed(descs[i].n_edges, ex, m->flops_dev + 4, st);
+      else if (descs[i].w.n_tiles > 0) launch_acc_executed(descs[i].n_edges, 3.0 * 2.0 * 144 * rows, m->flops_dev + 4, st);
+      // HBM bytes of the form that RUNS: the fused form's, except that the pair reads the edge record and the gathered rows twice and writes the
+      // scalar-output message columns once per SEGMENT (k_convz adds 4 x 48 per segment and irrep itself) and one flag byte per edge
+      const int D_in = descs[i].w.D_in, D_out = descs[i].w.D_out;
+      const double in_bytes = 4.0 * (48 + 9 + 3 + 48 + 48 + D_in);
+      if (!z) launch_acc_executed(descs[i].n_edges, fused_bytes(D_in, D_out), m->flops_dev + 5, st);
+      else launch_acc_executed(descs[i].n_edges, in_bytes + 1.0 + (descs[i].w.n_tiles > 0 ? in_bytes + 4.0 * (D_out - 48 * z[i].w.n_io) : 0.0), m->flops_dev + 5, st);
     }
 }
 
@@ -1608,21 +1622,30 @@ extern "C" int dbfr_profile_read(dbfr_model* m, double* conv_ms, int64_t* conv_l
     if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) { m->conv_ms_acc += ms; m->conv_launches_acc++; }
   }
   m->ev_used = 0;
-  double fl[4] = {0, 0, 0, 0};
+  double fl[6] = {0, 0, 0, 0, 0, 0};
   HIPCHECK(hipMemcpy(fl, m->flops_dev, sizeof fl, hipMemcpyDeviceToHost));
   m->fused_bytes_last = fl[2];
   m->executed_last = fl[3];
+  m->useful_last = fl[4];
+  m->form_bytes_last = fl[5];
   if (conv_ms) *conv_ms = m->conv_ms_acc;
   if (conv_launches) *conv_launches = m->conv_launches_acc;
   if (conv_flops) *conv_flops = fl[0];
   if (ref_form_bytes) *ref_form_bytes = fl[1];
-  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, 4 * sizeof(double))); }
+  if (reset) { m->conv_ms_acc = 0; m->conv_launches_acc = 0; HIPCHECK(hipMemset(m->flops_dev, 0, 6 * sizeof(double))); }
   return DBFR_OK;
 }
 
 extern "C" int dbfr_profile_executed_flops(const dbfr_model* m, double* executed_flops) {
   if (!m || !executed_flops) return fail(DBFR_ERR_ARG, "null argument");
   *executed_flops = m->executed_last;
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_profile_useful_flops(const dbfr_model* m, double* useful_flops, double* form_bytes) {
+  if (!m || (!useful_flops && !form_bytes)) return fail(DBFR_ERR_ARG, "null argument");
+  if (useful_flops) *useful_flops = m->useful_last;
+  if (form_bytes) *form_bytes = m->form_bytes_last;
   return DBFR_OK;
 }
 

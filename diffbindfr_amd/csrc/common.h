@@ -130,6 +130,7 @@ struct ConvZ {
   int nct[2];             // c tiles per irrep
   int ct0[2];             // first c tile of the irrep in cdesc / W2z
   int out_off[2];         // message column of the irrep's channel 0 (48 channels each)
+  int nc_valid[2];        // (path, u_in) pairs into the irrep without the padding of its last c tile (profiling: the flops that are not padding)
   const uint32_t* cdesc;  // [n c tiles][16]: x offset (floats) | l_in << 12 | sh offset << 16 | valid << 31
   const void* W2z;        // [c tile][k tile][8 k-steps][3 w tiles][hi, lo][64 lanes][8 fp16] x 2^s(w), s per output row
   const float* rowinv;    // [n_io][48]: 2^-s(w)
@@ -152,7 +153,7 @@ struct ConvZDesc {
   int max_chunks;
   const float* xmax;      // [graphs] largest |x| over the rows of every graph (k_row_absmax), or null: the kernel reads the chunk's gathered rows itself
 };
-struct ConvZArgs { ConvZDesc c[4]; int n_conv; float* dbg; double* executed; };   // executed (profiling only): += flops of the matrix instructions issued   // dbg (developer, DBFR_CONVZ_DEBUG=<file>): workgroup 0 / wave 0 of the first unit dumps h [32 slots][144]
+struct ConvZArgs { ConvZDesc c[4]; int n_conv; float* dbg; double* executed; int dbg_sel; };   // executed (profiling only): [0] += flops of the matrix instructions issued, [1] += the flops among them that are not padding (live edge slots, live segment columns, valid (path, u) pairs)   // dbg (developer, DBFR_CONVZ_DEBUG=<file>): workgroup 0 / wave 0 of the first unit dumps h [32 slots][144]
 
 static inline uint16_t dbfr_bf16_rne(float x) {   // round-to-nearest-even fp32 -> bf16 (finite inputs)
   uint32_t u;

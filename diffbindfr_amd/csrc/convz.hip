@@ -387,6 +387,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     for (int io = 0; io < W.n_io; ++io) {
       // ... step A: 3 per (segment slot, tile), step B: 9 per (column block, tile) -- of the k tile 9 by wave 0 only
       n_mfma += (long long)W.nct[io] * (3LL * CZ_NKT * CZ_MAXSEG + 9LL * ncb * (KT + (wave == 0)));
+
       f32x4 acc[3][CZ_NCB];
 #pragma unroll
       for (int wt = 0; wt < 3; ++wt)
@@ -667,7 +668,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       }
       __syncthreads();
     }
-    if (a.executed && lane == 0) atomicAdd(a.executed, 16384.0 * (double)n_mfma);   // 16 x 16 x 32 x 2 flops per instruction
+    if (a.executed && lane == 0) {                           // 16 x 16 x 32 x 2 flops per instruction
+      atomicAdd(a.executed, 16384.0 * (double)n_mfma);
+      // ... and the flops among them that are not padding (three partial products each): the hidden layer of my edges; step A the edges of a segment x the
+      // (path, u) pairs that exist x 145 (the k tile 9: one column); step B one column per segment x (c, k) values x 48 (every wave counts step B for
+      // the segments of its own chunk)
+      double useful = 144.0 * 144.0 * len;
+      for (int io = 0; io < W.n_io; ++io) useful += (double)W.nc_valid[io] * 145.0 * ((double)len + 48.0 * nseg_u);
+      atomicAdd(a.executed + 1, 6.0 * useful);
+      atomicAdd(a.executed + 2, 4.0 * 48.0 * W.n_io * nseg_u);   // (HBM bytes of the form that runs: a segment's scalar-output columns are written once)
+    }
   }
 }
 

@@ -99,7 +99,7 @@ class PdbTopology(C.Structure):
 SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_model_set_edge_log", "dbfr_model_fallback_convs", "dbfr_model_rowscaled_convs", "dbfr_model_set_gemm", "dbfr_model_get_gemm", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
            "dbfr_sample_range", "dbfr_capacity_report",
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_build_id", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths", "dbfr_test_pack_f16_tiles", "dbfr_test_pack_f16_rows", "dbfr_test_chunk_table", "dbfr_test_pack_f16_depth", "dbfr_probe_mfma_f16",
-           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_profile_fused_bytes", "dbfr_profile_executed_flops", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
+           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_profile_fused_bytes", "dbfr_profile_executed_flops", "dbfr_profile_useful_flops", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
            "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket", "dbfr_sdf_format",
            "dbfr_sdf_write_files", "dbfr_mdn_model_create", "dbfr_mdn_model_destroy", "dbfr_mdn_workspace_bytes", "dbfr_mdn_forward", "dbfr_mdn_pocket_features"]
 
@@ -150,6 +150,7 @@ def load():
     lib.dbfr_profile_enable.argtypes = [vp, i32]
     lib.dbfr_profile_fused_bytes.argtypes = [vp, C.POINTER(C.c_double)]
     lib.dbfr_profile_executed_flops.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.dbfr_profile_useful_flops.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dbfr_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), i32]
     lib.dbfr_workspace_layout.argtypes = [vp, C.POINTER(Batch), C.POINTER(Limits), C.c_char_p, C.c_size_t,
@@ -171,7 +172,7 @@ def load():
     lib.dbfr_mdn_workspace_bytes.argtypes = [C.POINTER(MdnBatch), C.POINTER(C.c_size_t)]
     lib.dbfr_mdn_pocket_features.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dbfr_mdn_forward.argtypes = [vp, C.POINTER(MdnBatch), vp, vp, vp, vp, C.c_size_t, vp]
-    if lib.dbfr_abi_version() != 5:
+    if lib.dbfr_abi_version() != 6:
         raise DbfrError("libdbfr ABI version mismatch")
     _lib = lib
     return lib

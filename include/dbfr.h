@@ -30,10 +30,11 @@
 extern "C" {
 #endif
 
-#define DBFR_ABI_VERSION 5   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
+#define DBFR_ABI_VERSION 6   /* 2: + dbfr_sample_range, dbfr_capacity_report, dbfr_sdf_*, dbfr_mdn_*, dbfr_build_id, dbfr_test_conv2;
                                 3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only);
                                 4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_model_set_edge_log takes the graph capacity; DBFR_GEMM_SPLIT_BF16_L1 (k_conv2s) retired; dbfr_test_conv2's message rows in that mode hold segment sums;
-                                5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back), dbfr_test_pack_f16_rows, dbfr_test_chunk_table; the reduce-first chunks hold <= 4 targets; DBFR_GEMM_SPLIT_BF16 (k_conv2r) retired */
+                                5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back), dbfr_test_pack_f16_rows, dbfr_test_chunk_table; the reduce-first chunks hold <= 4 targets; DBFR_GEMM_SPLIT_BF16 (k_conv2r) retired;
+                                6: + dbfr_profile_useful_flops (additions only) */
 
 typedef enum {
   DBFR_OK = 0,
@@ -490,6 +491,13 @@ int dbfr_profile_fused_bytes(const dbfr_model* m, double* fused_form_bytes);
 /* Flops the matrix pipe EXECUTED in the launches the last dbfr_profile_read reported: per edge `products` x 2 x 144 x (144 + rows walked) in the per-edge
  * kernels (products: 1 fp32 instruction, 3 two-piece fp16, 6 three-piece bf16), the instructions k_convz issued x 16384 in DBFR_GEMM_REDUCE_FIRST.   */
 int dbfr_profile_executed_flops(const dbfr_model* m, double* executed_flops);
+/* (ABI 6) Of those, the flops that are NOT padding -- *useful_flops: in DBFR_GEMM_REDUCE_FIRST the hidden layer once per edge (the pair of kernels computes it
+ * twice), step A's products over the edges a segment holds (k_convz issues them over all 32 slots of a chunk for each of four segment slots, filled or
+ * not), step B's over the segments a unit holds (not the 16-column blocks) and the (path, u) pairs that exist (not the padding of a c tile), times the three
+ * partial products; in the per-edge modes the executed flops.  *form_bytes: HBM bytes the form that RUNS has to move for the same launches (the fused
+ * form's of dbfr_profile_fused_bytes, but in DBFR_GEMM_REDUCE_FIRST the edge records and gathered rows once per kernel of the pair and the
+ * scalar-output message columns once per segment).  Either pointer may be null.                                                          */
+int dbfr_profile_useful_flops(const dbfr_model* m, double* useful_flops, double* form_bytes);
 
 /* What the fp16 matrix pipe of the CURRENT device sustains: a bare stream of v_mfma_f32_16x16x32_f16 (the instruction of DBFR_GEMM_SPLIT_F16)
  * with random operands on every compute unit, two waves per SIMD, for `seconds` (0 < seconds <= 60; the rate is taken over the second half,

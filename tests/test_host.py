@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(L.SYMBOLS) == declared
-    assert lib.dbfr_abi_version() == 5
+    assert lib.dbfr_abi_version() == 6
 
 
 def test_gemm_mode_entry_points_reject_bad_arguments():

@@ -19,6 +19,7 @@ def main():
     args = sys.argv[2:]
     srcs = ["convz.hip"]
     extra = []
+    srcdir = None
     i = 0
     while i < len(args):
         if args[i] == "--dev":
@@ -26,6 +27,9 @@ def main():
         elif args[i] == "--src":
             i += 1
             srcs = args[i].split(",")
+        elif args[i] == "--srcdir":          # take the named sources from another directory (e.g. an older revision checked out under tools/exp/ab/src_<x>/)
+            i += 1
+            srcdir = os.path.abspath(args[i])
         else:
             extra.append(args[i])
         i += 1
@@ -38,7 +42,7 @@ def main():
         obj = os.path.join(B.CSRC, os.path.splitext(s)[0] + ".o")
         if s in srcs:
             obj = os.path.join(obj_dir, os.path.splitext(s)[0] + ".o")
-            cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "-c", os.path.join(B.CSRC, s), "-o", obj] + B.FLAGS + B.FILE_FLAGS.get(s, B.DEFAULT_FP) + extra
+            cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "-c", os.path.join(srcdir or B.CSRC, s), "-o", obj, "-I", B.CSRC] + B.FLAGS + B.FILE_FLAGS.get(s, B.DEFAULT_FP) + extra
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode:
                 raise SystemExit(r.stderr)

@@ -1,27 +1,32 @@
-"""Developer: read the s_memtime timeline k_convz<8,128> wrote (DBFR_CONVZ_DEBUG=<file> DBFR_CONVZ_ABL=128, developer build) and print, per wave,
-the cycles between the stamps of the tile loop: 10 tile start, 11 step A done, 12 step B done, 13 barrier passed."""
+"""Developer: read the s_memtime timeline k_convz<128> wrote (DBFR_CONVZ_DEBUG=<file> DBFR_CONVZ_ABL=128, developer build) and print, per wave,
+the cycles between the stamps of workgroup 0's first unit: 1 unit start, 2 slots done, 3 hidden layer done, 10 tile start, 11 step A done,
+12 step B done, 13 barrier passed."""
 import sys, numpy as np
-t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(8, 1024)
-for w in range(8):
+t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(12, 512)      # [wave][stamp]: waves 0..7 chunk waves, 8..11 column waves
+for w in range(12):
     v = t[w][t[w] > 0]
     tags, ts = (v & 0xff).astype(int), (v >> 8).astype(np.int64)
     if len(ts) == 0:
         continue
-    print(f"wave {w}: {len(ts)} stamps; prologue: slots {ts[1]-ts[0] if len(ts)>1 else 0}  hidden+scan {ts[2]-ts[1] if len(ts)>2 else 0}")
-    # tile loop
-    i = 3; rows = []
+    first10 = int(np.argmax(tags == 10)) if (tags == 10).any() else len(tags)
+    print(f"wave {w}: {len(ts)} stamps; whole unit {ts[-1]-ts[0]}; prologue (tag: cycles since the stamp before):", [(int(tags[k]), int(ts[k] - ts[k-1])) for k in range(1, first10 + 1) if k < len(ts)])
+    i = first10; rows = []
     while i + 2 < len(ts) and len(rows) < 400:
         if tags[i] == 10:
             seq = {}
             k = 1
             while i + k < len(ts) and tags[i + k] != 10:
                 seq[int(tags[i + k])] = int(ts[i + k]); k += 1
-            rows.append((seq.get(11, ts[i]) - ts[i], seq.get(12, ts[i]) - ts[i], seq.get(13, ts[i]) - ts[i]))
+            nxt = int(ts[i + k]) if i + k < len(ts) else seq.get(13, int(ts[i]))
+            rows.append((seq.get(11, ts[i]) - ts[i], seq.get(12, ts[i]) - ts[i], seq.get(13, ts[i]) - ts[i], nxt - ts[i]))
             i += k
         else:
             i += 1
     r = np.array(rows)
     if len(r):
-        first = "A first" if w < 4 else "B first"
-        print(f"   {first}: tiles {len(r)}; mean cycles to [A done, B done, barrier passed] = {r.mean(0).round(0).tolist()}   median {np.median(r,0).tolist()}")
-        print("   first 12 tiles:", r[:12].tolist())
+        print(f"   tiles {len(r)}; mean cycles to [A done, B done, barrier passed, next tile] = {r.mean(0).round(0).tolist()}   median {np.median(r,0).tolist()}")
+        per = r.reshape(-1, 10, 4) if len(r) % 10 == 0 else None
+        if w >= 8: per = None
+        if per is not None:
+            print("   by k tile (mean over c tiles) [A, B, barrier]:", [per[:, k, :3].mean(0).round(0).astype(int).tolist() for k in range(10)])
+        print("   first 12 tiles:", r[:12, :3].tolist())
