@@ -182,7 +182,7 @@ def cpu_baseline(cfg_id, samp, dev, n_poses=1, batched=(2, 2), batched_steps=5):
     return out
 
 
-PMC_KERNEL = {"split_f16": "k_conv2h", "reduce_first": "k_conv"}
+PMC_KERNEL = {"split_f16": ("k_conv2h<",), "reduce_first": ("k_convz<", "k_conv2h<")}      # matched on "name<": `k_conv` alone also matched final_conv's k_conv<96> and k_conv2
 
 
 def measure_traffic(mode, args):
@@ -215,11 +215,11 @@ def measure_traffic(mode, args):
             tot, disp = 0.0, set()
             for f in files:
                 for row in csv.DictReader(open(f)):
-                    if kern in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    if any(k in row["Kernel_Name"] for k in kern) and row["Counter_Name"] == ctr:
                         tot += float(row["Counter_Value"])
                         # reduce_first: one 'launch' of the library's profile = k_convz + (where the conv has vector-output rows) k_conv2h;
                         # both kernels' bytes count, the launches are k_convz's
-                        if mode != "reduce_first" or "k_convz" in row["Kernel_Name"]:
+                        if mode != "reduce_first" or "k_convz<" in row["Kernel_Name"]:
                             disp.add(row["Dispatch_Id"])
             if not disp:
                 return None, f"no {kern} dispatch in the {ctr} pass"
@@ -359,8 +359,9 @@ def spawn_ranks(n, argv):
     base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", LOCAL_WORLD_SIZE=str(n))
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports (RCCL needs it)
     base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    # the rendezvous port: the socket that found it stays bound (SO_REUSEADDR) until the children are started, so that a second bench
-    # started at the same moment cannot be handed the same number
+    # the rendezvous port: a free one at this moment.  (The socket is closed right behind the Popen calls, seconds before rank 0 binds the port itself, so
+    # a second bench started in that window CAN be handed the same number -- rank 0's bind then fails and this function ends all ranks with its error;
+    # DBFR_DIST_TIMEOUT_S bounds the wait of the others.)
     sk = socket.socket()
     sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     sk.bind(("127.0.0.1", 0))
@@ -550,8 +551,9 @@ def main():
         # conv's flops); in the retired k_conv2r the 144 x 144 hidden layer stayed on the fp32 instruction inside the same kernel and was
         # not counted, k_conv2h runs it on the same three-product form (W1h tiles)
         ex = alg if mode == "f32" else P["products"] * (1.0 if P.get("hidden_on_pipe") else W2_SHARE) * alg
-        exe = C.c_double()
+        exe, use, formb = C.c_double(), C.c_double(), C.c_double()
         L.check(lib.dbfr_profile_executed_flops(h, C.byref(exe)))
+        L.check(lib.dbfr_profile_useful_flops(h, C.byref(use), C.byref(formb)))
         if mode == "reduce_first":
             # the reduce-first kernels do not execute products x the reference algorithm's flops: the library counts what the pipe executes (per-edge
             # kernel: 3 x 2 x 144 x (144 + vector-output rows) per edge; k_convz: the matrix instructions it issues x 16384)
@@ -575,7 +577,10 @@ def main():
                         f"launch of this kernel; 2 x FETCH_SIZE + WRITE_SIZE), valid for that workload only")
             else:
                 tsrc = f"{why}; no PMC file for this workload"
-        alg_bytes = fb.value / nl.value
+        # bytes per launch of the form that RUNS (reduce-first: the pair reads the edge records and gathered rows once per kernel and writes the
+        # scalar-output message columns once per segment); the fused single-kernel form's bytes stay in the line for comparison
+        alg_bytes = (formb.value if formb.value else fb.value) / nl.value
+        useful_tf = use.value / (ms.value * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ex, 1), "peak": P["peak"], "unit": "TFLOP/s", "frac": round(ex / P["peak"], 4),
                 "traffic": traffic, "traffic_source": tsrc, "traffic_counters": traw,
                 "algorithmic_bytes_per_launch": alg_bytes, "traffic_ratio": round(traffic / alg_bytes, 3) if traffic else None,
@@ -587,6 +592,12 @@ def main():
                          "algorithmic rate); peak = that instruction's dense peak; fp32_equivalent_tflops = algorithmic fp32 flops / kernel time"),
                 "kernel": P["kernel"], "instruction": P["instruction"], "products_per_fp32_product": P["products"],
                 "executed_tflops_counted": round(exe.value / (ms.value * 1e-3) / 1e12, 1),
+                #  what of the executed flops is not padding -- dbfr_profile_useful_flops: the hidden layer once per edge, step A over the
+                # edges a segment holds, step B over the segments a unit holds, the (path, u) pairs that exist; x 3 partial products
+                "useful_tflops": round(useful_tf, 1), "useful_frac": round(useful_tf / P["peak"], 4),
+                "padding_ratio": round(exe.value / use.value, 3) if use.value else None,
+                "reference_flops_over_time_tflops": round(alg, 2),
+                "fused_form_bytes_per_launch": fb.value / nl.value,
                 "reference_algorithm_flops_per_executed_flop": round(fl.value * P["products"] / exe.value, 3) if exe.value else None,
                 "fp32_equivalent_tflops": round(alg, 2), "fp32_matrix_peak": FP32_MATRIX_PEAK_TFLOPS,
                 "fp32_equivalent_over_fp32_matrix_peak": round(alg / FP32_MATRIX_PEAK_TFLOPS, 4),
@@ -597,10 +608,12 @@ def main():
                                    "nominal peak is reached with all-zero operands only") if P.get("sustained") else None,
                 "launches": nl.value, "avg_launch_ms": round(ms.value / nl.value, 4), "flops_per_launch": fl.value / nl.value,
                 "conv_time_share": round(ms.value * 1e-3 / elapsed_s, 4),
-                "algorithmic_bytes_note": "fused form: 4 (48 + 9 + 3 + 48 + 48 + D_in + D_out) B per edge (edge record, two gathered radial-MLP "
-                                          "rows, gathered input row, message); the [E,W] weights of the reference's two-kernel form are never "
-                                          "materialised, so north_star's HBM criterion is superseded by the MFMA bound (DESIGN.md section 5)",
-                "algorithmic_gbytes_per_s": round(fb.value / (ms.value * 1e-3) / 1e9, 1)}
+                "algorithmic_bytes_note": "the form that runs (dbfr_profile_useful_flops: form_bytes): per edge 4 (48 + 9 + 3 + 48 + 48 + D_in) B of inputs (edge record, "
+                                          "two gathered radial-MLP rows, gathered input row) ONCE PER KERNEL of the reduce-first pair, + 4 x the vector-output "
+                                          "message columns + 1 flag byte per edge, + 4 x 48 per scalar output irrep per SEGMENT; fused_form_bytes_per_launch = the "
+                                          "single-kernel form 4 (48 + 9 + 3 + 48 + 48 + D_in + D_out) per edge.  The [E,W] weights of the reference's two-kernel form "
+                                          "are never materialised, so north_star's HBM criterion is superseded by the MFMA bound (DESIGN.md section 5)",
+                "algorithmic_gbytes_per_s": round(alg_bytes * nl.value / (ms.value * 1e-3) / 1e9, 1)}
         return roof
 
     mode = main_mode = model.gemm_mode(dev)

@@ -49,6 +49,32 @@ def source_hash(dev=False):
     return h.hexdigest()[:16]
 
 
+def check_m0(hipcc, src):
+    """convz.hip writes m0 in inline assembly (`s_mov_b32 m0, <sgpr>` in front of each `global_load_lds_dword`: the LDS base of an LDS-DMA gather)
+    without declaring it clobbered -- hipcc rejects the clobber of a reserved register.  That is sound only while the COMPILER emits nothing that
+    reads or writes m0 in that kernel (movrel indexing, LDS-DMA builtins, GWS, sendmsg ...): this check compiles the file to assembly and fails the
+    build on any m0 operand that is not one of ours (verified on ROCm 7.2.0 / hipcc of this image)."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "convz.s")
+        cmd = [hipcc, "-x", "hip", "-S", "--cuda-device-only", src, "-o", out] + [f for f in FLAGS + FILE_FLAGS["convz.hip"] if not f.startswith("-Rpass")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc -S failed (m0 check):\n" + r.stderr)
+        lines = open(out).read().splitlines()
+    ours = re.compile(r"^\s*s_mov_b32 m0, s\d+\s*$")
+    bad = []
+    for i, l in enumerate(lines):
+        code = l.split(";")[0]
+        if re.search(r"\bm0\b", code) and not ours.match(code):
+            bad.append(f"{i + 1}: {l.strip()}")
+        if ours.match(code) and not any("global_load_lds_dword" in x for x in lines[i + 1:i + 4]):
+            bad.append(f"{i + 1}: s_mov_b32 m0 without an LDS-DMA load behind it: {l.strip()}")
+    if bad:
+        raise RuntimeError("convz.hip: the compiler (or an edit) uses m0 outside the LDS-DMA gathers -- the undeclared writes of prefetch_x are no longer safe:\n  " + "\n  ".join(bad[:10]))
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -84,6 +110,8 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
+    if any(j[4].endswith("convz.hip") for j in jobs):
+        check_m0(hipcc, os.path.join(CSRC, "convz.hip"))
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs)
     return LIB

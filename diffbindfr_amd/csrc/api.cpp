@@ -41,7 +41,8 @@ struct GraphArgs {
 };
 void dbfr_edge_form(const dbfr_batch& b, int* n_chunk, int* lanes);
 void launch_edges(const GraphArgs& A, bool heads_only, hipStream_t st);
-void launch_edge_log(const GraphArgs& A, int* log_row, hipStream_t st);
+void launch_edge_log(const GraphArgs& A, int* log_row, int stride, hipStream_t st);
+void launch_edge_ties(const GraphArgs& A, int* log_row, int stride, float tol, hipStream_t st);
 void launch_graph_chunks(const GraphArgs& A, hipStream_t st);
 void launch_flat_chunks(const int* tgt, const int* n_edges, int max_edges, int span, int n_span, int* cnt0, int cap, int* chunk_es, int* chunk_gl, hipStream_t st);
 void launch_row_absmax(const float* x, int ld, int D, const int* ptr, int G, float* out, hipStream_t st);
@@ -126,12 +127,15 @@ int dbfr_current_cu_count() {
 }
 
 // DBFR_GEMM = f32 | split_f16 | reduce_first: which matrix instruction carries the 144 x W GEMM of the K=144 convs (dbfr_model_set_gemm overrides)
+// Anything else -- the retired `split` / `split_l1` / 1 / 2 of rounds 2-4 among it -- is an ERROR (-1; dbfr_model_create fails with DBFR_ERR_ARG): until
+// round 6 an unknown value fell silently to the fp32 instruction, a quarter of the default's speed.
 static int gemm_from_env() {
   const char* e = getenv("DBFR_GEMM");
   if (!e || !*e) return DBFR_GEMM_DEFAULT;
+  if (!strcmp(e, "f32") || !strcmp(e, "0")) return DBFR_GEMM_F32;
   if (!strcmp(e, "split_f16") || !strcmp(e, "3")) return DBFR_GEMM_SPLIT_F16;
   if (!strcmp(e, "reduce_first") || !strcmp(e, "4")) return DBFR_GEMM_REDUCE_FIRST;
-  return DBFR_GEMM_F32;
+  return -1;
 }
 
 struct dbfr_model {
@@ -151,6 +155,7 @@ struct dbfr_model {
   std::string rowscaled_convs;  // 'name:depth;' of the convs packed with per-row factors (dbfr_model_rowscaled_convs)
   uint32_t layer_fallback;      // bit l: interaction layer l goes through the fp32-instruction kernel k_conv2 whatever the mode (a bias 2^48 above its row); bit 31: the torsion heads
   int* edge_log; int edge_log_steps, edge_log_graphs;   // dbfr_model_set_edge_log: caller-owned device buffer [steps][6][graphs], or null
+  int* tie_log; int tie_log_steps, tie_log_graphs; float tie_tol;   // dbfr_model_set_tie_log: likewise, candidate pairs within tie_tol of a cutoff
   Mlp2 lig_node_emb, lig_edge_emb, atom_edge_emb, la_edge_emb, center_edge_emb, tor_edge_emb, sc_edge_emb;
   Mlp2 tr_final, rot_final, tor_final, sc_final;
   const float* atom_emb[5]; int atom_dims[5];
@@ -812,6 +817,20 @@ extern "C" int dbfr_model_fallback_convs(const dbfr_model* m, char* names, size_
   return n;
 }
 
+// the per-graph read-outs are laid out for a graph capacity: a batch with MORE graphs is refused here, before any launch (a smaller one -- the ragged last
+// batch of a sharded run -- fills the first G entries of each row)
+static int check_logs(const dbfr_model* m, int G) {
+  if (m->edge_log && G > m->edge_log_graphs) return fail(DBFR_ERR_ARG, "dbfr_model_set_edge_log: the buffer was sized for " + std::to_string(m->edge_log_graphs) + " graphs, this batch has " + std::to_string(G));
+  if (m->tie_log && G > m->tie_log_graphs) return fail(DBFR_ERR_ARG, "dbfr_model_set_tie_log: the buffer was sized for " + std::to_string(m->tie_log_graphs) + " graphs, this batch has " + std::to_string(G));
+  return DBFR_OK;
+}
+
+extern "C" int dbfr_model_set_tie_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap, int32_t n_graphs_cap, float tol) {
+  if (!m || (log_dev && (n_steps_cap <= 0 || n_graphs_cap <= 0 || !(tol > 0.f)))) return fail(DBFR_ERR_ARG, "dbfr_model_set_tie_log: bad argument");
+  m->tie_log = log_dev; m->tie_log_steps = log_dev ? n_steps_cap : 0; m->tie_log_graphs = log_dev ? n_graphs_cap : 0; m->tie_tol = log_dev ? tol : 0.f;
+  return DBFR_OK;
+}
+
 extern "C" int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap, int32_t n_graphs_cap) {
   if (!m || (log_dev && (n_steps_cap <= 0 || n_graphs_cap <= 0))) return fail(DBFR_ERR_ARG, "dbfr_model_set_edge_log: bad argument");
   m->edge_log = log_dev; m->edge_log_steps = log_dev ? n_steps_cap : 0; m->edge_log_graphs = log_dev ? n_graphs_cap : 0;
@@ -884,11 +903,13 @@ static int model_create_impl(const dbfr_model_cfg* cfg, const dbfr_tensor* tenso
   m->profile = 0; m->ev_used = 0; m->flops_dev = nullptr; m->fused_bytes_last = 0; m->executed_last = 0; m->useful_last = 0; m->form_bytes_last = 0; m->conv_ms_acc = 0; m->conv_launches_acc = 0;
   m->streams_ready = false;
   m->edge_log = nullptr; m->edge_log_steps = 0; m->edge_log_graphs = 0; m->layer_fallback = 0;
+  m->tie_log = nullptr; m->tie_log_steps = 0; m->tie_log_graphs = 0; m->tie_tol = 0.f;
   // which fused-conv kernel the K=144 convs use: k_conv2 (persistent, one launch per layer, tail split) wins while a layer
   // is only a few rounds of workgroups (predict.py-sized batches), k_conv (conv.hip) at bench-sized batches.
   // DBFR_CONV2 = 0 / 1 forces one of them, default -1 = by batch size
   m->use_conv2 = getenv("DBFR_CONV2") ? atoi(getenv("DBFR_CONV2")) : -1;
   m->gemm_split = gemm_from_env();
+  if (m->gemm_split < 0) rc = fail(DBFR_ERR_ARG, std::string("DBFR_GEMM=") + getenv("DBFR_GEMM") + ": unknown or retired value (f32 | split_f16 | reduce_first)");
   m->conv2_layers = getenv("DBFR_CONV2_LAYERS") ? atoi(getenv("DBFR_CONV2_LAYERS")) : 0;
   m->conv_fuse = getenv("DBFR_CONV_FUSE") ? atoi(getenv("DBFR_CONV_FUSE")) : 1;
   const char* fam[4] = {"lig_conv_layers", "cross_al_conv_layers", "atom_conv_layers", "cross_la_conv_layers"};
@@ -1223,11 +1244,10 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
   // (a launcher that could not prepare its launch left the edge sets unbuilt: nothing below may run on them)
   if (int lrc = take_launch_error()) return lrc;
   if (m->gemm_split == DBFR_GEMM_REDUCE_FIRST) launch_graph_chunks(ga, st);   // per-graph chunks of 32 edges for k_convz
-  if (m->edge_log && step < m->edge_log_steps) {
-    // the log rows are laid out for the graph count the caller sized the buffer for: a batch with another count would write past it
-    if (G != m->edge_log_graphs) return fail(DBFR_ERR_ARG, "dbfr_model_set_edge_log: the buffer was sized for " + std::to_string(m->edge_log_graphs) + " graphs, this batch has " + std::to_string(G));
-    launch_edge_log(ga, m->edge_log + (size_t)step * N_SETS * G, st);
-  }
+  // (the log rows are laid out for the graph capacity the caller sized the buffer for; a batch with more graphs was refused before anything was launched:
+  // check_logs)
+  if (m->edge_log && step < m->edge_log_steps) launch_edge_log(ga, m->edge_log + (size_t)step * N_SETS * m->edge_log_graphs, m->edge_log_graphs, st);
+  if (m->tie_log && step < m->tie_log_steps) launch_edge_ties(ga, m->tie_log + (size_t)step * N_SETS * m->tie_log_graphs, m->tie_log_graphs, m->tie_tol, st);
   // ---- embeddings
   {
     MlpArgs a; memset(&a, 0, sizeof a);
@@ -1452,6 +1472,8 @@ static int begin(dbfr_model* m, const dbfr_batch* B, void* workspace, size_t wby
                  hipStream_t st) {
   g_launch_err = false;                                  // (a flag an earlier, failed call left on this thread is not this call's)
   int rc = check_batch(m, B);
+  if (rc) return rc;
+  rc = check_logs(m, B->G);
   if (rc) return rc;
   if (!workspace) return fail(DBFR_ERR_ARG, "null workspace");
   size_t needb = 0;
@@ -1760,6 +1782,23 @@ extern "C" int dbfr_test_conv2(dbfr_model* m, int32_t layer, int32_t family, int
                                const int32_t* idx2, const float* x, int32_t ldx, float* msg, void* hip_stream) {
   return test_conv_impl(m, true, layer, family, n_edges, n_edges_dev, tgt, gth, emb, sh, tab1, ld1, idx1, tab2, ld2, idx2, x, ldx,
                         msg, hip_stream);
+}
+
+// (ABI 6) ... with the message interface of DBFR_GEMM_REDUCE_FIRST: seg_first[e] = 1 marks the rows whose scalar-output columns hold a segment's sum (the
+// other rows' scalar columns are not read -- they may hold anything), the vector columns are per edge; seg_first == NULL: every column of every row
+extern "C" int dbfr_test_reduce_ln2(dbfr_model* m, int32_t layer, int32_t family, const float* msg, const int32_t* row_start, const int32_t* row_cnt,
+                                    int32_t n_nodes, const float* old, int32_t d_old, float* out, int32_t mode, const uint8_t* seg_first, void* hip_stream) {
+  if (!m) return fail(DBFR_ERR_ARG, "null model");
+  const ConvW* cw = pick_conv(m, layer, family);
+  if (!cw) return fail(DBFR_ERR_ARG, "no such conv");
+  unsigned long long lanes = 0;
+  if (seg_first) {
+    if (layer == -1 || cw->K != 144) return fail(DBFR_ERR_ARG, "dbfr_test_reduce_ln2: seg_first with a conv that has no reduce-first form");
+    lanes = convz_sc_lanes(layer >= 0 ? m->layerz[layer][family] : layer == -2 ? m->tor_convz : m->sc_convz);
+  }
+  launch_reduce_ln(msg, row_start, row_cnt, n_nodes, cw->D_out, cw->ln, old, d_old, out, cw->D_out, mode, (hipStream_t)hip_stream, seg_first, lanes);
+  HIPCHECK(hipGetLastError());
+  return DBFR_OK;
 }
 
 extern "C" int dbfr_test_reduce_ln(dbfr_model* m, int32_t layer, int32_t family, const float* msg,

@@ -387,7 +387,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
     for (int io = 0; io < W.n_io; ++io) {
       // ... step A: 3 per (segment slot, tile), step B: 9 per (column block, tile) -- of the k tile 9 by wave 0 only
       n_mfma += (long long)W.nct[io] * (3LL * CZ_NKT * CZ_MAXSEG + 9LL * ncb * (KT + (wave == 0)));
-
       f32x4 acc[3][CZ_NCB];
 #pragma unroll
       for (int wt = 0; wt < 3; ++wt)
@@ -668,16 +667,31 @@ __global__ __launch_bounds__(64 * NW, 2) void k_convz(ConvZArgs a) {
       }
       __syncthreads();
     }
-    if (a.executed && lane == 0) {                           // 16 x 16 x 32 x 2 flops per instruction
-      atomicAdd(a.executed, 16384.0 * (double)n_mfma);
-      // ... and the flops among them that are not padding (three partial products each): the hidden layer of my edges; step A the edges of a segment x the
-      // (path, u) pairs that exist x 145 (the k tile 9: one column); step B one column per segment x (c, k) values x 48 (every wave counts step B for
-      // the segments of its own chunk)
-      double useful = 144.0 * 144.0 * len;
-      for (int io = 0; io < W.n_io; ++io) useful += (double)W.nc_valid[io] * 145.0 * ((double)len + 48.0 * nseg_u);
-      atomicAdd(a.executed + 1, 6.0 * useful);
-      atomicAdd(a.executed + 2, 4.0 * 48.0 * W.n_io * nseg_u);   // (HBM bytes of the form that runs: a segment's scalar-output columns are written once)
+    if (a.executed && lane == 0) atomicAdd(a.executed, 16384.0 * (double)n_mfma);   // 16 x 16 x 32 x 2 flops per instruction
+  }
+}
+
+// (profiling only, its own launch -- k_convz itself is not touched: a handful of extra live values moved its spills and cost 14 % of its speed)
+// The flops among those k_convz issues that are not padding, [1] of the counters, and the message bytes of the form that runs, [2]: per chunk the hidden
+// layer of its edges; step A the edges x the (path, u) pairs that exist x 145 (the k tile 9: one column); step B one column per segment x (c, k) values
+// x 48; three partial products each.  One thread per chunk.
+__global__ void k_convz_useful(ConvZArgs a) {
+  for (int c = 0; c < a.n_conv; ++c) {
+    const ConvZDesc& d = a.c[c];
+    const ConvZ& W = d.w;
+    const int nch = min(*d.n_chunks, d.max_chunks), E = min(*d.n_edges, d.max_edges);
+    double useful = 0.0, bytes = 0.0;
+    for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < nch; ch += gridDim.x * blockDim.x) {
+      const int es = d.chunk_es[ch], len = min(min(d.chunk_gl[ch] & 63, 32), max(E - es, 0));
+      int nseg = 0;
+      for (int i = 0; i < len; ++i) nseg += (i == 0 || d.tgt[es + i] != d.tgt[es + i - 1]);
+      nseg = min(nseg, CZ_MAXSEG);
+      double u = 144.0 * 144.0 * len;
+      for (int io = 0; io < W.n_io; ++io) u += (double)W.nc_valid[io] * 145.0 * ((double)len + 48.0 * nseg);
+      useful += 6.0 * u;
+      bytes += 4.0 * 48.0 * W.n_io * nseg;
     }
+    if (useful > 0.0) { atomicAdd(a.executed + 1, useful); atomicAdd(a.executed + 2, bytes); }
   }
 }
 
@@ -704,6 +718,7 @@ void launch_convz(const ConvZArgs& a0, hipStream_t st) {
   static int abl = getenv("DBFR_CONVZ_ABL") ? atoi(getenv("DBFR_CONVZ_ABL")) : 0;
   if (abl == 1) V(1) if (abl == 2) V(2) if (abl == 4) V(4) if (abl == 8) V(8) if (abl == 16) V(16) if (abl == 32) V(32) if (abl == 12) V(12) if (abl == 5) V(5) if (abl == 64) V(64) if (abl == 128) V(128)
 #endif
+  if (a.executed) hipLaunchKernelGGL(k_convz_useful, dim3(64), dim3(256), 0, st, a);
   V(0)
 #undef V
 }

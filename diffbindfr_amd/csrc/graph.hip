@@ -578,20 +578,79 @@ void launch_row_absmax(const float* x, int ld, int D, const int* ptr, int G, flo
 }
 
 // dbfr_model_set_edge_log: per-graph edge counts of this step, log[k * G + g] = sum over the graph's target chunks
-__global__ void k_edge_log(GraphArgs A, int* log) {
+__global__ void k_edge_log(GraphArgs A, int* log, int stride) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
   if (g >= A.b.G) return;
   const EdgeSet& S = A.set[k];
   int c = 0;
   if (S.cap > 0)
     for (int i = 0; i < A.n_chunk; ++i) c += S.g_cnt[g * A.n_chunk + i];
-  log[k * A.b.G + g] = c;
+  log[k * stride + g] = c;
 }
 
-void launch_edge_log(const GraphArgs& A0, int* log_row, hipStream_t st) {
+void launch_edge_log(const GraphArgs& A0, int* log_row, int stride, hipStream_t st) {
   GraphArgs A = A0;
   if (A.n_chunk <= 0) dbfr_edge_form(A.b, &A.n_chunk, &A.lanes);
-  hipLaunchKernelGGL(k_edge_log, dim3((A.b.G + 255) / 256, N_SETS), dim3(256), 0, st, A, log_row);
+  hipLaunchKernelGGL(k_edge_log, dim3((A.b.G + 255) / 256, N_SETS), dim3(256), 0, st, A, log_row, stride);
+}
+
+// Diagnostic (dbfr_model_set_tie_log; never on the data path): per graph and edge set, the number of candidate pairs whose distance lies within `tol` of
+// the set's hard cutoff -- the pairs at which two runs that differ by rounding may build different graphs (the reference's radius graphs have no soft
+// edge).  Distances as the edge builder forms them (d2_rn of the staged coordinates, the cross sets in units of the graph's dynamic cutoff, pseudotorque
+// sets from the bond mid-point); a pair counts when |d - cutoff| <= tol, i.e. |d2 - cut2| <= 2 cutoff tol (+ tol^2).  One workgroup per (graph, set);
+// the cross sets 2 and 3 hold the same pairs.  The 32-neighbour caps (by index, not by distance) have no ties.
+__global__ void k_edge_ties(GraphArgs A, int* log, int stride, float tol) {
+  const int g = blockIdx.x, k = blockIdx.y;
+  const EdgeSet& S = A.set[k];
+  __shared__ int total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  int c = 0;
+  if (S.cap > 0) {
+    const int l0 = A.b.lig_ptr[g], nl = A.b.lig_ptr[g + 1] - l0, a0 = A.b.atm_ptr[g], na = A.b.atm_ptr[g + 1] - a0;
+    const float* LP = A.b.lig_pos;
+    const float* RP = A.b.rec_pos;
+    auto near = [&](float d2, float cut2, float t) { const float cut = sqrtf(cut2); return fabsf(d2 - cut2) <= 2.f * cut * t + t * t; };
+    if (k == SET_LL || k == SET_AA) {
+      const float* P = k == SET_LL ? LP : RP;
+      const int p0 = k == SET_LL ? l0 : a0, np = k == SET_LL ? nl : na;
+      const float cut2 = k == SET_LL ? A.lig_cut2 : A.atom_cut2;
+      for (long idx = threadIdx.x; idx < (long)np * np; idx += blockDim.x) {
+        const int i = (int)(idx / np), j = (int)(idx - (long)i * np);
+        if (i < j) c += near(d2_rn(P[3 * (p0 + i)], P[3 * (p0 + i) + 1], P[3 * (p0 + i) + 2], P[3 * (p0 + j)], P[3 * (p0 + j) + 1], P[3 * (p0 + j) + 2]), cut2, tol);
+      }
+    } else if (k == SET_AL || k == SET_LA) {
+      const float scale = A.dynamic_cross ? __fadd_rn(__fmul_rn(A.tr_sigma[g], 0.2f), 5.0f) : 1.0f;
+      for (long idx = threadIdx.x; idx < (long)nl * na; idx += blockDim.x) {
+        const int i = (int)(idx / na), j = (int)(idx - (long)i * na);
+        if (A.is_cab[a0 + j]) continue;                        // (CA / CB atoms are edges whatever their distance)
+        float x0 = LP[3 * (l0 + i)], y0 = LP[3 * (l0 + i) + 1], z0 = LP[3 * (l0 + i) + 2], x1 = RP[3 * (a0 + j)], y1 = RP[3 * (a0 + j) + 1], z1 = RP[3 * (a0 + j) + 2];
+        if (A.dynamic_cross) { x0 = __fdiv_rn(x0, scale); y0 = __fdiv_rn(y0, scale); z0 = __fdiv_rn(z0, scale); x1 = __fdiv_rn(x1, scale); y1 = __fdiv_rn(y1, scale); z1 = __fdiv_rn(z1, scale); }
+        c += near(d2_rn(x0, y0, z0, x1, y1, z1), A.cross_cut2, tol / scale);
+      }
+    } else {
+      const bool tor = k == SET_TOR;
+      const int t0 = tor ? A.b.tor_ptr[g] : A.b.sc_ptr[g], nt = (tor ? A.b.tor_ptr[g + 1] : A.b.sc_ptr[g + 1]) - t0;
+      const float* P = tor ? LP : RP;
+      const int p0 = tor ? l0 : a0, np = tor ? nl : na;
+      const float cut2 = tor ? A.lig_cut2 : A.atom_cut2;
+      for (long idx = threadIdx.x; idx < (long)nt * np; idx += blockDim.x) {
+        const int t = (int)(idx / np), j = (int)(idx - (long)t * np);
+        int u, v;
+        if (tor) { const int b = A.b.tor_bond[t0 + t]; u = A.b.bond_src[b]; v = A.b.bond_dst[b]; }
+        else { u = A.b.sc_bond[2 * (t0 + t)]; v = A.b.sc_bond[2 * (t0 + t) + 1]; }
+        const float mx = (P[3 * u] + P[3 * v]) / 2, my = (P[3 * u + 1] + P[3 * v + 1]) / 2, mz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
+        c += near(d2_rn(mx, my, mz, P[3 * (p0 + j)], P[3 * (p0 + j) + 1], P[3 * (p0 + j) + 2]), cut2, tol);
+      }
+    }
+  }
+  if (c) atomicAdd(&total, c);
+  __syncthreads();
+  if (threadIdx.x == 0) log[k * stride + g] = total;
+}
+
+void launch_edge_ties(const GraphArgs& A, int* log_row, int stride, float tol, hipStream_t st) {
+  hipLaunchKernelGGL(k_edge_ties, dim3(A.b.G, N_SETS), dim3(256), 0, st, A, log_row, stride, tol);
 }
 
 // ------------------------------------------------------------------------------------------------

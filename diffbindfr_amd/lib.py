@@ -96,10 +96,10 @@ class PdbTopology(C.Structure):
 
 
 # every symbol include/dbfr.h declares (tests check that the library exports all of them)
-SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_model_set_edge_log", "dbfr_model_fallback_convs", "dbfr_model_rowscaled_convs", "dbfr_model_set_gemm", "dbfr_model_get_gemm", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
+SYMBOLS = ["dbfr_model_create", "dbfr_model_destroy", "dbfr_model_set_edge_log", "dbfr_model_set_tie_log", "dbfr_model_fallback_convs", "dbfr_model_rowscaled_convs", "dbfr_model_set_gemm", "dbfr_model_get_gemm", "dbfr_workspace_bytes", "dbfr_score", "dbfr_sample",
            "dbfr_sample_range", "dbfr_capacity_report",
            "dbfr_init_poses", "dbfr_extract_templates", "dbfr_status_sync", "dbfr_abi_version", "dbfr_build_id", "dbfr_last_error", "dbfr_wigner3j", "dbfr_conv_paths", "dbfr_test_pack_f16_tiles", "dbfr_test_pack_f16_rows", "dbfr_test_chunk_table", "dbfr_test_pack_f16_depth", "dbfr_probe_mfma_f16",
-           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_profile_fused_bytes", "dbfr_profile_executed_flops", "dbfr_profile_useful_flops", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln",
+           "dbfr_profile_enable", "dbfr_profile_read", "dbfr_profile_fused_bytes", "dbfr_profile_executed_flops", "dbfr_profile_useful_flops", "dbfr_workspace_layout", "dbfr_test_conv", "dbfr_test_conv2", "dbfr_test_reduce_ln", "dbfr_test_reduce_ln2",
            "dbfr_pose_metrics", "dbfr_pdb_format", "dbfr_pdb_write_files", "dbfr_select_pocket", "dbfr_sdf_format",
            "dbfr_sdf_write_files", "dbfr_mdn_model_create", "dbfr_mdn_model_destroy", "dbfr_mdn_workspace_bytes", "dbfr_mdn_forward", "dbfr_mdn_pocket_features"]
 
@@ -125,6 +125,7 @@ def load():
     lib.dbfr_model_destroy.argtypes = [vp]
     lib.dbfr_model_destroy.restype = None
     lib.dbfr_model_set_edge_log.argtypes = [vp, vp, i32, i32]
+    lib.dbfr_model_set_tie_log.argtypes = [vp, vp, i32, i32, C.c_float]
     lib.dbfr_model_fallback_convs.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.dbfr_model_rowscaled_convs.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.dbfr_model_set_gemm.argtypes = [vp, i32]
@@ -158,6 +159,7 @@ def load():
     lib.dbfr_test_conv.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp]
     lib.dbfr_test_conv2.argtypes = lib.dbfr_test_conv.argtypes
     lib.dbfr_test_reduce_ln.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp]
+    lib.dbfr_test_reduce_ln2.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, i32, vp, vp]
     lib.dbfr_select_pocket.argtypes = [i32, i32, vp, i32, vp, vp, vp, vp, C.c_double, i32, vp, vp, vp]
     lib.dbfr_pose_metrics.argtypes = [C.POINTER(PoseMetricsIn), C.POINTER(PoseMetricsOut), vp]
     lib.dbfr_pdb_format.argtypes = [C.POINTER(PdbTopology), i32, vp, vp, i32, i32, vp, C.c_int64]

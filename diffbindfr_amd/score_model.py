@@ -237,6 +237,10 @@ class TensorProductModelHIP(nn.Module):
         if isinstance(log, dict) and ("cuda", idx) in log:      # the edge-count read-out survives a re-pack
             t = log[("cuda", idx)]
             L.check(lib.dbfr_model_set_edge_log(h, C.c_void_p(t.data_ptr()), t.shape[0], t.shape[2]))
+        tl = getattr(self, "_tie_log", None)
+        if isinstance(tl, dict) and ("cuda", idx) in tl:        # ... and the near-tie read-out
+            t, tol = tl[("cuda", idx)]
+            L.check(lib.dbfr_model_set_tie_log(h, C.c_void_p(t.data_ptr()), t.shape[0], t.shape[2], tol))
         self._handles[idx] = (fp, h)
         return h
 
@@ -275,6 +279,24 @@ class TensorProductModelHIP(nn.Module):
         log = torch.zeros(n_steps, 6, G, dtype=torch.int32, device=dev)
         L.check(L.load().dbfr_model_set_edge_log(self.handle(dev), C.c_void_p(log.data_ptr()), n_steps, G))
         self._edge_log[key] = log          # (kept alive while the library holds the pointer; a re-packed handle gets it again: handle())
+        return log
+
+    def tie_log(self, device, n_steps, G, tol=1e-5):
+        """The companion of ``edge_log`` (``dbfr_model_set_tie_log``): device int32 tensor [n_steps, 6, G] = per step, edge set and graph the number of
+        candidate pairs within ``tol`` Angstrom of the set's hard cutoff -- where two runs that differ by rounding (another GEMM mode, the reference
+        on another batch) may build different graphs.  All-zero rows: the step's graphs are decided by margins above ``tol``.  ``n_steps = 0``
+        switches it off."""
+        dev = torch.device(device)
+        if not isinstance(getattr(self, "_tie_log", None), dict):
+            self._tie_log = {}
+        key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+        if n_steps <= 0:
+            L.check(L.load().dbfr_model_set_tie_log(self.handle(dev), None, 0, 0, 0.0))
+            self._tie_log.pop(key, None)
+            return None
+        log = torch.zeros(n_steps, 6, G, dtype=torch.int32, device=dev)
+        L.check(L.load().dbfr_model_set_tie_log(self.handle(dev), C.c_void_p(log.data_ptr()), n_steps, G, float(tol)))
+        self._tie_log[key] = (log, float(tol))
         return log
 
     def set_gemm(self, mode):

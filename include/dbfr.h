@@ -34,7 +34,7 @@ extern "C" {
                                 3: + dbfr_model_set_edge_log, dbfr_model_fallback_convs, dbfr_test_pack_f16_depth, dbfr_probe_mfma_f16 (additions only);
                                 4: + DBFR_GEMM_REDUCE_FIRST (the new default), dbfr_profile_executed_flops; dbfr_model_set_edge_log takes the graph capacity; DBFR_GEMM_SPLIT_BF16_L1 (k_conv2s) retired; dbfr_test_conv2's message rows in that mode hold segment sums;
                                 5: + dbfr_model_rowscaled_convs (per-row factors instead of the three-bf16-piece fall-back), dbfr_test_pack_f16_rows, dbfr_test_chunk_table; the reduce-first chunks hold <= 4 targets; DBFR_GEMM_SPLIT_BF16 (k_conv2r) retired;
-                                6: + dbfr_profile_useful_flops (additions only) */
+                                6: + dbfr_profile_useful_flops, dbfr_model_set_tie_log, dbfr_test_reduce_ln2; dbfr_model_set_edge_log accepts batches with fewer graphs than its capacity; an unknown DBFR_GEMM value fails dbfr_model_create */
 
 typedef enum {
   DBFR_OK = 0,
@@ -200,14 +200,21 @@ int dbfr_capacity_report(void* workspace, void* hip_stream, int32_t* first_faile
 
 /* Per-graph read-out of the per-step graphs (dbfr_status_sync's counters are per batch).  With log != NULL every step s < n_steps_cap of
  * the dbfr_sample / dbfr_sample_range calls that follow on this model writes the edge count of graph g in edge set k to
- * log[(s * 6 + k) * G + g] (device int32, caller-owned, n_steps_cap * 6 * n_graphs_cap entries; a batch whose graph count G differs from
- * n_graphs_cap is refused with DBFR_ERR_ARG instead of written past the buffer), k = {0 ligand
+ * log[(s * 6 + k) * n_graphs_cap + g] (device int32, caller-owned, n_steps_cap * 6 * n_graphs_cap entries; a batch with MORE graphs than
+ * n_graphs_cap is refused with DBFR_ERR_ARG before anything is launched, a smaller one -- the ragged last batch of a sharded run -- fills the
+ * first G entries of each row; until ABI 6 any other count was refused, and only after the step's first launches), k = {0 ligand
  * (bonds + radius_graph, tpscore.py:586), 1 pocket (:613), 2 cross lig<-atom, 3 cross atom<-lig (the same pairs, :655-660), 4 ligand
  * torsion (:721), 5 side-chain torsion (:747)}; dbfr_score writes row s = 0.  A set that overflowed its capacity still reports the count
  * it needed.  log == NULL switches the read-out off (the default).  The counts make a hard-cutoff event visible: two runs whose
  * coordinates differ in the 5th decimal build different graphs exactly where a pair sits within rounding distance of a cutoff
  * (tests/test_examples.py).                                                                                                        */
 int dbfr_model_set_edge_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap, int32_t n_graphs_cap);
+/* (ABI 6) The companion read-out: ties[(s * 6 + k) * n_graphs_cap + g] = the number of candidate pairs of graph g in edge set k whose distance lies within
+ * `tol` (Angstrom, > 0) of the set's hard cutoff at step s -- the pairs at which two runs that differ by rounding (another DBFR_GEMM mode, another
+ * batch of the reference) may build different graphs.  A zero row means the step's graph is decided by margins above tol; tools/validate_checkpoint.py
+ * and tests/test_examples.py read it next to the edge counts.  Diagnostic: its kernel is launched only while a log is attached.  Same layout, capacity
+ * rule and switch-off (log == NULL) as dbfr_model_set_edge_log.                                                                                */
+int dbfr_model_set_tie_log(dbfr_model* m, int32_t* log_dev, int32_t n_steps_cap, int32_t n_graphs_cap, float tol);
 
 /* ---- pose initialisation, on the device.
  * Replaces the per-pose real-time transforms LigInit + SCProtInit +
@@ -425,7 +432,8 @@ int dbfr_status_sync(void* workspace, void* hip_stream, int64_t* counters);
  *                            its other rows are zero in the buffer dbfr_test_conv2 fills (the hook clears it first) and NOT WRITTEN inside the
  *                            sampler, whose reductions read them of segment-first rows only (vector columns: per edge as before).  Chunks
  *                            are cut per graph, by the graph's own targets: what is summed with what never depends on batch mates.
- * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split | split_f16 | reduce_first) says otherwise.
+ * The initial mode is DBFR_GEMM_DEFAULT unless the environment variable DBFR_GEMM (f32 | split_f16 | reduce_first, or the numbers 0 | 3 | 4) says otherwise;
+ * any other value -- the retired `split` / `split_l1` / 1 / 2 among them -- makes dbfr_model_create fail with DBFR_ERR_ARG (until ABI 6 it selected the fp32 instruction silently).
  * A workspace is laid out for the mode it was sized in: set the mode before dbfr_workspace_bytes.                       */
 #define DBFR_GEMM_F32 0
 /* (1 was DBFR_GEMM_SPLIT_BF16, k_conv2r: retired with ABI 5; 2 was DBFR_GEMM_SPLIT_BF16_L1, k_conv2s: retired with ABI 4; the numbers stay unused) */
@@ -526,6 +534,12 @@ int dbfr_test_conv2(dbfr_model* m, int32_t layer, int32_t family, int32_t n_edge
 int dbfr_test_reduce_ln(dbfr_model* m, int32_t layer, int32_t family, const float* msg, const int32_t* row_start,
                         const int32_t* row_cnt, int32_t n_nodes, const float* old, int32_t d_old, float* out,
                         int32_t mode, void* hip_stream);
+/* (ABI 6) The same reduction with the message interface of DBFR_GEMM_REDUCE_FIRST: seg_first [n_edges] bytes, 1 = the row's scalar-output columns hold a
+ * segment's sum (k_convz stores it in the segment's first row and writes nothing into those columns of the other rows: they are not read, whatever
+ * they hold); vector-output columns are per edge.  seg_first == NULL: as dbfr_test_reduce_ln.  K = 144 convs only.                              */
+int dbfr_test_reduce_ln2(dbfr_model* m, int32_t layer, int32_t family, const float* msg, const int32_t* row_start,
+                         const int32_t* row_cnt, int32_t n_nodes, const float* old, int32_t d_old, float* out,
+                         int32_t mode, const uint8_t* seg_first, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """Fixtures the ORACLE generates (no reference needed, so this runs anywhere -- e.g. on the GPU box's 128 host threads):
 
-    python tests/golden/make_oracle_fixtures.py [out_dir [5] [2] [25] [55]]
+    python tests/golden/make_oracle_fixtures.py [out_dir [5] [2] [25] [55]]      (555: the cfg-5 batch TRAJECTORY search that finds no robust seed)
 
   cfg5_traj.npz   BASELINE.json configs[4] (large pocket: ~600 pocket atoms / ~80 ligand atoms, flexible side chains), one complex x
                   one pose, all 20 reverse-diffusion steps through oracle/sampler.py (pinned on the reference's own sample(), see
@@ -10,7 +10,15 @@
   cfg2_batch_traj.npz (argument 25)  configs[1] as a BATCH: 3 complexes of ragged sizes x 2 poses (6 graphs) in one collated batch, 20 steps --
                   batch-level indexing (CSR pointers, per-graph chunks of the reduce-first conv, per-graph noise) at the BASELINE shape against
                   the oracle, not only against the library itself.
-  cfg5_batch_traj.npz (argument 55)  configs[4] likewise: 2 complexes x 2 poses.
+  cfg5_batch_steps.npz (argument 55)  configs[4] as a batch (2 complexes x 2 poses, ~2 400 pocket atoms / ~300 ligand atoms in one collated batch), STEP BY STEP:
+                  the state the oracle holds entering steps 0, 6, 12 and 19 of its 20-step run and the scores its model returns there.  A 20-step
+                  TRAJECTORY fixture cannot exist at this shape: the reference's graphs have hard cutoffs, a batch this size has ~560 000 candidate
+                  pairs per Angstrom of distance at its cutoffs, i.e. about one pair within 1e-6 A of a cutoff PER STEP, and a run that differs by fp32
+                  rounding flips it and ends 1e-2 .. 5e-1 A away -- eight seeds in a row were rejected by the robustness search of `cfg_trajectory`
+                  (second oracle run from coordinates moved by N(0, 1e-5 A): 2e-2 .. 6e-1 A apart after 20 steps; round 6, 2.3 CPU hours).  Held step
+                  by step the comparison does not amplify: tests/test_gpu_parity.py::test_cfg5_batch_scores_step_by_step feeds the library the oracle's
+                  state and compares the scores graph by graph, with the library's own near-tie read-out (dbfr_model_set_tie_log) deciding which
+                  graphs of which step sit at a cutoff.
 """
 import copy
 import os
@@ -75,6 +83,45 @@ def cfg_trajectory(out_dir, cfg_id, seed, noise_seed, robust=False, n_complex=1,
     print(path, os.path.getsize(path) // 1024, "KiB")
 
 
+def cfg_batch_steps(out_dir, cfg_id, seed, noise_seed, n_complex=2, poses=2, steps=(0, 6, 12, 19)):
+    """The batch through the oracle's 20 steps; at `steps` the evolving state (ligand / pocket coordinates, torsion angles) entering the step and the
+    four score tensors the oracle's model returns for it."""
+    T = synthetic.residue_tables()
+    mcfg = sm.default_cfg()
+    params = sm.init_params(mcfg, seed=1)
+    scfg = schedule.default_sample_cfg()
+    a14g = torch.from_numpy(T["atom14_to_group"]).long()
+    d = synthetic.make_batch(cfg_id, n_complex=n_complex, poses=poses, seed=seed)
+    G = d.num_graphs
+    n_tor, n_sc = int(d.tor_edge_mask.sum()), int(d.sc_torsion_edge_mask.sum())
+    noise = sampler.draw_noise(scfg.actual_steps, G, n_tor, n_sc, seed=noise_seed)
+    run = copy.deepcopy(d)
+    snap = {}
+
+    def tap(t_idx, scores):
+        if t_idx in steps:
+            snap[t_idx] = dict(lig_pos=run.lig_pos.clone(), rec_atm_pos=run.rec_atm_pos.clone(), torsion_angle=run.torsion_angle.clone(),
+                               tr=scores[0].clone(), rot=scores[1].clone(), tor=scores[2].clone(), sc_tor=scores[3].clone())
+    t0 = time.time()
+    sampler.sample(params, mcfg, scfg, run, noise, a14g, visualize=False, score_tap=tap)
+    print(f"cfg {cfg_id} batch ({n_complex} x {poses}): {int(d.rec_atm_pos.shape[0])} pocket atoms / {int(d.lig_pos.shape[0])} ligand atoms, {scfg.actual_steps} steps through the "
+          f"oracle on {torch.get_num_threads()} threads in {time.time() - t0:.0f}s; states kept at steps {sorted(snap)}")
+    out = {k: npy(v) for k, v in vars(d).items() if torch.is_tensor(v)}
+    for g, m in enumerate(d.rot_node_mask):
+        out[f"rot_node_mask_{g}"] = npy(m)
+    out["num_graphs"] = np.asarray(G)
+    out["params_seed"] = np.asarray(1)
+    out["steps"] = np.asarray(sorted(snap), np.int32)
+    for s_, v in snap.items():
+        for k, t in v.items():
+            out[f"step{s_}_{k}"] = npy(t).astype(np.float32)
+    for k in ("default_frame", "rigid_group_positions"):
+        out[k] = out[k].astype(np.float32)
+    path = os.path.join(out_dir, f"cfg{cfg_id}_batch_steps.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     out_dir = sys.argv[1] if len(sys.argv) > 1 else HERE
     os.makedirs(out_dir, exist_ok=True)
@@ -86,4 +133,6 @@ if __name__ == "__main__":
     if 25 in which:
         cfg_trajectory(out_dir, 2, 4212, 23, robust=True, n_complex=3, poses=2, tag="batch_traj", robust_tol=5e-4)      # (seeds 212 .. 3212 of the first search: 5e-4 .. 3e-3)
     if 55 in which:
+        cfg_batch_steps(out_dir, 5, 515, 56)
+    if 555 in which:      # (the trajectory-level search that found no seed: kept for the record)
         cfg_trajectory(out_dir, 5, 515, 56, robust=True, n_complex=2, poses=2, tag="batch_traj", robust_tol=5e-4)

@@ -159,6 +159,7 @@ def _oracle_rerun(z, samp, jobs, tapes, raws, g, s0, dev):
     from oracle import sampler as osampler, schedule as osched, score_model as sm
     from tests.helpers import oracle_batch_from_packed
     samp.diffusion_model.edge_log(dev, 0, 0)      # (the counts of the batch run were read already; the log buffer is sized for that batch)
+    samp.diffusion_model.tie_log(dev, 0, 0)
     pb1, _, _ = samp.run_complexes([jobs[g]], 1, dev, seeds=[0], tapes=[tapes[g]], stop=s0)
     torch.cuda.synchronize()
     d = oracle_batch_from_packed([raws[g]], 1, pb1)
@@ -174,8 +175,10 @@ def _oracle_rerun(z, samp, jobs, tapes, raws, g, s0, dev):
                            visualize=True, first_step=s0)
 
 
-def _check_against_reference(z, pb, lig, a14, log, tr_sigmas, before_tol=1e-4, margin_tol=5e-6, rerun=None):
-    """The assertions of the module docstring.  Returns the printed table's rows."""
+def _check_against_reference(z, pb, lig, a14, log, tr_sigmas, before_tol=1e-4, margin_tol=5e-6, rerun=None, ties=None, tie_tol=1e-5):
+    """The assertions of the module docstring.  Returns the printed table's rows.  `ties` (round 6): the library's own near-tie read-out
+    (dbfr_model_set_tie_log, [20, 6, G] candidate pairs within `tie_tol` of a cutoff): where a job's graphs leave the reference's, the library
+    itself must have flagged a pair at that step in one of the sets that differ -- a user without the reference can see the event coming."""
     assert "edge_counts" in z.files, "fixture without edge_counts: regenerate (GOLDEN_EXAMPLES_EDGES_ONLY=1 make_golden.py examples)"
     hip = log.cpu().numpy()                                   # [20, 6, G]
     assert np.array_equal(hip[:, 2], hip[:, 3]), "the two cross sets hold the same pairs"
@@ -196,6 +199,13 @@ def _check_against_reference(z, pb, lig, a14, log, tr_sigmas, before_tol=1e-4, m
         before = float(dev[g, :s0].max()) if s0 else 0.0
         mg = float(min(margin[s0, g, k] for k in sets))
         rows.append((g, f"step {s0}: " + ", ".join(f"{SETS[k]} {mine[s0, g, k]} vs {ref[s0, g, k]}" for k in sets), before, mg, worst, da[g]))
+        if ties is not None:
+            tl = ties.cpu().numpy()[:, HIP_SETS].transpose(0, 2, 1)      # [20, G, 5]
+            flagged = [int(tl[s0, g, k]) for k in sets]
+            print(f"  job {g}: the library's own tie read-out at step {s0} (pairs within {tie_tol:.0e} A of the cutoff) in the sets that differ: {flagged}; reference margin {mg:.1e}")
+            if mg < 0.5 * tie_tol:
+                assert max(flagged) > 0, f"job {g} step {s0}: graphs differ at a pair {mg:.1e} A from the cutoff, but the library's tie read-out is empty"
+
         if s0 > 0:      # (B): the library's graphs of step s0 against the oracle's builders on the library's OWN coordinates entering s0
             lp, rp = pb.lig_ptr_host.tolist(), pb.res_ptr_host.tolist()
             m14 = pb.atom14_mask[rp[g]:rp[g + 1]].cpu().bool()
@@ -246,13 +256,29 @@ def test_gpu_examples_follow_the_reference_trajectories(name):
     for mode in ("f32", default):
         model.set_gemm(mode)
         log = model.edge_log(dev, 20, len(jobs))
+        ties = model.tie_log(dev, 20, len(jobs), tol=1e-5)
         pb, lig, a14 = samp.run_complexes(jobs, 1, dev, seeds=[0] * len(jobs), tapes=[tapes[g] for g in range(len(jobs))], visualize=True)
         assert lig.shape[0] == 20
         print(f"{name} [gemm {mode}]")
+        # the reference's margins and the library's tie counts describe the same thing from both sides: wherever the reference has a pair within half
+        # the tolerance of a cutoff (and the trajectories still agree), the library flags that (step, graph, set) too; where the margin is twice the
+        # tolerance or more, it flags nothing
+        tl, mgn = ties.cpu().numpy()[:, HIP_SETS].transpose(0, 2, 1), z["cutoff_margin"]
+        devs = _per_step_deviation(z, pb, lig)
+        for s in range(20):
+            for g in range(len(jobs)):
+                if (float(devs[g, :s].max()) if s else 0.0) < 2e-6:      # (the two runs' coordinates entering step s agree to 2e-6 A: their margins to 4e-6)
+                    for k in range(5):
+                        if mgn[s, g, k] < 0.4e-5 and k < 4:      # (side-chain torsion set: the reference's margin is taken over all chi bonds, the library's over the flexible ones)
+                            assert tl[s, g, k] > 0, (name, mode, s, g, k, float(mgn[s, g, k]))
+                        if mgn[s, g, k] > 2.5e-5:
+                            assert tl[s, g, k] == 0, (name, mode, s, g, k, float(mgn[s, g, k]), int(tl[s, g, k]))
+        print(f"  near-tie read-out (pairs within 1e-5 A of a cutoff): {int((tl > 0).sum())} of {tl.size} (step, job, set) entries flagged")
         rows = _check_against_reference(z, pb, lig, a14, log, [r.tr_sigma for r in samp.schedule()[0]],
-                                        rerun=lambda g, s0: _oracle_rerun(z, samp, jobs, tapes, raws, g, s0, dev))
+                                        rerun=lambda g, s0: _oracle_rerun(z, samp, jobs, tapes, raws, g, s0, dev), ties=ties)
         n_event[mode] = sum(r[1] != "equal" for r in rows)
         model.edge_log(dev, 0, 0)
+        model.tie_log(dev, 0, 0)
     assert max(n_event.values()) <= max(2, len(jobs) // 4), n_event        # cutoff events are the exception, not the rule
     # small batches through the job driver: the poses of a job do not depend on its batch mates -> the very same final poses, in job order
     res = ddist.run_sharded(samp, jobs, 1, seed=0, device=dev, batch_poses=4, tapes=tapes)

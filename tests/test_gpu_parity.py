@@ -85,8 +85,15 @@ def test_native_library_is_loaded(setup):
     assert L.load().dbfr_build_id().decode() == build.source_hash()
 
 
+@pytest.fixture(params=["f32", "reduce_first"])
+def two_gemms(request, setup):
+    with gemm(setup[2], request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize("step", [0, 10, 19])
-def test_scores_match_reference_fixture(setup, dev, step, both_gemms):
+def test_scores_match_reference_fixture(setup, dev, step, two_gemms):
+    # (the per-edge fp16 mode `split_f16` left this matrix in round 6 -- GPU-suite time; it stays in the trajectory and per-conv tests)
     mcfg, params, model = setup
     d, z = load_golden_batch()
     sc = osched.step_scalars(osched.default_sample_cfg(), step)
@@ -445,6 +452,21 @@ def _fused_conv_and_reduce(setup, dev, layer, fam, name, kernel):
     L.check(lib.dbfr_test_reduce_ln(h, layer, fam, ptr(mrefd), ptr(rs), ptr(cntd), Nt, None, 0, ptr(outd), 2, None))
     torch.cuda.synchronize()
     assert rel_err(outd, out_ref) < 1e-5
+    if kernel == "k_convz":
+        # the FLAGGED reduction on its own (dbfr_test_reduce_ln2): k_convz's message buffer as the kernel left it -- segment sums in the flagged rows, the
+        # scalar columns of the other rows poisoned here -- must reduce to scatter-mean + LayerNorm of the reference messages (oracle.cluster.scatter +
+        # sm.layer_norm), not only inside full-model runs
+        poisoned = msg.clone()
+        sl = o3.Irreps(o).slices()
+        for k, mir in enumerate(o3.Irreps(o)):
+            if mir.ir.l == 0:
+                poisoned[(~first).to(dev), sl[k]] = float("nan")
+        flags = first.to(dev, torch.uint8).contiguous()
+        out2 = torch.zeros(Nt, Dout, device=dev)
+        L.check(lib.dbfr_test_reduce_ln2(h, layer, fam, ptr(poisoned), ptr(rs), ptr(cntd), Nt, None, 0, ptr(out2), 2, ptr(flags), None))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out2).all()
+        assert rel_err(out2, out_ref) < 1e-5
 
 
 def test_bitwise_reproducible(setup, dev):
@@ -799,9 +821,14 @@ def test_reduce_first_accuracy_against_float64(setup, dev):
     and to 2e-6 of the largest node sum in absolute terms."""
     mcfg, p, model = setup
     lib, h = L.load(), model.handle(dev)
-    for name, layer, fam, E in (("atom_conv_layers.3", 3, 2, 600), ("lig_conv_layers.0", 0, 0, 600), ("tor_bond_conv", -2, 0, 600)):
+    for name, layer, fam, E, outlier in (("atom_conv_layers.3", 3, 2, 600, 0), ("lig_conv_layers.0", 0, 0, 600, 0), ("tor_bond_conv", -2, 0, 600, 0),
+                                         ("atom_conv_layers.3", 3, 2, 600, 1), ("lig_conv_layers.0", 0, 0, 600, 2)):
         i, shirr, o, nef = sm.conv_specs(mcfg)[name]
         c = _random_conv_inputs(dev, layer, E)
+        if outlier == 1:      # ONE gathered node whose features are 3e4 x the others': the y scale is taken per chunk (per graph in the model), so every
+            c["x"] = c["x"].clone(); c["x"][5] *= 3e4      # other edge of that chunk is cut into fp16 pieces 15 binades below the largest
+        if outlier == 2:      # ... and one radial-MLP input row (the target's scalar features) 1e4 x the others': the per-edge input scale and the chunk's h scale
+            c["xt"] = c["xt"].clone(); c["xt"][3] *= 1e4
         if "tor" not in name:
             c["sh"] = o3.spherical_harmonics(shirr, torch.randn(E, 3, generator=torch.Generator().manual_seed(4)), True, "component").to(dev).contiguous()
         x, xt, emb, sh = (c[k].cpu().double() for k in ("x", "xt", "emb", "sh"))
@@ -819,9 +846,12 @@ def test_reduce_first_accuracy_against_float64(setup, dev):
                 m = _run_conv_hook(fn, h, layer, fam, c, E, dev)
             dm = (_node_sums(m, tgt, n) - s64) / col
             res[mode] = (float(dm.abs().max()), float(dm.pow(2).mean().sqrt()))
-        print(name, "node sums vs float64 (max, rms per column):", res)
-        assert res["reduce_first"][0] < 2e-6, (name, res)
-        assert res["reduce_first"][1] <= 2.5 * res["f32"][1] and res["reduce_first"][0] <= 4.0 * res["f32"][0], (name, res)
+        print(name, "outlier" if outlier else "", "node sums vs float64 (max, rms per column):", res)
+        assert res["reduce_first"][0] < (2e-6 if not outlier else 2e-5), (name, res)
+        if not outlier:
+            assert res["reduce_first"][1] <= 2.5 * res["f32"][1] and res["reduce_first"][0] <= 4.0 * res["f32"][0], (name, res)
+        else:      # an outlier costs the small values sharing its power of two their low bits: held to 10 x the fp32 instruction's error (and finite)
+            assert res["reduce_first"][1] <= 10.0 * res["f32"][1] and res["reduce_first"][0] <= 10.0 * res["f32"][0] + 1e-6, (name, res)
 
 
 def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, dev):
@@ -853,20 +883,20 @@ def test_split_gemm_is_no_less_accurate_than_the_fp32_matrix_instruction(setup, 
     assert err["split_f16"] <= err["f32"] and rms["split_f16"] <= rms["f32"], (err, rms)
 
 
-@pytest.mark.parametrize("cfg_id,min_atoms,min_lig,tag", [(5, 500, 60, "traj"), (2, 150, 20, "traj"), (2, 3 * 150, 3 * 20, "batch_traj"), (5, 2 * 500, 2 * 60, "batch_traj")])
+@pytest.mark.parametrize("cfg_id,min_atoms,min_lig,tag", [(5, 500, 60, "traj"), (2, 150, 20, "traj"), (2, 3 * 150, 3 * 20, "batch_traj")])
 def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms, min_lig, tag):
     """BASELINE configs[4] (~600 pocket atoms / ~80 ligand atoms) and configs[1] (~200 / ~30: the shape the bench line is quoted on) at
     their own shapes: tests/golden/cfg{5,2}_traj.npz hold one complex x one pose taken through all 20 steps by the ORACLE
     (tests/golden/make_oracle_fixtures.py, generated offline on host cores).  The HIP sampler must follow the ligand trajectory and
-    end on the same side chains within 1e-3 A, in every GEMM mode.  `batch_traj` (round 5): the same for a BATCH at those shapes -- 3 ragged
-    complexes x 2 poses of configs[1], 2 x 2 of configs[4], one collated batch through the oracle -- so that batch-level indexing (CSR
-    pointers, the per-graph edge chunks of the reduce-first conv, per-graph noise rows) is held to the oracle at full shape, not only to the
-    library itself (default mode + the fp32 instruction)."""
+    end on the same side chains within 1e-3 A, in every GEMM mode.  `batch_traj` (round 5): the same for a BATCH at configs[1]'s shape -- 3 ragged
+    complexes x 2 poses, one collated batch through the oracle -- so that batch-level indexing (CSR pointers, the per-graph edge chunks of the
+    reduce-first conv, per-graph noise rows) is held to the oracle at full shape, not only to the library itself (default mode + the fp32
+    instruction).  (configs[4] as a batch: test_cfg5_batch_scores_step_by_step -- no 20-step trajectory fixture can exist at that size.)
+    A fixture named in make_oracle_fixtures.py that is missing is a FAILURE, not a skip."""
     import os
     from tests.helpers import GOLDEN
     path = os.path.join(GOLDEN, f"cfg{cfg_id}_{tag}.npz")
-    if not os.path.exists(path):
-        pytest.skip(f"cfg{cfg_id}_{tag}.npz not generated (tests/golden/make_oracle_fixtures.py)")
+    assert os.path.exists(path), f"cfg{cfg_id}_{tag}.npz not generated (tests/golden/make_oracle_fixtures.py)"
     d, z = load_golden_batch(path)
     assert int(d.rec_atm_pos.shape[0]) >= min_atoms and int(d.lig_pos.shape[0]) >= min_lig
     params = sm.init_params(sm.default_cfg(), seed=int(z["params_seed"]))
@@ -883,6 +913,57 @@ def test_cfg_shape_trajectory_matches_the_oracle_fixture(dev, cfg_id, min_atoms,
         assert float(dl.max()) < POSE_ATOL, (mode, float(dl.max()))
         assert (a14[0].cpu() - torch.from_numpy(z["atom14_step0"])).norm(dim=-1).max() < POSE_ATOL, mode
         assert (a14[-1].cpu() - torch.from_numpy(z["final_atom14"])).norm(dim=-1).max() < POSE_ATOL, mode
+    model.set_gemm(DEFAULT_GEMM)
+    model.release()
+
+
+def test_cfg5_batch_scores_step_by_step(dev):
+    """BASELINE configs[4] as a BATCH (2 complexes x 2 poses: ~2 400 pocket atoms / ~300 ligand atoms, targets with more than 32 edges, 1000+-atom
+    batches -- what k_convz's chunk table and the CSR indexing see at that shape) against the ORACLE, step by step: tests/golden/cfg5_batch_steps.npz
+    holds the state the oracle's 20-step run is in entering steps 0, 6, 12 and 19 and the scores its model returns there.  The library is given that
+    state and must return those scores, graph by graph.  (A trajectory fixture cannot exist at this size: about one candidate pair per step lies
+    within 1e-6 A of a hard cutoff, see make_oracle_fixtures.py.)  A graph in which the library's own near-tie read-out (dbfr_model_set_tie_log, 2e-6 A)
+    flags a pair may have one edge more or less than the oracle's: it is held to 5 % instead of the score tolerance, and at most a third of the
+    (step, graph) pairs may need that."""
+    import os
+    from tests.helpers import GOLDEN
+    path = os.path.join(GOLDEN, "cfg5_batch_steps.npz")
+    assert os.path.exists(path), "cfg5_batch_steps.npz not generated (tests/golden/make_oracle_fixtures.py 55)"
+    d, z = load_golden_batch(path)
+    for k in [k for k in vars(d) if k.startswith("step")]:
+        delattr(d, k)
+    delattr(d, "steps")
+    G = d.num_graphs
+    assert int(d.rec_atm_pos.shape[0]) >= 2 * 2 * 500 and int(d.lig_pos.shape[0]) >= 2 * 2 * 60
+    model = dba.TensorProductModelHIP({}).to(dev)
+    model.load_state_dict(sm.init_params(sm.default_cfg(), seed=int(z["params_seed"])), strict=True)
+    lig_b, tor_b = d.lig_node_batch, d.lig_node_batch[d.lig_edge_index[0][d.tor_edge_mask.bool()]]
+    sc_b = d.rec_atm_pos_batch[d.torsion_edge_index[d.sc_torsion_edge_mask.bool()][:, 0]]      # graph of every flexible chi (tpscore.py: sc_torsion_edge_index)
+    loose = total = 0
+    for mode in ("reduce_first", "f32"):
+        model.set_gemm(mode)
+        for step in [int(x) for x in z["steps"]]:
+            dd = copy.deepcopy(d)
+            dd.lig_pos, dd.rec_atm_pos, dd.torsion_angle = (torch.from_numpy(z[f"step{step}_{k}"]) for k in ("lig_pos", "rec_atm_pos", "torsion_angle"))
+            sc = osched.step_scalars(osched.default_sample_cfg(), step)
+            ties = model.tie_log(dev, 1, G, tol=2e-6)
+            out = hip_scores(model, osampler.set_time(dd, sc, G), dev)
+            torch.cuda.synchronize()
+            tied = ties.cpu()[0].sum(0) > 0                      # [G]
+            model.tie_log(dev, 0, 0)
+            ref = [torch.from_numpy(z[f"step{step}_{k}"]) for k in ("tr", "rot", "tor", "sc_tor")]
+            for g in range(G):
+                rows = [slice(g, g + 1), slice(g, g + 1), (tor_b == g), (sc_b == g)]
+                worst = 0.0
+                for a, b, r in zip(out, ref, rows):
+                    a_g, b_g = a.cpu()[r], b[r]
+                    if b_g.numel():
+                        worst = max(worst, rel_err(a_g, b_g))
+                total += 1
+                tol = 5e-2 if bool(tied[g]) else SCORE_RTOL
+                loose += bool(tied[g])
+                assert worst < tol, (mode, step, g, worst, "near-tie flagged" if bool(tied[g]) else "no near-tie")
+    assert loose <= total // 3, (loose, total)
     model.set_gemm(DEFAULT_GEMM)
     model.release()
 
@@ -987,6 +1068,21 @@ def test_default_gemm_on_weights_nobody_has_seen(dev, dist):
             assert torch.isfinite(m).all(), (name, mode)
             dm = (m.cpu().double() - m64) / col
             res[mode] = (float(dm.abs().max()), float(dm.pow(2).mean().sqrt()))
+        # ... and the mode that IS the default since round 5, reduce_first (k_convz + vector-only k_conv2h): its message rows hold segment sums, so
+        # what is compared is what the scatter defines -- the per-node sums -- per output column, next to those of the fp32 instruction; the gate of
+        # test_reduce_first_accuracy_against_float64 (2.5 x rms / 4 x max of the fp32 instruction's, measured 1.1-1.8 / 1.5-2.5) on every distribution
+        # (the fixed Z scale 2^-20, the per-chunk y / h scales and the per-output-row W2' factors had seen seeded weights only)
+        s64 = _node_sums(m64, tgt, N)
+        coln = s64.abs().amax(dim=0).clamp_min(1e-300)
+        resn = {}
+        for mode, fn in (("f32", lib.dbfr_test_conv), ("reduce_first", lib.dbfr_test_conv2)):
+            with gemm(model, mode):
+                m = _run_conv_hook(fn, h, layer, fam, c, E, dev)
+            assert torch.isfinite(_node_sums(m, tgt, N)).all(), (name, mode)
+            dn = (_node_sums(m, tgt, N) - s64) / coln
+            resn[mode] = (float(dn.abs().max()), float(dn.pow(2).mean().sqrt()))
+        print(f"  {dist:10s} {name:24s} node sums: f32 {resn['f32'][0]:.2e} / {resn['f32'][1]:.2e}   reduce_first {resn['reduce_first'][0]:.2e} / {resn['reduce_first'][1]:.2e}")
+        assert resn["reduce_first"][1] <= 2.5 * resn["f32"][1] + 2e-8 and resn["reduce_first"][0] <= 4.0 * resn["f32"][0] + 1e-7, (name, resn)
         worst[name] = res
         print(f"  {dist:10s} {name:24s} max/rms per-column error vs float64: f32 {res['f32'][0]:.2e} / {res['f32'][1]:.2e}   "
               f"default {res['split_f16'][0]:.2e} / {res['split_f16'][1]:.2e}" + ("   (per-row factors)" if name in rowscaled else ""))

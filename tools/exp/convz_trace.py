@@ -2,8 +2,9 @@
 the cycles between the stamps of workgroup 0's first unit: 1 unit start, 2 slots done, 3 hidden layer done, 10 tile start, 11 step A done,
 12 step B done, 13 barrier passed."""
 import sys, numpy as np
-t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(12, 512)      # [wave][stamp]: waves 0..7 chunk waves, 8..11 column waves
-for w in range(12):
+NWV, CAP = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (12, 512)      # [wave][stamp]: role-split kernel 12 x 512 (waves 0..7 chunk waves, 8..11 column waves); round 5's kernel 8 x 1024
+t = np.fromfile(sys.argv[1], dtype=np.uint64)[:NWV * CAP].reshape(NWV, CAP)
+for w in range(NWV):
     v = t[w][t[w] > 0]
     tags, ts = (v & 0xff).astype(int), (v >> 8).astype(np.int64)
     if len(ts) == 0:
@@ -26,7 +27,7 @@ for w in range(12):
     if len(r):
         print(f"   tiles {len(r)}; mean cycles to [A done, B done, barrier passed, next tile] = {r.mean(0).round(0).tolist()}   median {np.median(r,0).tolist()}")
         per = r.reshape(-1, 10, 4) if len(r) % 10 == 0 else None
-        if w >= 8: per = None
+        if w >= 8 and NWV == 12: per = None
         if per is not None:
             print("   by k tile (mean over c tiles) [A, B, barrier]:", [per[:, k, :3].mean(0).round(0).astype(int).tolist() for k in range(10)])
         print("   first 12 tiles:", r[:12, :3].tolist())
