@@ -930,9 +930,8 @@ def test_cfg5_batch_scores_step_by_step(dev):
     path = os.path.join(GOLDEN, "cfg5_batch_steps.npz")
     assert os.path.exists(path), "cfg5_batch_steps.npz not generated (tests/golden/make_oracle_fixtures.py 55)"
     d, z = load_golden_batch(path)
-    for k in [k for k in vars(d) if k.startswith("step")]:
+    for k in [k for k in vars(d) if k.startswith("step")]:      # (the kept states and scores, and the list of their steps: not batch fields)
         delattr(d, k)
-    delattr(d, "steps")
     G = d.num_graphs
     assert int(d.rec_atm_pos.shape[0]) >= 2 * 2 * 500 and int(d.lig_pos.shape[0]) >= 2 * 2 * 60
     model = dba.TensorProductModelHIP({}).to(dev)
