@@ -45,7 +45,7 @@ void launch_edge_log(const GraphArgs& A, int* log_row, int stride, hipStream_t s
 void launch_edge_ties(const GraphArgs& A, int* log_row, int stride, float tol, hipStream_t st);
 void launch_graph_chunks(const GraphArgs& A, hipStream_t st);
 void launch_flat_chunks(const int* tgt, const int* n_edges, int max_edges, int span, int n_span, int* cnt0, int cap, int* chunk_es, int* chunk_gl, hipStream_t st);
-void launch_row_absmax(const float* x, int ld, int D, const int* ptr, int G, float* out, int n_rows, hipStream_t st);
+void launch_row_absmax(const float* lx, const int* lig_ptr, float* out_l, const float* ax, const int* atm_ptr, float* out_a, int ld, int D, int G, int n_rows_a, hipStream_t st);
 void launch_batch_vectors(const dbfr_batch& b, int* lig_batch, int* atm_batch, uint8_t* is_cab, int* n_cab,
                           int* tor_batch, int* sc_batch, hipStream_t st);
 void launch_time_embed(const float* t, int G, float emb_scale, float* temb, hipStream_t st);
@@ -1290,8 +1290,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
           conv2_desc(L2[3], LA.n_edges, LA.cap, LA.gth, LA.emb, LA.sh, ax, Di, LA.tgt, lx, Di, LA.gth, lx, Di, w.msg[3])};
       const int Ws[4] = {m->layer[l][0].W, m->layer[l][1].W, m->layer[l][2].W, m->layer[l][3].W};
       if (rf) {   // the y scale of k_convz: largest |x| per graph and node set (x = the rows a conv gathers: LL, LA read ligand rows, AL, AA pocket rows)
-        launch_row_absmax(lx, Di, Di, B->lig_ptr, G, w.xmax_l, NL, st);
-        launch_row_absmax(ax, Di, Di, B->atm_ptr, G, w.xmax_a, NA, st);
+        launch_row_absmax(lx, B->lig_ptr, w.xmax_l, ax, B->atm_ptr, w.xmax_a, Di, Di, G, NA, st);
       }
       auto zd = [&](int i, const EdgeSet& S, const float* xmax) { return convz_desc(ds[i], m->layerz[l][i], S.tgt, Do, S.chunk_es, S.chunk_gl, S.chunk0 + G, S.chunk_cap, xmax); };
       const ConvZDesc zs[4] = {zd(0, LL, w.xmax_l), zd(1, AL, w.xmax_a), zd(2, AA, w.xmax_a), zd(3, LA, w.xmax_l)};
@@ -1397,8 +1396,7 @@ static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, con
     const bool rf = m->gemm_split == DBFR_GEMM_REDUCE_FIRST && !((m->layer_fallback >> 31) & 1u);
     Conv2Desc ds[2]; ConvZDesc zs[2]; int Ws[2]; int nd = 0;
     if (rf) {
-      launch_row_absmax(lx, D, D, B->lig_ptr, G, w.xmax_l, NL, st);
-      launch_row_absmax(ax, D, D, B->atm_ptr, G, w.xmax_a, NA, st);
+      launch_row_absmax(lx, B->lig_ptr, w.xmax_l, ax, B->atm_ptr, w.xmax_a, D, D, G, NA, st);
     }
     if (do_t) {
       launch_bond_attr(lx, D, B->bond_src, B->bond_dst, B->tor_bond, 0, B->NTOR, w.tor_attr, st);

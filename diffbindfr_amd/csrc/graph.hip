@@ -560,10 +560,14 @@ void launch_flat_chunks(const int* tgt, const int* n_edges, int max_edges, int s
 // batch: a power of two derived from it must not depend on batch mates.  One workgroup per graph.
 // (four independent loads per thread and trip, and 1 024 threads where the graphs are large: a 3DBS-sized pocket behind ONE workgroup of 256 threads
 // with one load in flight took 26 us, a tenth of a 4-graph call's time.  A maximum does not depend on the order it is taken in.)
-__global__ __launch_bounds__(1024) void k_row_absmax(const float* x, int ld, int D, const int* ptr, float* out) {
-  const int NT = blockDim.x;
+__global__ __launch_bounds__(1024) void k_row_absmax(const float* x0, const int* ptr0, float* out0, const float* x1, const int* ptr1, float* out1, int ld, int D, int G) {
   __shared__ float sm[16];
-  const int g = blockIdx.x, r0 = ptr[g], r1 = ptr[g + 1];
+  const int NT = blockDim.x;
+  const bool second = (int)blockIdx.x >= G;                  // blocks [0, G): the first node set (ligand), [G, 2 G): the second (pocket atoms)
+  const int g = second ? blockIdx.x - G : blockIdx.x;
+  const float* x = second ? x1 : x0;
+  const int* ptr = second ? ptr1 : ptr0;
+  const int r0 = ptr[g], r1 = ptr[g + 1];
   const int d4 = D >> 2;
   const long n = (long)(r1 - r0) * d4;
   auto at = [&](long i) {
@@ -584,13 +588,14 @@ __global__ __launch_bounds__(1024) void k_row_absmax(const float* x, int ld, int
   if (threadIdx.x < 16) {
     m = (int)threadIdx.x < (NT >> 6) ? sm[threadIdx.x] : 0.f;
     for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (threadIdx.x == 0) out[g] = m;
+    if (threadIdx.x == 0) (second ? out1 : out0)[g] = m;
   }
 }
-void launch_row_absmax(const float* x, int ld, int D, const int* ptr, int G, float* out, int n_rows, hipStream_t st) {
+// both node sets of a layer in one launch (two launches per layer were 2-3 % of a 16-graph call)
+void launch_row_absmax(const float* lx, const int* lig_ptr, float* out_l, const float* ax, const int* atm_ptr, float* out_a, int ld, int D, int G, int n_rows_a, hipStream_t st) {
   if (G <= 0) return;
-  const int nt = (long)(n_rows / G) * (D >> 2) >= 16384 ? 1024 : 256;      // (mean float4s per graph: ~64 trips of 256 threads and up)
-  hipLaunchKernelGGL(k_row_absmax, dim3(G), dim3(nt), 0, st, x, ld, D, ptr, out);
+  const int nt = (long)(n_rows_a / G) * (D >> 2) >= 16384 ? 1024 : 256;      // (mean float4s per graph of the larger set: ~64 trips of 256 threads and up)
+  hipLaunchKernelGGL(k_row_absmax, dim3(2 * G), dim3(nt), 0, st, lx, lig_ptr, out_l, ax, atm_ptr, out_a, ld, D, G);
 }
 
 // dbfr_model_set_edge_log: per-graph edge counts of this step, log[k * G + g] = sum over the graph's target chunks

@@ -1,5 +1,7 @@
+#!/bin/bash
+# developer (round 6): the tree's library against tools/exp/ab/libdbfr_base.so (an older revision's api.cpp / conv.hip / graph.hip) -- same poses bit for bit? seconds per call?
 cd $GRAFT_REPO_ROOT
-python tools/exp/pose_hash.py cfg1 bs16 cfg1x40 c5p16
-echo "== tree"; bash tools/exp/r6_small.sh bs16 cfg1 2>&1 | grep "poses/s\|absmax\|span"
-echo "== base"; DBFR_LIB=$GRAFT_REPO_ROOT/tools/exp/ab/libdbfr_base.so bash tools/exp/r6_small.sh bs16 cfg1 2>&1 | grep "poses/s\|absmax\|span"
-cd $GRAFT_REPO_ROOT; bash tools/exp/bench_ab.sh 1 base tree
+for r in 1 2; do
+python tools/exp/pose_hash.py cfg1 bs16 cfg1x40 c5p16 p160
+DBFR_LIB=$GRAFT_REPO_ROOT/tools/exp/ab/libdbfr_base.so python tools/exp/pose_hash.py cfg1 bs16 cfg1x40 c5p16 p160
+done
