@@ -88,6 +88,8 @@ void launch_select_pocket(int n_prot, int n_res_total, const int* res_ptr, int m
                           const float* ref, float cut2, int max_neighbors, float* d2, unsigned char* out, hipStream_t st);
 void launch_acc_flops(const int* n_edges, double flops_per_edge, double bytes_per_edge, double fused_bytes_per_edge, double* counter, hipStream_t st);
 void launch_acc_executed(const int* n_edges, double flops_per_edge, double* counter, hipStream_t st);
+struct AccBatch { const int* n[32]; double coef[32]; double* dst[32]; int count; };   // (heads.hip)
+void launch_acc_batch(const AccBatch& b, hipStream_t st);
 // HBM bytes per edge of the FUSED conv (what the kernels of this library have to move): edge record (48 embedding floats, 9 harmonics,
 // 3 indices), two gathered 48-float rows for the radial MLP, the gathered D_in-float input row, the D_out-float message
 static inline double fused_bytes(int D_in, int D_out) { return 4.0 * (48 + 9 + 3 + 48 + 48 + D_in + D_out); }
@@ -1203,26 +1205,32 @@ static void conv2_call(dbfr_model* m, const Conv2Desc* descs, const int* Ws, int
   else if (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) launch_conv2h(a, st);
   else launch_conv2(a, st);   // DBFR_GEMM_F32, and a launch holding a conv that even per-row factors cannot fit into two fp16 pieces: the fp32 instruction
   if (m->profile == 1) (void)hipEventRecord(e1, st);
-  if (m->profile)
+  if (m->profile) {
+    AccBatch ab; ab.count = 0;
+    auto acc = [&](const int* ne, double coef, double* dst) { if (ab.count < 32) { ab.n[ab.count] = ne; ab.coef[ab.count] = coef; ab.dst[ab.count] = dst; ++ab.count; } };
     for (int i = 0; i < n; ++i) {
-      launch_acc_flops(descs[i].n_edges, 2.0 * 144 * (144.0 + Ws[i]), 4.0 * (Ws[i] + descs[i].w.D_in + 9) + 16.0, fused_bytes(descs[i].w.D_in, descs[i].w.D_out), m->flops_dev, st);
+      acc(descs[i].n_edges, 2.0 * 144 * (144.0 + Ws[i]), m->flops_dev);
+      acc(descs[i].n_edges, 4.0 * (Ws[i] + descs[i].w.D_in + 9) + 16.0, m->flops_dev + 1);
+      acc(descs[i].n_edges, fused_bytes(descs[i].w.D_in, descs[i].w.D_out), m->flops_dev + 2);
       // what the matrix pipe executes in the per-edge kernel of this launch: `products` MFMA flops per flop of the hidden layer and of the W2 rows it walks
       // (reduce-first: the vector-output rows only; the split kernels of round 2 keep the hidden layer on the fp32 instruction)
       const double rows = 16.0 * descs[i].w.n_tiles;
       const bool f16 = (m->gemm_split >= DBFR_GEMM_SPLIT_F16 && !f16_fallback) || z;
       const double ex = f16 ? 3.0 * 2.0 * 144 * (144.0 + rows) : 2.0 * 144 * (144.0 + rows);
-      if (!z || descs[i].w.n_tiles > 0) launch_acc_executed(descs[i].n_edges, ex, m->flops_dev + 3, st);
+      if (!z || descs[i].w.n_tiles > 0) acc(descs[i].n_edges, ex, m->flops_dev + 3);
       // ... of which are not padding: everything in the per-edge kernels, except that the pair of DBFR_GEMM_REDUCE_FIRST computes the hidden layer twice
       // (k_convz counts its own instructions and the useful ones among them itself, the hidden layer included)
-      if (!z) launch_acc_executed(descs[i].n_edges, ex, m->flops_dev + 4, st);
-      else if (descs[i].w.n_tiles > 0) launch_acc_executed(descs[i].n_edges, 3.0 * 2.0 * 144 * rows, m->flops_dev + 4, st);
+      if (!z) acc(descs[i].n_edges, ex, m->flops_dev + 4);
+      else if (descs[i].w.n_tiles > 0) acc(descs[i].n_edges, 3.0 * 2.0 * 144 * rows, m->flops_dev + 4);
       // HBM bytes of the form that RUNS: the fused form's, except that the pair reads the edge record and the gathered rows twice and writes the
       // scalar-output message columns once per SEGMENT (k_convz adds 4 x 48 per segment and irrep itself) and one flag byte per edge
       const int D_in = descs[i].w.D_in, D_out = descs[i].w.D_out;
       const double in_bytes = 4.0 * (48 + 9 + 3 + 48 + 48 + D_in);
-      if (!z) launch_acc_executed(descs[i].n_edges, fused_bytes(D_in, D_out), m->flops_dev + 5, st);
-      else launch_acc_executed(descs[i].n_edges, in_bytes + 1.0 + (descs[i].w.n_tiles > 0 ? in_bytes + 4.0 * (D_out - 48 * z[i].w.n_io) : 0.0), m->flops_dev + 5, st);
+      if (!z) acc(descs[i].n_edges, fused_bytes(D_in, D_out), m->flops_dev + 5);
+      else acc(descs[i].n_edges, in_bytes + 1.0 + (descs[i].w.n_tiles > 0 ? in_bytes + 4.0 * (D_out - 48 * z[i].w.n_io) : 0.0), m->flops_dev + 5);
     }
+    launch_acc_batch(ab, st);
+  }
 }
 
 static int run_score(dbfr_model* m, const dbfr_batch* B, const dbfr_cond* c, const dbfr_scores* out, Ws& w,
